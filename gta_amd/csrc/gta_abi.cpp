@@ -1,0 +1,157 @@
+// gta_abi.cpp -- extern "C" boundary of libgta_hip.so: argument validation, the chunk table that
+// encodes the reference's slab layout (gta.py:115-122), kernel dispatch.  No state, no allocation.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include "../../include/gta_hip.h"
+#include "gta_fwd_params.h"
+
+// chunk-descriptor constants (mirrors gta_common.h, which is device-only)
+#define HALF_ID 0u
+#define HALF_SE3 1u
+#define HALF_SO2 2u
+#define CHUNK_SO3 (1u << 4)
+
+int gta_fwd_lds_bytes(int dhp, int esz);
+int gta_fwd_dispatch(const GtaFwdParams& p, int dhp, int esz, bool dma, int n_wg, hipStream_t stream);
+
+namespace {
+
+thread_local const char* g_detail = "";
+
+int fail(int code, const char* why) { g_detail = why; return code; }
+
+int padded_dh(int dh) { return dh <= 32 ? 32 : dh <= 64 ? 64 : dh <= 96 ? 96 : dh <= 128 ? 128 : -1; }
+
+// Build the per-chunk descriptors for the fused kernels, or say why this layout needs the
+// generic (unfused) path.
+int build_ctab(const GtaAttnDesc* d, uint32_t* ctab) {
+    if (d->d_triv < 0 || d->d_se3 < 0 || d->d_so3 < 0 || d->d_so2 < 0 || d->d_t2 < 0)
+        return fail(GTA_E_LAYOUT, "negative slab size");
+    if (d->d_triv + d->d_se3 + d->d_so3 + d->d_so2 + d->d_t2 != d->dh)
+        return fail(GTA_E_LAYOUT, "f_dims do not sum to dh");
+    if (d->d_se3 % 4) return fail(GTA_E_LAYOUT, "se3 slab must be a multiple of 4 channels (gta.py:161)");
+    if (d->d_so2 % 4) return fail(GTA_E_LAYOUT, "so2 slab must be 4*nfreqs channels (gta.py:212-214)");
+    if (d->d_t2 % 3) return fail(GTA_E_LAYOUT, "t2 slab must be a multiple of 3 channels (gta.py:231)");
+    if (d->d_so3 > 0) {
+        int tot = 0;
+        for (int l = 1; l <= d->so3_degree; ++l) tot += 2 * l + 1;
+        if (d->so3_degree < 1 || d->d_so3 % tot) return fail(GTA_E_LAYOUT, "so3 slab must be r*sum(2l+1) channels (gta.py:182)");
+    }
+    if (d->dh % 8 || d->dh > 128) return fail(GTA_E_UNSUPPORTED, "fused kernel needs dh % 8 == 0 and dh <= 128");
+    if (d->d_t2 > 0) return fail(GTA_E_UNSUPPORTED, "t2 slab has no fused kernel (ablation; use the unfused path)");
+    if (d->flags & GTA_FLAG_EUCLID) return fail(GTA_E_UNSUPPORTED, "euclid similarity has no fused kernel");
+    if (d->d_so3 > 0 && (d->so3_degree != 2 || d->d_so3 % 8))
+        return fail(GTA_E_UNSUPPORTED, "fused so3 needs degree 2 ([3|5] groups of 8 channels)");
+    const int s_se3 = d->d_triv, s_so3 = s_se3 + d->d_se3, s_so2 = s_so3 + d->d_so3;
+    if (s_se3 % 4 || (d->d_so3 > 0 && s_so3 % 8) || s_so2 % 4)
+        return fail(GTA_E_UNSUPPORTED, "fused kernel needs 4-aligned se3/so2 slabs and an 8-aligned so3 slab");
+    for (int c = 0; c < 16; ++c) ctab[c] = 0;
+    for (int c = 0; c < d->dh / 8; ++c) {
+        uint32_t desc = 0;
+        const int lo = 8 * c, hi = 8 * c + 4;
+        if (d->d_so3 > 0 && lo >= s_so3 && lo < s_so2) { ctab[c] = CHUNK_SO3; continue; }
+        for (int half = 0; half < 2; ++half) {
+            const int ch = half ? hi : lo;
+            uint32_t kind = HALF_ID, blk = 0;
+            if (ch >= s_se3 && ch < s_so3) kind = HALF_SE3;
+            else if (ch >= s_so2 && ch < s_so2 + d->d_so2) { kind = HALF_SO2; blk = (uint32_t)(ch - s_so2) / 2; }
+            desc |= kind << (2 * half);
+            desc |= blk << (8 + 8 * half);
+        }
+        ctab[c] = desc;
+    }
+    return GTA_OK;
+}
+
+int check_common(const GtaAttnDesc* d) {
+    if (!d) return fail(GTA_E_BADARG, "null descriptor");
+    if (d->abi_version != GTA_ABI_VERSION) return fail(GTA_E_BADARG, "abi_version mismatch");
+    if (d->dtype != GTA_DTYPE_F32 && d->dtype != GTA_DTYPE_BF16) return fail(GTA_E_BADARG, "bad dtype");
+    if (d->B <= 0 || d->H <= 0 || d->Tq <= 0 || d->Tk <= 0 || d->dh <= 0) return fail(GTA_E_BADARG, "non-positive size");
+    if (d->Nq <= 0 || d->Nk <= 0 || d->Tq % d->Nq || d->Tk % d->Nk)
+        return fail(GTA_E_BADARG, "tokens must split evenly into views (gta.py:160-162)");
+    if (d->Nq > GTA_MAX_VIEWS || d->Nk > GTA_MAX_VIEWS) return fail(GTA_E_UNSUPPORTED, "more than GTA_MAX_VIEWS views per side");
+    if (d->Tq >= (1 << 22) || d->Tk >= (1 << 22)) return fail(GTA_E_UNSUPPORTED, "more than 2^22 tokens per side");
+    const int esz = d->dtype == GTA_DTYPE_BF16 ? 2 : 4;
+    const int64_t* st[4] = {d->q_stride, d->k_stride, d->v_stride, d->o_stride};
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 3; ++j)
+            if ((st[i][j] * esz) % 16) return fail(GTA_E_BADARG, "strides must keep every head row 16-byte aligned");
+    return GTA_OK;
+}
+
+}  // namespace
+
+extern "C" int gta_abi_version(void) { return GTA_ABI_VERSION; }
+extern "C" int gta_sizeof_attn_desc(void) { return (int)sizeof(GtaAttnDesc); }
+
+extern "C" const char* gta_strerror(int code) {
+    static thread_local char buf[256];
+    const char* base = "unknown";
+    switch (code) {
+        case GTA_OK: return "ok";
+        case GTA_E_BADARG: base = "bad argument"; break;
+        case GTA_E_LAYOUT: base = "inconsistent f_dims layout"; break;
+        case GTA_E_UNSUPPORTED: base = "unsupported by this build"; break;
+        case GTA_E_LAUNCH: base = "HIP launch failed"; break;
+        case GTA_E_NODEVICE: base = "no HIP device"; break;
+    }
+    snprintf(buf, sizeof buf, "%s: %s", base, g_detail);
+    return buf;
+}
+
+extern "C" int gta_attn_fwd_supported(const GtaAttnDesc* desc) {
+    int rc = check_common(desc);
+    if (rc) return rc;
+    uint32_t ctab[16];
+    return build_ctab(desc, ctab);
+}
+
+extern "C" int gta_attn_fwd_launch_info(const GtaAttnDesc* desc, int32_t* lds_bytes, int32_t* n_workgroups,
+                                        int32_t* threads_per_wg) {
+    int rc = gta_attn_fwd_supported(desc);
+    if (rc) return rc;
+    const int esz = desc->dtype == GTA_DTYPE_BF16 ? 2 : 4;
+    if (lds_bytes) *lds_bytes = gta_fwd_lds_bytes(padded_dh(desc->dh), esz);
+    if (n_workgroups) *n_workgroups = desc->B * desc->H * ((desc->Tq + 127) / 128);
+    if (threads_per_wg) *threads_per_wg = 256;
+    return GTA_OK;
+}
+
+extern "C" int gta_attn_fwd(const GtaAttnDesc* d, const void* q, const void* k, const void* v,
+                            const float* vrep_q, const float* vrep_k, const float* cs_q, const float* cs_k,
+                            const float* trans_coeff, const float* tau, void* out, float* lse, void* stream) {
+    int rc = check_common(d);
+    if (rc) return rc;
+    if (!q || !k || !v || !out) return fail(GTA_E_BADARG, "null q/k/v/out");
+    GtaFwdParams p;
+    memset(&p, 0, sizeof p);
+    rc = build_ctab(d, p.ctab);
+    if (rc) return rc;
+    const bool pre = (d->flags & GTA_FLAG_PRETRANSFORMED) != 0;
+    const bool need_view = d->d_se3 > 0 || d->d_so3 > 0;
+    const bool need_cs = d->d_so2 > 0;
+    if (need_view && (!vrep_q || (!pre && !vrep_k))) return fail(GTA_E_BADARG, "se3/so3 slabs need vrep_q and vrep_k");
+    if (need_cs && (!cs_q || (!pre && !cs_k))) return fail(GTA_E_BADARG, "so2 slab needs cs_q and cs_k");
+    const int esz = d->dtype == GTA_DTYPE_BF16 ? 2 : 4;
+    p.q = q; p.k = k; p.v = v; p.o = out; p.lse = lse;
+    p.vrep_q = need_view ? vrep_q : nullptr; p.vrep_k = need_view ? vrep_k : nullptr;
+    p.cs_q = need_cs ? cs_q : nullptr; p.cs_k = need_cs ? cs_k : nullptr;
+    p.trans_coeff = trans_coeff; p.tau = tau;
+    p.q_sb = d->q_stride[0]; p.q_sh = d->q_stride[1]; p.q_st = d->q_stride[2];
+    p.k_sb = d->k_stride[0]; p.k_sh = d->k_stride[1]; p.k_st = d->k_stride[2];
+    p.v_sb = d->v_stride[0]; p.v_sh = d->v_stride[1]; p.v_st = d->v_stride[2];
+    p.o_sb = d->o_stride[0]; p.o_sh = d->o_stride[1]; p.o_st = d->o_stride[2];
+    p.B = d->B; p.H = d->H; p.Tq = d->Tq; p.Tk = d->Tk; p.Nq = d->Nq; p.Nk = d->Nk;
+    p.Pq = d->Tq / d->Nq; p.Pk = d->Tk / d->Nk;
+    p.invPq = 1.0f / (float)p.Pq; p.invPk = 1.0f / (float)p.Pk;
+    p.dh = d->dh; p.nso2 = d->d_so2 / 2;
+    p.n_qtiles = (d->Tq + 127) / 128;
+    p.flags = d->flags; p.scale = d->scale;
+    const long n_wg = (long)d->B * d->H * p.n_qtiles;
+    if (n_wg > 0x7fffffffL) return fail(GTA_E_UNSUPPORTED, "grid too large");
+    rc = gta_fwd_dispatch(p, padded_dh(d->dh), esz, !(d->flags & GTA_FLAG_NO_DMA), (int)n_wg, (hipStream_t)stream);
+    if (rc) return fail(rc, rc == GTA_E_LAUNCH ? hipGetErrorString(hipGetLastError()) : "no kernel instance");
+    return GTA_OK;
+}

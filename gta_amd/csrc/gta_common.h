@@ -1,0 +1,195 @@
+// gta_common.h -- device helpers shared by the gfx950 GTA kernels.
+//
+// Data model used by every kernel in this directory
+//   * a head's dh channels are cut into 8-channel CHUNKS (16 B of bf16 = one ds_read_b128 /
+//     one MFMA operand fragment).  A chunk is two 4-channel HALVES.  The reference's
+//     block-diagonal reps (gta.py:160-219) never straddle a chunk when the slab offsets are
+//     8-aligned (true for every shipped config), so rho acts on a chunk as:
+//        half kind ID   : identity                      (triv slab, gta.py:127-132)
+//        half kind SE3  : one 4x4 per-VIEW matrix       (gta.py:160-168)
+//        half kind SO2  : two 2x2 per-TOKEN rotations   (gta.py:212-219)
+//        chunk kind SO3 : [D^1 (3x3) | D^2 (5x5)] per view (gta.py:174-201, degree-2 layout)
+//   * a chunk descriptor (uint32) says which; it is wave-uniform wherever it is used, so the
+//     type switch is a scalar branch, never lane divergence.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+#define GTA_DEV __device__ __forceinline__
+
+// ---- chunk descriptor -----------------------------------------------------------------------
+#define GTA_HALF_ID  0u
+#define GTA_HALF_SE3 1u
+#define GTA_HALF_SO2 2u
+#define GTA_CHUNK_SO3 (1u << 4)
+#define GTA_CHUNK_ZERO (1u << 5)   // padding chunk beyond dh (fused kernels pad dh up to 32k)
+GTA_DEV uint32_t cd_lo(uint32_t d) { return d & 3u; }
+GTA_DEV uint32_t cd_hi(uint32_t d) { return (d >> 2) & 3u; }
+GTA_DEV uint32_t cd_so2_lo(uint32_t d) { return (d >> 8) & 0xffu; }   // first so2 block of the lo half
+GTA_DEV uint32_t cd_so2_hi(uint32_t d) { return (d >> 16) & 0xffu; }  // first so2 block of the hi half
+
+// ---- bf16 <-> f32 -------------------------------------------------------------------------------
+GTA_DEV uint32_t pack_bf16x2(float lo, float hi) {
+    f32x2_t v = {lo, hi};
+    bf16x2_t b = __builtin_convertvector(v, bf16x2_t);   // v_cvt_pk_bf16_f32 (RNE) on gfx950
+    return __builtin_bit_cast(uint32_t, b);
+}
+GTA_DEV float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
+GTA_DEV float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+GTA_DEV void unpack8(const u32x4_t w, float* x) {
+    x[0] = bf16_lo(w.x); x[1] = bf16_hi(w.x); x[2] = bf16_lo(w.y); x[3] = bf16_hi(w.y);
+    x[4] = bf16_lo(w.z); x[5] = bf16_hi(w.z); x[6] = bf16_lo(w.w); x[7] = bf16_hi(w.w);
+}
+GTA_DEV u32x4_t pack8(const float* x) {
+    u32x4_t w;
+    w.x = pack_bf16x2(x[0], x[1]); w.y = pack_bf16x2(x[2], x[3]);
+    w.z = pack_bf16x2(x[4], x[5]); w.w = pack_bf16x2(x[6], x[7]);
+    return w;
+}
+
+// ---- LDS tile swizzle -----------------------------------------------------------------------
+// A tile is rows x UNITS 16-byte units.  Unit `u` of row `r` lives at position swz<UNITS>(r,u):
+// a per-row ROTATION chosen so that 16 rows distinct mod 16 reading the same logical unit with
+// ds_read_b128 touch 16 distinct 16-B slots of the 256-B bank row (conflict-free both for the
+// lane==row staging reads and for the MFMA fragment reads).  tests/test_host_logic.py brute
+// forces this against the ds_read_b128 lane groups of MI355X_MICROARCH.md.
+template <int UNITS>
+GTA_DEV int swz(int r, int u) {
+    constexpr int tz = (UNITS % 16 == 0) ? 4 : (UNITS % 8 == 0) ? 3 : (UNITS % 4 == 0) ? 2
+                       : (UNITS % 2 == 0) ? 1 : 0;
+    const int rot = (r >> (4 - tz)) & ((1 << tz) - 1);
+    int p = u + rot;
+    return p >= UNITS ? p - UNITS : p;
+}
+
+// ---- small block transforms (all in fp32 registers) ------------------------------------------
+GTA_DEV void mat4_apply(const float* M, float* x) {           // x[0..3] <- M(4x4 row-major) x
+    const float a = x[0], b = x[1], c = x[2], d = x[3];
+    x[0] = M[0] * a + M[1] * b + M[2] * c + M[3] * d;
+    x[1] = M[4] * a + M[5] * b + M[6] * c + M[7] * d;
+    x[2] = M[8] * a + M[9] * b + M[10] * c + M[11] * d;
+    x[3] = M[12] * a + M[13] * b + M[14] * c + M[15] * d;
+}
+GTA_DEV void mat3_apply_p4(const float* M, float* x) {        // rows padded to 4 floats
+    const float a = x[0], b = x[1], c = x[2];
+    x[0] = M[0] * a + M[1] * b + M[2] * c;
+    x[1] = M[4] * a + M[5] * b + M[6] * c;
+    x[2] = M[8] * a + M[9] * b + M[10] * c;
+}
+GTA_DEV void mat5_apply_p8(const float* M, float* x) {        // rows padded to 8 floats
+    const float a = x[0], b = x[1], c = x[2], d = x[3], e = x[4];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+        x[i] = M[8 * i] * a + M[8 * i + 1] * b + M[8 * i + 2] * c + M[8 * i + 3] * d + M[8 * i + 4] * e;
+}
+// (c, s) rotation [[c,-s],[s,c]] (gta.py:64-67); INV = transpose
+template <bool INV>
+GTA_DEV void rot2_apply(float c, float s, float* x) {
+    const float a = x[0], b = x[1];
+    if (INV) { x[0] = c * a + s * b; x[1] = c * b - s * a; }
+    else     { x[0] = c * a - s * b; x[1] = s * a + c * b; }
+}
+
+// LDS -> registers for the small per-view matrices (all lanes of a view read the same address:
+// broadcast, no bank conflict)
+GTA_DEV void lds_load16(const float* p, float* M) {
+    const f32x4_t* v = reinterpret_cast<const f32x4_t*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f32x4_t t = v[i]; M[4*i] = t.x; M[4*i+1] = t.y; M[4*i+2] = t.z; M[4*i+3] = t.w; }
+}
+template <int N4>
+GTA_DEV void lds_loadN4(const float* p, float* M) {
+    const f32x4_t* v = reinterpret_cast<const f32x4_t*>(p);
+#pragma unroll
+    for (int i = 0; i < N4; ++i) { f32x4_t t = v[i]; M[4*i] = t.x; M[4*i+1] = t.y; M[4*i+2] = t.z; M[4*i+3] = t.w; }
+}
+
+// Per-view records staged in LDS by the attention kernels (floats):
+//   q side: [  0: 16) Aq  = (E (.) m)^T      applied to Q           (gta.py:165)
+//           [ 16: 32) Oq  =  E (.) m         applied to the output  (gta.py:255-257)
+//           [ 32: 44) D1q (rows padded to 4) [ 44: 84) D2q (rows padded to 8)   (gta.py:193-194)
+//           [ 84: 96) D1q^T                  [ 96:136) D2q^T                    (gta.py:259-267)
+//   k side: [  0: 16) Bk  = inv(E) (.) m     applied to K and V     (gta.py:166-168)
+//           [ 16: 28) D1k                    [ 28: 68) D2k
+// with m the trans_coeff mask of gta.py:40-44.
+#define GTA_QREC 136
+#define GTA_KREC 68
+#define GTA_QREC_A 0
+#define GTA_QREC_O 16
+#define GTA_QREC_D1 32
+#define GTA_QREC_D2 44
+#define GTA_QREC_D1T 84
+#define GTA_QREC_D2T 96
+#define GTA_KREC_B 0
+#define GTA_KREC_D1 16
+#define GTA_KREC_D2 28
+
+// Apply one chunk's rho to up to two 8-vectors that share it (K and V of one token).
+//   se3  : LDS pointer to the 4x4 to use (already masked / transposed as the caller needs)
+//   d1,d2: LDS pointers to padded D^1 / D^2 (or their transposes)
+//   cs   : this token's (cos,sin) pairs for the chunk: cs[0..1] lo half, cs[2..3] hi half
+template <bool SO2_INV, int NV>
+GTA_DEV void chunk_apply(uint32_t desc, const float* se3, const float* d1, const float* d2,
+                         const f32x2_t* cs, float (*x)[8]) {
+    if (desc & GTA_CHUNK_SO3) {
+        float M1[12], M2[40];
+        lds_loadN4<3>(d1, M1);
+        lds_loadN4<10>(d2, M2);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) { mat3_apply_p4(M1, x[v]); mat5_apply_p8(M2, x[v] + 3); }
+        return;
+    }
+    const uint32_t lo = cd_lo(desc), hi = cd_hi(desc);
+    if (lo == GTA_HALF_SE3 || hi == GTA_HALF_SE3) {
+        float M[16];
+        lds_load16(se3, M);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            if (lo == GTA_HALF_SE3) mat4_apply(M, x[v]);
+            if (hi == GTA_HALF_SE3) mat4_apply(M, x[v] + 4);
+        }
+    }
+    if (lo == GTA_HALF_SO2) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            rot2_apply<SO2_INV>(cs[0].x, cs[0].y, x[v]);
+            rot2_apply<SO2_INV>(cs[1].x, cs[1].y, x[v] + 2);
+        }
+    }
+    if (hi == GTA_HALF_SO2) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            rot2_apply<SO2_INV>(cs[2].x, cs[2].y, x[v] + 4);
+            rot2_apply<SO2_INV>(cs[3].x, cs[3].y, x[v] + 6);
+        }
+    }
+}
+
+// Load the (cos,sin) pairs a chunk needs for token row `t` of a [T, nso2] float2 table.
+GTA_DEV void load_cs(uint32_t desc, const float* __restrict__ cs_row, f32x2_t* cs) {
+    if (desc & GTA_CHUNK_SO3) return;
+    if (cd_lo(desc) == GTA_HALF_SO2) {
+        const f32x4_t t = *reinterpret_cast<const f32x4_t*>(cs_row + 2 * cd_so2_lo(desc));
+        cs[0] = f32x2_t{t.x, t.y}; cs[1] = f32x2_t{t.z, t.w};
+    }
+    if (cd_hi(desc) == GTA_HALF_SO2) {
+        const f32x4_t t = *reinterpret_cast<const f32x4_t*>(cs_row + 2 * cd_so2_hi(desc));
+        cs[2] = f32x2_t{t.x, t.y}; cs[3] = f32x2_t{t.z, t.w};
+    }
+}
+
+// view index of token t when every view has P tokens: exact for t < 2^22 (float estimate + fix)
+GTA_DEV int view_of(int t, int P, float invP) {
+    int n = (int)((float)t * invP);
+    if (n * P > t) --n;
+    if ((n + 1) * P <= t) ++n;
+    return n;
+}

@@ -1,0 +1,17 @@
+// gta_fwd_params.h -- kernel argument block of the fused forward (host fills it in gta_abi.cpp).
+#pragma once
+#include <stdint.h>
+
+struct GtaFwdParams {
+    const void* q; const void* k; const void* v; void* o; float* lse;
+    const float* vrep_q; const float* vrep_k;   // [B,N,GTA_VREP_STRIDE]
+    const float* cs_q; const float* cs_k;       // [B,T,nso2,2] (cos,sin)
+    const float* trans_coeff; const float* tau; // device scalars or null
+    long q_sb, q_sh, q_st, k_sb, k_sh, k_st, v_sb, v_sh, v_st, o_sb, o_sh, o_st;  // element strides
+    int B, H, Tq, Tk, Nq, Nk, Pq, Pk;           // P* = tokens per view
+    float invPq, invPk;
+    int dh, nso2, n_qtiles;
+    uint32_t flags;
+    float scale;
+    uint32_t ctab[16];                          // chunk descriptors (gta_common.h)
+};

@@ -1,0 +1,203 @@
+"""Functional GTA operator on MI355X -- host-side mirror of ``source/utils/gta.py``.
+
+``multihead_geometric_transform_attention`` keeps the reference's name, argument meaning and
+``reps`` dict contract (gta.py:92-279) but runs the whole operator as one fused HIP kernel.
+What differs, deliberately:
+  * the dense attention matrix is never formed, so the second return value is ``None``
+    (the reference only consumes it under ``return_attmap``, layers.py:441-442);
+  * ``attn_fn`` is accepted for signature compatibility; its ``scale`` attribute is honoured,
+    the softmax itself is the kernel's.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import native
+
+GROUP_ORDER = ("triv", "se3", "so3", "so2", "t2")   # gta.py:115
+
+
+def make_2dcoord(H: int, W: int) -> np.ndarray:
+    """[H, W, 2] with entry (i, j) = (i/H, j/W)   (gta.py:9-16)."""
+    r = np.arange(H, dtype=np.float32) / H
+    c = np.arange(W, dtype=np.float32) / W
+    rr, cc = np.meshgrid(r, c, indexing="ij")
+    return np.stack([rr, cc], -1)
+
+
+def make_SO2mats(coord: torch.Tensor, nfreqs: int, max_freqs=(1, 1), shared_freqs: bool = False) -> torch.Tensor:
+    """[..., F, 2, 2, 2] rotation blocks like gta.py:47-69, built from the device (cos,sin) table."""
+    lead = coord.shape[:-1]
+    cs = native.build_so2_table(coord.reshape(1, -1, 2), nfreqs, max_freqs[0], max_freqs[1], shared_freqs)
+    c, s = cs[0, ..., 0], cs[0, ..., 1]                       # [T, 2F]
+    m = torch.stack([torch.stack([c, -s], -1), torch.stack([s, c], -1)], -2)   # [T, 2F, 2, 2]
+    return m.reshape(*lead, nfreqs, 2, 2, 2)
+
+
+# --------------------------------------------------------------------------------------------
+# reps: reference-style dict  ->  packed device tables the kernels read
+# --------------------------------------------------------------------------------------------
+def _pack_view(inv: Optional[torch.Tensor], rep: Optional[torch.Tensor], Ds) -> torch.Tensor:
+    ref = inv if inv is not None else (rep if rep is not None else Ds[0])
+    B, N = ref.shape[:2]
+    out = torch.zeros(B, N, native.VREP_STRIDE, device=ref.device, dtype=torch.float32)
+    if inv is not None:
+        out[..., native.VREP_INV:native.VREP_INV + 16] = inv.detach().reshape(B, N, 16)
+    if rep is not None:
+        out[..., native.VREP_REP:native.VREP_REP + 16] = rep.detach().reshape(B, N, 16)
+    if Ds:
+        out[..., native.VREP_D1:native.VREP_D1 + 9] = Ds[0].detach().reshape(B, N, 9)
+        if len(Ds) > 1:
+            out[..., native.VREP_D2:native.VREP_D2 + 25] = Ds[1].detach().reshape(B, N, 25)
+    return out
+
+
+def _pack_so2(rep: torch.Tensor) -> torch.Tensor:
+    """[B,T,C,2,2] rotation blocks -> [B,T,C,2] (cos, sin) = (M[0,0], M[1,0])."""
+    return torch.stack([rep[..., 0, 0], rep[..., 1, 0]], -1).detach().to(torch.float32).contiguous()
+
+
+def pack_reps(reps: dict, f_dims: dict) -> dict:
+    """Return (and cache in ``reps``) the packed tables for a reference-style ``reps`` dict.
+
+    Accepts either the packed keys written by ``gta_amd.reps.pre_compute_reps_*``
+    (``gta_vrep_q/k``, ``gta_cs_q/k``) or the reference's own tensors (``se3rep_q/k``,
+    ``inv_se3rep_q``, ``so3rep_q/k`` lists, ``so2rep_q/k``; encoder.py:197,235-236,259).
+    """
+    need_view = f_dims.get("se3", 0) > 0 or f_dims.get("so3", 0) > 0
+    need_so2 = f_dims.get("so2", 0) > 0
+    out = {}
+    if need_view:
+        for side in ("q", "k"):
+            key = f"gta_vrep_{side}"
+            # the packed table is tied to the tensors it was built from (decoder replaces *_q)
+            src = (id(reps.get(f"se3rep_{side}")), id(reps.get("inv_se3rep_q")) if side == "q" else 0,
+                   id(reps.get(f"so3rep_{side}")))
+            if key not in reps or reps.get(key + "_src", src) != src:
+                Ds = list(reps.get(f"so3rep_{side}", [])) if f_dims.get("so3", 0) > 0 else []
+                reps[key] = _pack_view(reps.get("inv_se3rep_q") if side == "q" else None,
+                                       reps.get(f"se3rep_{side}"), Ds)
+                reps[key + "_src"] = src
+            out[f"vrep_{side}"] = reps[key]
+    if need_so2:
+        for side in ("q", "k"):
+            key = f"gta_cs_{side}"
+            src = id(reps.get(f"so2rep_{side}"))
+            if key not in reps or reps.get(key + "_src", src) != src:
+                reps[key] = _pack_so2(reps[f"so2rep_{side}"])
+                reps[key + "_src"] = src
+            out[f"cs_{side}"] = reps[key]
+    return out
+
+
+def _so3_degree(f_dims: dict, packed: dict, reps: dict) -> int:
+    if f_dims.get("so3", 0) <= 0:
+        return 0
+    if "gta_so3_degree" in reps:
+        return int(reps["gta_so3_degree"])
+    return len(reps["so3rep_q"])
+
+
+def _views(f_dims, packed, q, k) -> Tuple[int, int]:
+    if "vrep_q" in packed:
+        return packed["vrep_q"].shape[1], packed["vrep_k"].shape[1]
+    return 1, 1
+
+
+# --------------------------------------------------------------------------------------------
+# autograd wrapper around the C ABI
+# --------------------------------------------------------------------------------------------
+def _as_kernel_layout(t: torch.Tensor) -> torch.Tensor:
+    """[B,H,T,dh] view usable by the kernel as is (unit channel stride, 16-B aligned rows)."""
+    esz = t.element_size()
+    ok = t.stride(3) == 1 and t.data_ptr() % 16 == 0 and all((s * esz) % 16 == 0 for s in t.stride()[:3])
+    return t if ok else t.contiguous()
+
+
+class _GtaAttn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, trans_coeff, tau, f_dims_t, cfg, vrep_q, vrep_k, cs_q, cs_k):
+        f_dims, so3_degree, Nq, Nk, scale, flags = cfg
+        dt = q.dtype
+        if dt not in (torch.float32, torch.bfloat16):
+            raise native.GtaError(f"unsupported dtype {dt}: use float32 or bfloat16")
+        k = k.to(dt) if k.dtype != dt else k
+        v = v.to(dt) if v.dtype != dt else v
+        q, k, v = _as_kernel_layout(q), _as_kernel_layout(k), _as_kernel_layout(v)
+        B, H, Tq, dh = q.shape
+        # out is allocated [B,Tq,H,dh] so the caller's 'b h n d -> b n (h d)' is a free view
+        out = torch.empty(B, Tq, H, dh, device=q.device, dtype=dt).permute(0, 2, 1, 3)
+        lse = torch.empty(B, H, Tq, device=q.device, dtype=torch.float32)
+        tc = trans_coeff.detach().to(torch.float32).reshape(-1) if trans_coeff is not None else None
+        ta = tau.detach().to(torch.float32).reshape(-1) if tau is not None else None
+        desc = native.make_desc(q, k, v, out, f_dims, so3_degree, Nq, Nk, scale, flags)
+        native.attn_fwd(desc, q, k, v, vrep_q, vrep_k, cs_q, cs_k, tc, ta, out, lse)
+        ctx.cfg = cfg
+        ctx.save_for_backward(q, k, v, out, lse, tc, ta, vrep_q, vrep_k, cs_q, cs_k)
+        ctx.tc_shape = None if trans_coeff is None else trans_coeff.shape
+        ctx.tc_dtype = None if trans_coeff is None else trans_coeff.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import backward as _bw
+        q, k, v, out, lse, tc, ta, vrep_q, vrep_k, cs_q, cs_k = ctx.saved_tensors
+        if ta is not None and ctx.needs_input_grad[4]:
+            raise native.GtaError("gradient w.r.t. the adjustable softmax temperature is not implemented")
+        dq, dk, dv, dtc = _bw.attn_bwd(ctx.cfg, q, k, v, out, dout, lse, tc, ta, vrep_q, vrep_k, cs_q, cs_k)
+        if ctx.tc_shape is not None and dtc is not None:
+            dtc = dtc.reshape(ctx.tc_shape).to(ctx.tc_dtype)
+        else:
+            dtc = None
+        return dq, dk, dv, dtc, None, None, None, None, None, None, None
+
+
+def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: int = 0,
+                  trans_coeff=None, tau=None, scale: Optional[float] = None, v_transform: bool = True,
+                  euclid: bool = False, pretransformed: bool = False, use_dma: bool = True) -> torch.Tensor:
+    """Fused GTA attention on packed reps.  q [B,H,Tq,dh], k/v [B,H,Tk,dh] -> out [B,H,Tq,dh]."""
+    if scale is None:
+        scale = q.shape[-1] ** -0.5
+    flags = 0
+    if v_transform:
+        flags |= native.FLAG_V_TRANSFORM
+    if euclid:
+        flags |= native.FLAG_EUCLID
+    if pretransformed:
+        flags |= native.FLAG_PRETRANSFORMED
+    if not use_dma:
+        flags |= native.FLAG_NO_DMA
+    Nq, Nk = _views(f_dims, packed, q, k)
+    cfg = ({k_: int(v_) for k_, v_ in f_dims.items()}, int(so3_degree), Nq, Nk, float(scale), flags)
+    if isinstance(trans_coeff, (int, float)):
+        trans_coeff = torch.tensor([float(trans_coeff)], device=q.device, dtype=torch.float32)
+    if isinstance(tau, (int, float)):
+        tau = None if float(tau) == 1.0 else torch.tensor([float(tau)], device=q.device, dtype=torch.float32)
+    return _GtaAttn.apply(q, k, v, trans_coeff, tau, None, cfg, packed.get("vrep_q"), packed.get("vrep_k"),
+                          packed.get("cs_q"), packed.get("cs_k"))
+
+
+def multihead_geometric_transform_attention(q, k, v, attn_fn=None, f_dims=None, reps=None,
+                                            trans_coeff=1.0, v_transform=True, euclid=False, **kwargs):
+    """Drop-in for gta.py:92-279.  Returns ``(out_t, None)``.
+
+    Args mirror the reference: q [B,H,Nq*Tq,C]; k, v [B,H,Nk*Tk,C]; ``f_dims`` the slab sizes;
+    ``reps`` the dict filled by ``pre_compute_reps`` (reference-style tensors or this package's
+    packed tables); ``trans_coeff`` a scalar or the layer's 1-element parameter.
+    """
+    if f_dims is None or reps is None:
+        raise TypeError("f_dims and reps are required")
+    f_dims = {k_: v_ for k_, v_ in f_dims.items() if k_ in GROUP_ORDER}
+    packed = pack_reps(reps, f_dims)
+    scale = getattr(attn_fn, "scale", None)
+    tau = kwargs.get("tau", getattr(attn_fn, "tau", None))
+    if f_dims.get("se3", 0) <= 0:
+        trans_coeff = None
+    out = gta_attention(q, k, v, f_dims, packed, so3_degree=_so3_degree(f_dims, packed, reps),
+                        trans_coeff=trans_coeff, tau=tau, scale=scale, v_transform=v_transform, euclid=euclid,
+                        use_dma=kwargs.get("use_dma", True))
+    return out, None

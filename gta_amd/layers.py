@@ -1,0 +1,166 @@
+"""Transformer blocks with GTA attention -- drop-ins for ``source/layers.py``.
+
+Same constructor arguments, ``forward`` signatures, ``extras`` contract and state-dict keys as
+the reference's ``Attention`` (layers.py:172-444), ``Transformer`` (:447-488), ``PreNorm``
+(:146-154), ``FeedForward`` (:157-169), ``JaxLinear`` (:14-25) and ``ViTLinear`` (:28-37), so a
+reference checkpoint loads with ``load_state_dict(strict=True)``.  The attention core is the
+fused HIP kernel; projections, LayerNorm and the MLP stay PyTorch-ROCm (rocBLAS/hipBLASLt).
+Only ``method: gta`` is built -- the other positional-encoding baselines of the reference
+(repast/ape/mln/gbt/rpe/frustum) are out of scope.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+from torch.nn import init
+
+from . import gta as _gta
+from . import native
+
+
+class JaxLinear(nn.Linear):
+    """Truncated-normal(std = fan_in^-1/2, +-2 std) weights, zero bias (layers.py:14-25)."""
+
+    def reset_parameters(self):
+        std = math.sqrt(1.0 / self.weight.shape[-1])
+        init.trunc_normal_(self.weight, std=std, a=-2.0 * std, b=2.0 * std)
+        if self.bias is not None:
+            init.zeros_(self.bias)
+
+
+class ViTLinear(nn.Linear):
+    """Xavier-uniform weights, N(0, 1e-6) bias (layers.py:28-37)."""
+
+    def reset_parameters(self):
+        init.xavier_uniform_(self.weight)
+        if self.bias is not None:
+            init.normal_(self.bias, std=1e-6)
+
+
+class TemperatureAdjustableSoftmax(nn.Module):
+    """Holds the learnable temperature ``tau`` (layers.py:135-143); the softmax runs in the kernel."""
+
+    def __init__(self, init_tau=1.0):
+        super().__init__()
+        self.tau = nn.Parameter(torch.tensor([float(init_tau)]))
+
+
+class PreNorm(nn.Module):
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+        self.fn = fn
+
+    def forward(self, x, **kwargs):
+        return self.fn(self.norm(x), **kwargs)   # LayerNorm on x only, never on z (layers.py:153-154)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, hidden_dim, dropout=0.0, linear_module=ViTLinear):
+        super().__init__()
+        self.net = nn.Sequential(
+            linear_module(dim, hidden_dim),
+            nn.GELU(),
+            nn.Dropout(dropout) if dropout > 0.0 else nn.Identity(),
+            linear_module(hidden_dim, dim),
+            nn.Dropout(dropout) if dropout > 0.0 else nn.Identity(),
+        )
+
+    def forward(self, x):
+        return self.net(x)
+
+
+class Attention(nn.Module):
+    """GTA multi-head attention (layers.py:172-444, ``method == 'gta'`` branch)."""
+
+    def __init__(self, dim, heads=8, dim_head=64, dropout=0.0, kv_dim=None, attn_args=None,
+                 linear_module=JaxLinear, **kwargs):
+        super().__init__()
+        attn_args = attn_args or {}
+        inner_dim = dim_head * heads
+        project_out = not (heads == 1 and dim_head == dim)
+        self.selfatt = kv_dim is None
+        self.heads = heads
+        self.dim_head = dim_head
+        self.scale = dim_head ** -0.5
+        self.method = attn_args["method"]["name"]
+        self.method_args = attn_args["method"]["args"]
+        if self.method != "gta":
+            raise NotImplementedError(f"attention method {self.method!r}: only 'gta' is built (see DESIGN.md)")
+        if self.method_args.get("elementwise_mul", False):
+            raise NotImplementedError("elementwise_mul (vecrep) ablation is not built")
+        if self.method_args.get("rpe", False):
+            raise NotImplementedError("rpe baseline is not built")
+        use_bias = self.method_args.get("use_bias", False)
+        self.f_dims = dict(self.method_args["f_dims"])
+        if sum(self.f_dims.values()) != dim_head:
+            raise ValueError(f"f_dims {self.f_dims} must sum to dim_head={dim_head}")
+        if self.f_dims.get("se3", 0) > 0:
+            self.trans_coeff = nn.Parameter(torch.tensor([0.01]))        # layers.py:191
+        else:
+            self.trans_coeff = None
+        if attn_args.get("softmax") == "adjustable":
+            self.attend = TemperatureAdjustableSoftmax(1.0)               # key 'attend.tau'
+        else:
+            self.attend = None
+        self.euclid = self.method_args.get("euclid_sim", False)
+        if kv_dim is not None:
+            self.to_q = linear_module(dim, inner_dim, bias=use_bias)
+            self.to_kv = linear_module(kv_dim, 2 * inner_dim, bias=use_bias)
+        else:
+            self.to_qkv = linear_module(dim, 3 * inner_dim, bias=use_bias)
+        self.to_out = nn.Sequential(linear_module(inner_dim, dim), nn.Dropout(dropout)) if project_out \
+            else nn.Identity()
+
+    def forward(self, x, z=None, return_attmap=False, extras=None):
+        if extras is None:
+            raise ValueError("GTA attention needs `extras` (the reps dict)")
+        if return_attmap:
+            raise NotImplementedError("return_attmap needs the dense attention matrix; not built yet")
+        B, Tq, _ = x.shape
+        H, dh = self.heads, self.dim_head
+        if z is None:
+            qkv = self.to_qkv(x).view(B, Tq, 3, H, dh)                    # layers.py:389
+            q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))   # strided views, no copy
+        else:
+            q = self.to_q(x).view(B, Tq, H, dh).permute(0, 2, 1, 3)      # layers.py:391-392
+            kv = self.to_kv(z).view(B, z.shape[1], 2, H, dh)
+            k, v = (kv[:, :, i].permute(0, 2, 1, 3) for i in range(2))
+        packed = _gta.pack_reps(extras, self.f_dims)
+        out = _gta.gta_attention(
+            q, k, v, self.f_dims, packed,
+            so3_degree=_gta._so3_degree(self.f_dims, packed, extras),
+            trans_coeff=self.trans_coeff, tau=self.attend.tau if self.attend is not None else None,
+            scale=self.scale, v_transform=self.method_args.get("v_transform", True), euclid=self.euclid)
+        out = out.permute(0, 2, 1, 3).reshape(B, Tq, H * dh)              # free: out is [B,Tq,H,dh] in memory
+        return self.to_out(out)
+
+
+class Transformer(nn.Module):
+    """Pre-LN Transformer (layers.py:447-488)."""
+
+    def __init__(self, dim, depth, heads, dim_head, mlp_dim, dropout=0.0, selfatt=True, kv_dim=None,
+                 return_last_attmap=False, attn_args=None):
+        super().__init__()
+        self.heads = heads
+        self.layers = nn.ModuleList([])
+        dropout = 0.0 if dropout is None else dropout
+        for _ in range(depth):
+            attn = PreNorm(dim, Attention(dim, heads=heads, dim_head=dim_head, dropout=dropout, selfatt=selfatt,
+                                          kv_dim=kv_dim, attn_args=attn_args, linear_module=JaxLinear))
+            ff = PreNorm(dim, FeedForward(dim, mlp_dim, dropout=dropout, linear_module=ViTLinear))
+            self.layers.append(nn.ModuleList([attn, ff]))
+        self.return_last_attmap = return_last_attmap
+
+    def forward(self, x, z=None, extras=None):
+        attmap = None
+        for l, (attn, ff) in enumerate(self.layers):
+            if l == len(self.layers) - 1 and self.return_last_attmap:
+                out, attmap = attn(x, z=z, return_attmap=True, extras=extras)
+                x = out + x
+            else:
+                x = attn(x, z=z, extras=extras) + x
+            x = ff(x) + x
+        return (x, attmap) if self.return_last_attmap else x

@@ -1,0 +1,162 @@
+"""ctypes binding of libgta_hip.so (the C ABI declared in include/gta_hip.h).
+
+There is no CPU or eager fallback anywhere in this package: if the shared library is missing
+or a kernel refuses a request, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int32, c_int64, c_uint32, c_void_p
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgta_hip.so")
+
+GTA_ABI_VERSION = 1
+DTYPE_F32, DTYPE_BF16 = 0, 1
+FLAG_V_TRANSFORM = 1 << 0
+FLAG_EUCLID = 1 << 1
+FLAG_PRETRANSFORMED = 1 << 2
+FLAG_NO_DMA = 1 << 8
+VREP_STRIDE = 72
+VREP_INV, VREP_REP, VREP_D1, VREP_D2 = 0, 16, 32, 41
+MAX_VIEWS = 16
+
+# every symbol include/gta_hip.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = (
+    "gta_build_view_reps", "gta_build_so2_table", "gta_attn_fwd", "gta_attn_fwd_supported",
+    "gta_attn_fwd_launch_info", "gta_strerror", "gta_abi_version", "gta_sizeof_attn_desc",
+)
+
+
+class GtaError(RuntimeError):
+    pass
+
+
+class GtaAttnDesc(ctypes.Structure):
+    _fields_ = [
+        ("abi_version", c_int32), ("dtype", c_int32), ("B", c_int32), ("H", c_int32),
+        ("Tq", c_int32), ("Tk", c_int32), ("Nq", c_int32), ("Nk", c_int32), ("dh", c_int32),
+        ("d_triv", c_int32), ("d_se3", c_int32), ("d_so3", c_int32), ("d_so2", c_int32),
+        ("d_t2", c_int32), ("so3_degree", c_int32), ("flags", c_uint32), ("scale", c_float),
+        ("_pad", c_int32),
+        ("q_stride", c_int64 * 3), ("k_stride", c_int64 * 3), ("v_stride", c_int64 * 3),
+        ("o_stride", c_int64 * 3),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises GtaError with the build command when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GtaError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"or `make -C gta_amd/csrc` (hipcc --offload-arch=gfx950). gta_amd has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        L.gta_strerror.restype = ctypes.c_char_p
+        L.gta_strerror.argtypes = [ctypes.c_int]
+        L.gta_abi_version.restype = ctypes.c_int
+        L.gta_sizeof_attn_desc.restype = ctypes.c_int
+        if L.gta_abi_version() != GTA_ABI_VERSION:
+            raise GtaError("libgta_hip.so ABI version mismatch")
+        if L.gta_sizeof_attn_desc() != ctypes.sizeof(GtaAttnDesc):
+            raise GtaError("GtaAttnDesc layout mismatch between gta_hip.h and gta_amd/native.py")
+        L.gta_build_view_reps.argtypes = [c_void_p, c_int32, c_int32, c_void_p, c_void_p]
+        L.gta_build_so2_table.argtypes = [c_void_p, c_int32, c_int32, c_float, c_float, c_int32, c_void_p, c_void_p]
+        L.gta_attn_fwd.argtypes = [ctypes.POINTER(GtaAttnDesc)] + [c_void_p] * 12
+        L.gta_attn_fwd_supported.argtypes = [ctypes.POINTER(GtaAttnDesc)]
+        L.gta_attn_fwd_launch_info.argtypes = [ctypes.POINTER(GtaAttnDesc)] + [ctypes.POINTER(c_int32)] * 3
+        if hasattr(L, "gta_attn_bwd"):
+            L.gta_attn_bwd.argtypes = [ctypes.POINTER(GtaAttnDesc)] + [c_void_p] * 19
+            L.gta_attn_bwd_workspace_bytes.argtypes = [ctypes.POINTER(GtaAttnDesc)]
+            L.gta_attn_bwd_workspace_bytes.restype = c_int64
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise GtaError(f"{what} failed ({rc}): {lib().gta_strerror(rc).decode()}")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise GtaError("gta_amd kernels need CUDA/HIP tensors (MI355X); there is no CPU path")
+
+
+def build_view_reps(transforms: torch.Tensor, so3_degree: int) -> torch.Tensor:
+    """extrinsics [B,N,4,4] -> packed per-view reps [B,N,VREP_STRIDE] (see gta_hip.h)."""
+    _require_cuda(transforms)
+    B, N = transforms.shape[:2]
+    E = transforms.detach().to(torch.float32).contiguous()
+    out = torch.empty(B, N, VREP_STRIDE, device=E.device, dtype=torch.float32)
+    check(lib().gta_build_view_reps(_ptr(E), B * N, int(so3_degree), _ptr(out), _stream()),
+          "gta_build_view_reps")
+    return out
+
+
+def build_so2_table(coord: torch.Tensor, nfreqs: int, max_freq_h: float, max_freq_w: float,
+                    shared_freqs: bool = False) -> torch.Tensor:
+    """coord [B,T,2] -> (cos, sin) table [B,T,2*nfreqs,2]."""
+    _require_cuda(coord)
+    B, T = coord.shape[:2]
+    c = coord.detach().to(torch.float32).contiguous()
+    out = torch.empty(B, T, 2 * nfreqs, 2, device=c.device, dtype=torch.float32)
+    check(lib().gta_build_so2_table(_ptr(c), B * T, int(nfreqs), float(max_freq_h), float(max_freq_w),
+                                    int(bool(shared_freqs)), _ptr(out), _stream()), "gta_build_so2_table")
+    return out
+
+
+def make_desc(q, k, v, out, f_dims: dict, so3_degree: int, Nq: int, Nk: int, scale: float,
+              flags: int) -> GtaAttnDesc:
+    """q/k/v/out are [B,H,T,dh] tensors (any strides with unit channel stride)."""
+    d = GtaAttnDesc()
+    d.abi_version = GTA_ABI_VERSION
+    d.dtype = DTYPE_BF16 if q.dtype == torch.bfloat16 else DTYPE_F32
+    d.B, d.H, d.Tq, d.dh = q.shape
+    d.Tk = k.shape[2]
+    d.Nq, d.Nk = Nq, Nk
+    d.d_triv = int(f_dims.get("triv", 0)); d.d_se3 = int(f_dims.get("se3", 0))
+    d.d_so3 = int(f_dims.get("so3", 0)); d.d_so2 = int(f_dims.get("so2", 0)); d.d_t2 = int(f_dims.get("t2", 0))
+    d.so3_degree = int(so3_degree)
+    d.flags = flags
+    d.scale = float(scale)
+    for name, t in (("q_stride", q), ("k_stride", k), ("v_stride", v), ("o_stride", out)):
+        if t.stride(3) != 1:
+            raise GtaError(f"{name}: channel stride must be 1")
+        getattr(d, name)[:] = [t.stride(0), t.stride(1), t.stride(2)]
+    return d
+
+
+def attn_fwd(desc: GtaAttnDesc, q, k, v, vrep_q, vrep_k, cs_q, cs_k, trans_coeff, tau, out, lse):
+    _require_cuda(q, k, v, out)
+    check(lib().gta_attn_fwd(ctypes.byref(desc), _ptr(q), _ptr(k), _ptr(v), _ptr(vrep_q), _ptr(vrep_k),
+                             _ptr(cs_q), _ptr(cs_k), _ptr(trans_coeff), _ptr(tau), _ptr(out), _ptr(lse),
+                             _stream()), "gta_attn_fwd")
+
+
+def attn_fwd_supported(desc: GtaAttnDesc) -> int:
+    return lib().gta_attn_fwd_supported(ctypes.byref(desc))
+
+
+def launch_info(desc: GtaAttnDesc):
+    a, b, c = c_int32(), c_int32(), c_int32()
+    check(lib().gta_attn_fwd_launch_info(ctypes.byref(desc), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)),
+          "gta_attn_fwd_launch_info")
+    return {"lds_bytes": a.value, "workgroups": b.value, "threads": c.value}

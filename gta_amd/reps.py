@@ -1,0 +1,67 @@
+"""Rep builders on device -- mirrors ``pre_compute_reps`` of the reference's encoder and decoder
+(source/encoder.py:183-265, source/decoder.py:247-353).
+
+Same contract as the reference: ``extras`` is the caller-owned dict shared by encoder, decoder
+and every layer; it is mutated in place.  Instead of the reference's dense tensors
+(``se3rep_*`` [B,N,4,4], ``so3rep_*`` lists, ``so2rep_*`` [B,T,2F,2,2]) the packed tables the
+kernels read are stored:
+
+    extras['gta_vrep_q'], extras['gta_vrep_k']   [B, N, 72]      per-view E, inv(E), D^1, D^2
+    extras['gta_cs_q'],   extras['gta_cs_k']     [B, T, 2F, 2]   per-token (cos, sin)
+    extras['gta_so3_degree']
+
+The encoder call sets q-side == k-side (self-attention); the decoder call overwrites only the
+q-side from ``target_transforms`` / ``target_coord`` and keeps the encoder's k-side
+(decoder.py:309-311,346), rebuilding ``*_k`` only when missing or under ``recompute_so2``
+(decoder.py:263-272).  The dead ``ray_to_se3`` branch (undefined ``ray2rotation``) and the
+``flattened_*`` tensors of the ``elementwise_mul`` ablation are not reproduced.
+"""
+from __future__ import annotations
+
+from . import native
+
+
+def _so2(attn_kwargs, coord):
+    c = coord.reshape(coord.shape[0], -1, 2)
+    return native.build_so2_table(c, attn_kwargs["so2"], attn_kwargs["max_freq_h"], attn_kwargs["max_freq_w"],
+                                  attn_kwargs.get("shared_freqs", False))
+
+
+def _check(attn_kwargs):
+    f = attn_kwargs["f_dims"]
+    if attn_kwargs.get("ray_to_se3", False):
+        raise NotImplementedError("ray_to_se3 is dead code in the reference (ray2rotation is undefined)")
+    if f.get("t2", 0) > 0:
+        raise NotImplementedError("t2 reps: use the reference-style dict + the unfused path")
+    for key in ("zeroout_so3", "id_so3"):
+        if attn_kwargs.get(key, False):
+            raise NotImplementedError(f"{key} ablation is not built")
+    return f
+
+
+def pre_compute_reps_encoder(attn_kwargs: dict, extras: dict) -> dict:
+    """encoder.py:183-265: reps of the input views, q-side == k-side."""
+    f = _check(attn_kwargs)
+    if f.get("so2", 0) > 0:
+        extras["gta_cs_q"] = extras["gta_cs_k"] = _so2(attn_kwargs, extras["input_coord"])
+    if f.get("se3", 0) > 0 or f.get("so3", 0) > 0:
+        L = attn_kwargs.get("so3", 0) if f.get("so3", 0) > 0 else 0
+        extras["gta_vrep_q"] = extras["gta_vrep_k"] = native.build_view_reps(extras["input_transforms"], L)
+        extras["gta_so3_degree"] = L
+    return extras
+
+
+def pre_compute_reps_decoder(attn_kwargs: dict, extras: dict) -> dict:
+    """decoder.py:247-353: q-side from the target views; k-side kept from the encoder call."""
+    f = _check(attn_kwargs)
+    if f.get("so2", 0) > 0:
+        extras["gta_cs_q"] = _so2(attn_kwargs, extras["target_coord"])
+        if attn_kwargs.get("recompute_so2", False) or "gta_cs_k" not in extras:
+            extras["gta_cs_k"] = _so2(attn_kwargs, extras["input_coord"])
+    if f.get("se3", 0) > 0 or f.get("so3", 0) > 0:
+        L = attn_kwargs.get("so3", 0) if f.get("so3", 0) > 0 else 0
+        extras["gta_vrep_q"] = native.build_view_reps(extras["target_transforms"], L)
+        if "gta_vrep_k" not in extras:
+            extras["gta_vrep_k"] = native.build_view_reps(extras["input_transforms"], L)
+        extras["gta_so3_degree"] = L
+    return extras

@@ -1,0 +1,129 @@
+/*
+ * gta_hip.h -- C ABI of libgta_hip.so: MI355X (gfx950) kernels for GTA attention.
+ *
+ * The reference (autonomousvision/gta) has no FFI: its seam for this path is the Python
+ * function ``multihead_geometric_transform_attention`` (source/utils/gta.py:92-279) called
+ * from ``Attention.forward`` (source/layers.py:409-430) and the rep builders
+ * ``pre_compute_reps`` (source/encoder.py:183-265, source/decoder.py:247-353).  The entry
+ * points below are what a ctypes binding of those call sites needs.
+ *
+ * Conventions
+ *   - plain C, raw DEVICE pointers, no torch types; the caller allocates every buffer, the
+ *     library owns nothing and keeps no state; every call is asynchronous on `stream`
+ *     (a hipStream_t passed as void*) and re-entrant.
+ *   - return 0 on success, a negative GTA_E_* code otherwise; nothing throws, nothing is
+ *     printed.  gta_strerror() names a code.
+ *   - tokens are view-major (t = view * tokens_per_view + p), gta.py:160-162.
+ *   - per-head channels are laid out [triv | se3 | so3 | so2 | t2], gta.py:115-122.
+ */
+#ifndef GTA_HIP_H
+#define GTA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GTA_ABI_VERSION 1
+
+/* element types of q/k/v/out (all four share one type per call) */
+#define GTA_DTYPE_F32  0
+#define GTA_DTYPE_BF16 1
+
+/* flags of GtaAttnDesc.flags */
+#define GTA_FLAG_V_TRANSFORM   (1u << 0) /* gta.py: v_transform=True (default)                 */
+#define GTA_FLAG_EUCLID        (1u << 1) /* gta.py:146-156 + layers.py:213-224 (not fused yet) */
+#define GTA_FLAG_PRETRANSFORMED (1u << 2) /* q,k,v already carry rho; only rho_q^-1 on output   */
+#define GTA_FLAG_NO_DMA        (1u << 8) /* debug: stage K/V tiles through VGPRs, not LDS-DMA  */
+
+/* error codes */
+#define GTA_OK              0
+#define GTA_E_BADARG       -1   /* null pointer / non-positive size / bad dtype                 */
+#define GTA_E_LAYOUT       -2   /* f_dims do not add up to dh, or a slab is mis-sized           */
+#define GTA_E_UNSUPPORTED  -3   /* valid request this build has no kernel for (says which in    */
+                                /* gta_strerror); never silently falls back                     */
+#define GTA_E_LAUNCH       -4   /* HIP launch error                                             */
+#define GTA_E_NODEVICE     -5
+
+/* Per-view rep record produced by gta_build_view_reps and consumed by the attention kernels.
+ * One record of GTA_VREP_STRIDE floats per (batch, view):
+ *   [ 0:16)  "inv" matrix  = extrinsic E           (reference: extras['inv_se3rep_q'], encoder.py:236)
+ *   [16:32)  "rep" matrix  = inverse(E)            (reference: extras['se3rep_q/k'],  encoder.py:219,235)
+ *   [32:41)  D^1(R), R = inverse(E)[:3,:3]         (reference: extras['so3rep_*'][0], encoder.py:247-259)
+ *   [41:66)  D^2(R)                                (reference: extras['so3rep_*'][1])
+ * all row-major, fp32.  trans_coeff is NOT folded in (it is a per-layer parameter). */
+#define GTA_VREP_STRIDE 72
+#define GTA_VREP_INV    0
+#define GTA_VREP_REP    16
+#define GTA_VREP_D1     32
+#define GTA_VREP_D2     41
+
+#define GTA_MAX_VIEWS   16   /* per side, fused kernels */
+
+typedef struct GtaAttnDesc {
+    int32_t abi_version;      /* GTA_ABI_VERSION                                              */
+    int32_t dtype;            /* GTA_DTYPE_*                                                  */
+    int32_t B, H;             /* batch, heads                                                 */
+    int32_t Tq, Tk;           /* tokens (all views) on the query / key side                   */
+    int32_t Nq, Nk;           /* views per side; Tq % Nq == 0, Tk % Nk == 0 (gta.py:160-162)  */
+    int32_t dh;               /* channels per head = d_triv+d_se3+d_so3+d_so2+d_t2            */
+    int32_t d_triv, d_se3, d_so3, d_so2, d_t2;   /* f_dims (gta.py:115-122)                  */
+    int32_t so3_degree;       /* L: so3 sub-blocks of 3,5,..,2L+1 channels (gta.py:174-198)   */
+    uint32_t flags;           /* GTA_FLAG_*                                                   */
+    float   scale;            /* dim_head ** -0.5 (layers.py:181)                             */
+    int32_t _pad;
+    /* element strides of (batch, head, token); the channel stride is 1.  q/k/v may be views
+     * into a packed [B, T, 3*H*dh] projection (layers.py:389,394-395) -- no copy needed.     */
+    int64_t q_stride[3], k_stride[3], v_stride[3], o_stride[3];
+} GtaAttnDesc;
+
+/* -------------------------------------------------------------------------------------------
+ * Rep builders  (replace encoder.py:183-265 / decoder.py:247-353, gta.py:47-69, wigner_d.py:16-58)
+ * ------------------------------------------------------------------------------------------- */
+
+/* extrinsics [n_views,4,4] fp32 (extras['input_transforms'] / ['target_transforms'], flattened
+ * over batch) -> vrep [n_views, GTA_VREP_STRIDE].  so3_degree in {0,1,2}.  The Wigner-D path is
+ * the reference's ZYZ-Euler formula D = Z(g3) J Z(g2) J Z(g1) incl. its 1e-5 gimbal masks
+ * (wigner_d.py:28-49); J is a restatement of the absent J_dense.pt (parity unpinned there). */
+int gta_build_view_reps(const float* extrinsics, int32_t n_views, int32_t so3_degree,
+                        float* vrep, void* stream);
+
+/* coord [n_tokens,2] fp32 in [0,1) (extras['input_coord'] / ['target_coord'] flattened) ->
+ * cs [n_tokens, 2*nfreqs, 2] = (cos, sin) of theta_{t, c=2f+d} = max_freq_d * 2pi * coord_d *
+ * 2^(f+1-F)  (make_SO2mats, gta.py:47-69; block order c = 2f+d from gta.py:68 + encoder.py:195). */
+int gta_build_so2_table(const float* coord, int32_t n_tokens, int32_t nfreqs,
+                        float max_freq_h, float max_freq_w, int32_t shared_freqs,
+                        float* cs, void* stream);
+
+/* -------------------------------------------------------------------------------------------
+ * Fused forward  (replaces gta.py:92-279 + AttnFn, layers.py:202-211)
+ *   q [B,H,Tq,dh], k,v [B,H,Tk,dh] through the strides in desc; out like q.
+ *   vrep_q [B,Nq,GTA_VREP_STRIDE], vrep_k [B,Nk,...] (may be NULL when d_se3 = d_so3 = 0)
+ *   cs_q [B,Tq,d_so2/2,2], cs_k [B,Tk,d_so2/2,2]      (may be NULL when d_so2 = 0)
+ *   trans_coeff: device pointer to the layer's scalar parameter (layers.py:191) or NULL (=1)
+ *   tau:         device pointer to the softmax temperature (layers.py:195-200) or NULL (=1)
+ *   lse [B,H,Tq] fp32 out (natural-log sum-exp of the scaled logits; needed by backward), or NULL
+ * ------------------------------------------------------------------------------------------- */
+int gta_attn_fwd(const GtaAttnDesc* desc,
+                 const void* q, const void* k, const void* v,
+                 const float* vrep_q, const float* vrep_k,
+                 const float* cs_q, const float* cs_k,
+                 const float* trans_coeff, const float* tau,
+                 void* out, float* lse, void* stream);
+
+/* 0 when gta_attn_fwd has a fused kernel for this desc, else the error it would return. */
+int gta_attn_fwd_supported(const GtaAttnDesc* desc);
+
+/* bytes of LDS / number of workgroups the fused forward uses for desc (diagnostics). */
+int gta_attn_fwd_launch_info(const GtaAttnDesc* desc, int32_t* lds_bytes, int32_t* n_workgroups,
+                             int32_t* threads_per_wg);
+
+const char* gta_strerror(int code);
+int gta_abi_version(void);
+int gta_sizeof_attn_desc(void);   /* sizeof(GtaAttnDesc) as compiled: binding self-check */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GTA_HIP_H */

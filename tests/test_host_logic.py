@@ -1,0 +1,119 @@
+"""CPU: host-side logic -- the C ABI library loads and exports every declared symbol, descriptor
+validation (no GPU needed), the LDS swizzle is conflict-free, reps packing, module surface."""
+import ctypes
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import gta_amd
+from gta_amd import native
+from tests import _golden as G
+
+
+def test_library_exports_every_declared_symbol():
+    lib = native.lib()
+    hdr = open(native.LIB_PATH.replace("gta_amd/csrc/libgta_hip.so", "include/gta_hip.h")).read()
+    declared = set(re.findall(r"\b(gta_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(native.ABI_SYMBOLS), declared ^ set(native.ABI_SYMBOLS)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert lib.gta_abi_version() == native.GTA_ABI_VERSION
+    assert lib.gta_sizeof_attn_desc() == ctypes.sizeof(native.GtaAttnDesc)
+
+
+def _desc(dh=96, f=None, L=2, **kw):
+    f = f or {"se3": 48, "so3": 24, "so2": 24}
+    q = torch.empty(2, 8, 1280, dh)
+    d = native.make_desc(q, q, q, q, f, L, 5, 5, dh ** -0.5, native.FLAG_V_TRANSFORM)
+    for k, v in kw.items():
+        setattr(d, k, v)
+    return d
+
+
+def test_descriptor_validation_without_gpu():
+    ok = native.attn_fwd_supported
+    assert ok(_desc()) == 0
+    assert ok(_desc(64, {"se3": 32, "so2": 32}, 0)) == 0
+    assert ok(_desc(64, {"so2": 64}, 0)) == 0
+    assert ok(_desc(64, {"triv": 8, "se3": 24, "so2": 32}, 0)) == 0
+    assert ok(_desc(96, {"se3": 48, "so3": 24, "so2": 20}, 2)) == -2          # slabs do not sum to dh
+    assert ok(_desc(64, {"se3": 30, "so2": 34}, 0)) == -2                     # se3 not a multiple of 4
+    assert ok(_desc(64, {"so2": 56, "t2": 8}, 0)) == -2                       # t2 not a multiple of 3
+    assert ok(_desc(96, {"se3": 48, "so3": 24, "so2": 24}, 1)) == -3          # valid (8 x [3]) but not fused
+    assert ok(_desc(96, {"se3": 48, "so3": 28, "so2": 20}, 2)) == -2          # so3 not r*(3+5)
+    assert ok(_desc(Tq=1281)) == -1                                           # views must split evenly
+    d = _desc()
+    d.flags |= native.FLAG_EUCLID
+    assert ok(d) == -3
+    assert b"euclid" in native.lib().gta_strerror(-3)
+    info = native.launch_info(_desc())
+    assert info == {"lds_bytes": 64256, "workgroups": 2 * 8 * 10, "threads": 256}
+
+
+# ds_read_b128 lane groups on gfx950 (MI355X_MICROARCH.md, LDS table)
+B128_GROUPS = [
+    [0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27],
+    [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31],
+    [32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59],
+    [36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63],
+]
+
+
+def swz(units, r, u):
+    """Python model of swz<UNITS>() in gta_amd/csrc/gta_common.h."""
+    tz = 4 if units % 16 == 0 else 3 if units % 8 == 0 else 2 if units % 4 == 0 else 1 if units % 2 == 0 else 0
+    rot = (r >> (4 - tz)) & ((1 << tz) - 1)
+    return (u + rot) % units
+
+
+@pytest.mark.parametrize("units", [4, 8, 12, 16, 24, 32])
+def test_swizzle_is_a_conflict_free_permutation(units):
+    for r in range(64):
+        assert sorted(swz(units, r, u) for u in range(units)) == list(range(units))
+    # (a) staging reads: lane == row, all lanes read the same logical unit
+    # (b) MFMA fragment reads: lanes 0-31 rows 0-31 unit u, lanes 32-63 rows 0-31 unit u+1
+    for u in range(units - 1):
+        for mode in ("stage", "frag"):
+            for grp in B128_GROUPS:
+                slots = []
+                for lane in grp:
+                    row = lane if mode == "stage" else (lane & 31)
+                    uu = u if mode == "stage" else u + (lane >> 5)
+                    slots.append((row * units + swz(units, row, uu)) % 16)   # 16-B slot in the 256-B bank row
+                assert len(set(slots)) == 16, (units, u, mode, slots)
+
+
+def test_pack_reps_from_reference_style_dict():
+    d, meta = G.load("op_ms_cross")
+    ex = G.extras_of(d, torch.float32)
+    packed = gta_amd.pack_reps(ex, meta["f_dims"])
+    vq = packed["vrep_q"]
+    assert vq.shape == (meta["B"], meta["Nq"], native.VREP_STRIDE)
+    assert torch.equal(vq[..., :16].reshape(ex["inv_se3rep_q"].shape), ex["inv_se3rep_q"])
+    assert torch.equal(vq[..., 16:32].reshape(ex["se3rep_q"].shape), ex["se3rep_q"])
+    assert torch.equal(vq[..., 32:41].reshape(ex["so3rep_q"][0].shape), ex["so3rep_q"][0])
+    assert torch.equal(vq[..., 41:66].reshape(ex["so3rep_q"][1].shape), ex["so3rep_q"][1])
+    cs = packed["cs_k"]
+    assert torch.equal(cs[..., 0], ex["so2rep_k"][..., 0, 0]) and torch.equal(cs[..., 1], ex["so2rep_k"][..., 1, 0])
+    assert gta_amd.pack_reps(ex, meta["f_dims"])["vrep_q"] is vq          # cached in the shared dict
+
+
+@pytest.mark.parametrize("case", G.list_cases("mod_"))
+def test_module_state_dict_is_reference_compatible(case):
+    d, meta = G.load("mod_" + case)
+    ak = {"f_dims": meta["f_dims"], "so2": meta["so2"], "so3": meta["so3"], "max_freq_h": 1, "max_freq_w": 1}
+    tr = gta_amd.Transformer(meta["dim"], meta["depth"], meta["H"], meta["dh"], 2 * meta["dim"], 0.0,
+                             not meta["cross"], meta["kv_dim"], False, {"method": {"name": "gta", "args": ak}})
+    sd = {k[len("param."):]: torch.from_numpy(v).float() for k, v in d.items() if k.startswith("param.")}
+    tr.load_state_dict(sd, strict=True)
+
+
+def test_no_cpu_fallback():
+    q = torch.randn(1, 2, 16, 16)
+    with pytest.raises(native.GtaError):
+        gta_amd.gta_attention(q, q, q, {"triv": 16}, {})
+    with pytest.raises(NotImplementedError):
+        gta_amd.Attention(32, 2, 16, attn_args={"method": {"name": "repast", "args": {}}})
