@@ -49,8 +49,8 @@ def test_descriptor_validation_without_gpu():
     d.flags |= native.FLAG_EUCLID
     assert ok(d) == -3
     assert b"euclid" in native.lib().gta_strerror(-3)
-    info = native.launch_info(_desc())
-    assert info == {"lds_bytes": 64256, "workgroups": 2 * 8 * 10, "threads": 256}
+    assert native.launch_info(_desc()) == {"lds_bytes": 86784, "workgroups": 2 * 8 * 10, "threads": 256}  # fp32
+    assert native.launch_info(_desc(dtype=native.DTYPE_BF16))["lds_bytes"] == 64256      # bf16: 2 WGs per CU
 
 
 # ds_read_b128 lane groups on gfx950 (MI355X_MICROARCH.md, LDS table)
