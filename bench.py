@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- GTA-attention throughput on MI355X (contract: one JSON line on rank 0).
+
+A "step" is one pass of the hot path over one synthetic batch: build the per-view / per-token
+reps from poses and patch coordinates on device, then ONE fused GTA attention forward
+(`gta_attn_fwd`) on already-projected Q/K/V resident in HBM.  Default workload = BASELINE.json's
+metric configuration: the MSN-Hard `gta_so3` encoder attention (V=5 views of 128x128 images ->
+16x16 patches/view -> 1280 tokens, d=768 = 8 heads x 96 channels, f_dims se3 48 / so3 24 /
+so2 24), bf16, 32 scenes per GPU.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: data-parallel replicas (one process per GPU, fixed per-GPU batch -> "weak"); the
+operator has no exchange step, so there is no data-path collective -- only the barrier and the
+MAX-over-ranks of the timed region go through RCCL.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+WORKLOADS = {
+    # name: (H, Nq, Pq, Nk, Pk, f_dims, so2, so3, default per-GPU batch)
+    "ms-enc": (8, 5, 256, 5, 256, {"triv": 0, "se3": 48, "so3": 24, "so2": 24}, 6, 2, 32),
+    "ms-dec": (8, 5, 512, 5, 256, {"triv": 0, "se3": 48, "so3": 24, "so2": 24}, 6, 2, 32),
+    "cl-enc": (6, 2, 300, 2, 300, {"se3": 32, "so2": 32}, 8, 0, 32),
+    "cl-dec": (6, 3, 853, 2, 300, {"se3": 32, "so2": 32}, 8, 0, 32),
+    "dit": (16, 1, 1024, 1, 1024, {"so2": 64}, 16, 0, 32),
+}
+
+
+def make_inputs(workload, B, dtype, device, seed):
+    from tests import _hip_cases as C
+    H, Nq, Pq, Nk, Pk, f_dims, so2, so3, _ = WORKLOADS[workload]
+    q, k, v, ex, ak, cross = C.synth_inputs(B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, dtype, seed=seed)
+    # Q/K/V as the module's packed projection leaves them: [B, T, H, dh] in memory, viewed [B, H, T, dh]
+    to_dev = lambda t: t.to(dtype).to(device).permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
+    exd = {kk: vv.to(device) for kk, vv in ex.items()}
+    return to_dev(q), to_dev(k), to_dev(v), exd, ak, cross, (q, k, v, ex)
+
+
+def cpu_baseline(workload, seed):
+    """The CPU oracle (a port of the reference's PyTorch path) on a bounded sample of the same
+    workload, all host cores.  Reported beside the GPU number; baseline only."""
+    from tests import _hip_cases as C
+    H, Nq, Pq, Nk, Pk, f_dims, so2, so3, _ = WORKLOADS[workload]
+    Bs = 2
+    q, k, v, ex, ak, cross = C.synth_inputs(Bs, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, torch.float32, seed=seed)
+    ncpu = os.cpu_count() or 1
+    best = None
+    t_end = time.time() + 25.0
+    # intra-op threading of many small einsums stops scaling early: try a few counts, keep the best
+    for nthreads in sorted({min(ncpu, n) for n in (8, 16, 32, 64)}):
+        if time.time() > t_end:
+            break
+        torch.set_num_threads(nthreads)
+        C.oracle_forward(q, k, v, ex, ak, cross, 0.01)          # warm-up
+        times = []
+        while len(times) < 5 and time.time() < t_end:
+            t0 = time.perf_counter()
+            C.oracle_forward(q, k, v, ex, ak, cross, 0.01)
+            times.append(time.perf_counter() - t0)
+        if times:
+            times.sort()
+            med_n = times[len(times) // 2]
+            if best is None or med_n < best[0]:
+                best = (med_n, nthreads, len(times))
+    med, cores, nruns = best
+    times = [0] * nruns
+    return {"value": Bs * Nq * Pq / med / 1e6, "unit": "Mtokens/s", "cores": cores, "host_cpus": ncpu,
+            "kind": "port",
+            "sample": f"oracle/gta_oracle.py fp32 (rep build + attention), B={Bs} scenes of the same workload, "
+                      f"median of {len(times)} runs, {med * 1e3:.1f} ms each"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="ms-enc", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import gta_amd
+    from gta_amd import native
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        import torch.distributed as dist
+        assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    device = torch.device("cuda", local_rank if world > 1 else 0)
+    native.lib()   # fail loudly if the HIP library is missing
+
+    H, Nq, Pq, Nk, Pk, f_dims, so2, so3, Bdef = WORKLOADS[args.workload]
+    B = args.batch or Bdef
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    q, k, v, exd, ak, cross, _ = make_inputs(args.workload, B, dtype, device, seed=1234 + rank)
+    tc = torch.tensor([0.01], device=device) if f_dims.get("se3", 0) > 0 else None
+    Tq, Tk, dh = Nq * Pq, Nk * Pk, sum(f_dims.values())
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        ex = dict(exd)                                   # reps are rebuilt every step (timed)
+        gta_amd.pre_compute_reps_encoder(ak, ex)
+        if cross:
+            gta_amd.pre_compute_reps_decoder(ak, ex)
+        packed = gta_amd.pack_reps(ex, f_dims)
+        if i is not None:
+            ev[i][0].record()
+        out = gta_amd.gta_attention(q, k, v, f_dims, packed, so3_degree=ex.get("gta_so3_degree", 0), trans_coeff=tc)
+        if i is not None:
+            ev[i][1].record()
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps      # fused kernel only (same stream)
+    flops = 4.0 * B * H * Tq * Tk * dh                               # QK^T + PV, 2 flop/MAC
+    alg_bytes = (2 * Tq + 2 * Tk) * H * dh * q.element_size() * B    # read Q,K,V once, write O once
+    achieved = flops / (kern_ms * 1e-3) / 1e12
+
+    if rank == 0:
+        n = max(world, 1)
+        ms_per_step = elapsed / args.steps * 1e3
+        line = {
+            "metric": "GTA-attn Mtokens/s (V=5,H=W=128,d=768)" if args.workload == "ms-enc"
+                      else f"GTA-attn Mtokens/s ({args.workload})",
+            "value": n * B * Tq * args.steps / elapsed / 1e6,
+            "unit": "Mtokens/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.workload}: GTA attention forward (rep build + fused kernel), "
+                                   f"B={B}/GPU, H={H}, Tq={Tq}, Tk={Tk}, dh={dh}, f_dims={f_dims}, "
+                                   f"views q/k={Nq}/{Nk}", "global_batch": n * B, "parallelism": f"dp{n}"},
+            "roofline": {"bound": "mfma", "kernel": "gta_fwd_kernel", "achieved": achieved,
+                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
+                         "traffic": None, "kernel_ms": kern_ms, "algorithmic_flops": flops,
+                         "algorithmic_bytes": alg_bytes,
+                         "hbm_frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+        }
+        if not args.no_cpu_baseline and n == 1:
+            line["cpu_baseline"] = cpu_baseline(args.workload, 99)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
