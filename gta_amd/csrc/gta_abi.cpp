@@ -2,6 +2,7 @@
 // encodes the reference's slab layout (gta.py:115-122), kernel dispatch.  No state, no allocation.
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "../../include/gta_hip.h"
 #include "gta_fwd_params.h"
@@ -14,6 +15,9 @@
 
 int gta_fwd_lds_bytes(int dhp, int esz);
 int gta_fwd_dispatch(const GtaFwdParams& p, int dhp, int esz, bool dma, int n_wg, hipStream_t stream);
+long gta_fwd2_workspace_bytes(int B, int H, int Tk, int dhp);
+int gta_fwd2_lds_bytes(int dhp, int nq);
+int gta_fwd2_dispatch(GtaFwdParams& p, int dhp, int esz, bool run_prep, bool run_flash, int nw, hipStream_t stream);
 
 namespace {
 
@@ -83,6 +87,9 @@ int check_common(const GtaAttnDesc* d) {
 
 }  // namespace
 
+static unsigned long long* g_prof = nullptr;
+// debug hook (not part of the product ABI): device buffer [n_workgroups][8] for s_memtime stamps
+extern "C" void gta_debug_set_profile_buffer(void* p) { g_prof = (unsigned long long*)p; }
 extern "C" int gta_abi_version(void) { return GTA_ABI_VERSION; }
 extern "C" int gta_sizeof_attn_desc(void) { return (int)sizeof(GtaAttnDesc); }
 
@@ -108,6 +115,11 @@ extern "C" int gta_attn_fwd_supported(const GtaAttnDesc* desc) {
     return build_ctab(desc, ctab);
 }
 
+extern "C" int64_t gta_attn_fwd_workspace_bytes(const GtaAttnDesc* desc) {
+    if (gta_attn_fwd_supported(desc)) return 0;
+    return gta_fwd2_workspace_bytes(desc->B, desc->H, desc->Tk, padded_dh(desc->dh));
+}
+
 extern "C" int gta_attn_fwd_launch_info(const GtaAttnDesc* desc, int32_t* lds_bytes, int32_t* n_workgroups,
                                         int32_t* threads_per_wg) {
     int rc = gta_attn_fwd_supported(desc);
@@ -121,10 +133,11 @@ extern "C" int gta_attn_fwd_launch_info(const GtaAttnDesc* desc, int32_t* lds_by
 
 extern "C" int gta_attn_fwd(const GtaAttnDesc* d, const void* q, const void* k, const void* v,
                             const float* vrep_q, const float* vrep_k, const float* cs_q, const float* cs_k,
-                            const float* trans_coeff, const float* tau, void* out, float* lse, void* stream) {
+                            const float* trans_coeff, const float* tau, void* out, float* lse,
+                            void* workspace, int64_t workspace_bytes, void* stream) {
     int rc = check_common(d);
     if (rc) return rc;
-    if (!q || !k || !v || !out) return fail(GTA_E_BADARG, "null q/k/v/out");
+    if (!k || !v || ((!q || !out) && !(d->flags & GTA_FLAG_PREP_ONLY))) return fail(GTA_E_BADARG, "null q/k/v/out");
     GtaFwdParams p;
     memset(&p, 0, sizeof p);
     rc = build_ctab(d, p.ctab);
@@ -149,8 +162,22 @@ extern "C" int gta_attn_fwd(const GtaAttnDesc* d, const void* q, const void* k, 
     p.dh = d->dh; p.nso2 = d->d_so2 / 2;
     p.n_qtiles = (d->Tq + 127) / 128;
     p.flags = d->flags; p.scale = d->scale;
+#ifdef GTA_ABLATE
+    { const char* e = getenv("GTA_DBG"); p.dbg = e ? (uint32_t)atoi(e) : 0u; }
+    p.prof = g_prof;
+#endif
     const long n_wg = (long)d->B * d->H * p.n_qtiles;
     if (n_wg > 0x7fffffffL) return fail(GTA_E_UNSUPPORTED, "grid too large");
+    if (workspace && !(d->flags & GTA_FLAG_FUSED_KV) && !pre) {
+        if (workspace_bytes < gta_fwd2_workspace_bytes(d->B, d->H, d->Tk, padded_dh(d->dh)))
+            return fail(GTA_E_BADARG, "workspace smaller than gta_attn_fwd_workspace_bytes()");
+        if (d->H > 65535 || d->B > 65535) return fail(GTA_E_UNSUPPORTED, "B or H above 65535");
+        p.kp = workspace;
+        rc = gta_fwd2_dispatch(p, padded_dh(d->dh), esz, !(d->flags & GTA_FLAG_KV_READY), !(d->flags & GTA_FLAG_PREP_ONLY),
+                               (d->flags & GTA_FLAG_WG8) ? 8 : 4, (hipStream_t)stream);
+        if (rc) return fail(rc, rc == GTA_E_LAUNCH ? hipGetErrorString(hipGetLastError()) : "no kernel instance");
+        return GTA_OK;
+    }
     rc = gta_fwd_dispatch(p, padded_dh(d->dh), esz, !(d->flags & GTA_FLAG_NO_DMA), (int)n_wg, (hipStream_t)stream);
     if (rc) return fail(rc, rc == GTA_E_LAUNCH ? hipGetErrorString(hipGetLastError()) : "no kernel instance");
     return GTA_OK;

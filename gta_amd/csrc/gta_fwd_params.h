@@ -4,6 +4,7 @@
 
 struct GtaFwdParams {
     const void* q; const void* k; const void* v; void* o; float* lse;
+    void* kp;                                   // K'/V' tile-image workspace (two-stage path)
     const float* vrep_q; const float* vrep_k;   // [B,N,GTA_VREP_STRIDE]
     const float* cs_q; const float* cs_k;       // [B,T,nso2,2] (cos,sin)
     const float* trans_coeff; const float* tau; // device scalars or null
@@ -12,6 +13,8 @@ struct GtaFwdParams {
     float invPq, invPk;
     int dh, nso2, n_qtiles;
     uint32_t flags;
+    unsigned long long* prof;                   // debug: per-workgroup phase timestamps (or null)
+    uint32_t dbg;                               // ablation bits (GTA_DBG env; 0 in production)
     float scale;
     uint32_t ctab[16];                          // chunk descriptors (gta_common.h)
 };

@@ -119,6 +119,8 @@ def _as_kernel_layout(t: torch.Tensor) -> torch.Tensor:
 
 
 class _GtaAttn(torch.autograd.Function):
+    flash_events = None     # (start, end) torch.cuda.Event pair set by bench.py, else None
+
     @staticmethod
     def forward(ctx, q, k, v, trans_coeff, tau, f_dims_t, cfg, vrep_q, vrep_k, cs_q, cs_k):
         f_dims, so3_degree, Nq, Nk, scale, flags = cfg
@@ -135,7 +137,23 @@ class _GtaAttn(torch.autograd.Function):
         tc = trans_coeff.detach().to(torch.float32).reshape(-1) if trans_coeff is not None else None
         ta = tau.detach().to(torch.float32).reshape(-1) if tau is not None else None
         desc = native.make_desc(q, k, v, out, f_dims, so3_degree, Nq, Nk, scale, flags)
-        native.attn_fwd(desc, q, k, v, vrep_q, vrep_k, cs_q, cs_k, tc, ta, out, lse)
+        ws = None
+        if not (flags & (native.FLAG_FUSED_KV | native.FLAG_PRETRANSFORMED)):
+            ws = torch.empty(native.attn_fwd_workspace_bytes(desc), device=q.device, dtype=torch.uint8)
+        if ws is not None and _GtaAttn.flash_events is not None:
+            # instrumentation (bench.py): bracket the attention kernel alone with stream events
+            desc.flags = flags | native.FLAG_PREP_ONLY
+            native.attn_fwd(desc, q, k, v, vrep_q, vrep_k, cs_q, cs_k, tc, ta, out, lse, ws)
+            desc.flags = flags | native.FLAG_KV_READY
+            _GtaAttn.flash_events[0].record()
+            native.attn_fwd(desc, q, k, v, vrep_q, vrep_k, cs_q, cs_k, tc, ta, out, lse, ws)
+            _GtaAttn.flash_events[1].record()
+        else:
+            if _GtaAttn.flash_events is not None:
+                _GtaAttn.flash_events[0].record()
+            native.attn_fwd(desc, q, k, v, vrep_q, vrep_k, cs_q, cs_k, tc, ta, out, lse, ws)
+            if _GtaAttn.flash_events is not None:
+                _GtaAttn.flash_events[1].record()
         ctx.cfg = cfg
         ctx.save_for_backward(q, k, v, out, lse, tc, ta, vrep_q, vrep_k, cs_q, cs_k)
         ctx.tc_shape = None if trans_coeff is None else trans_coeff.shape
@@ -158,8 +176,13 @@ class _GtaAttn(torch.autograd.Function):
 
 def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: int = 0,
                   trans_coeff=None, tau=None, scale: Optional[float] = None, v_transform: bool = True,
-                  euclid: bool = False, pretransformed: bool = False, use_dma: bool = True) -> torch.Tensor:
-    """Fused GTA attention on packed reps.  q [B,H,Tq,dh], k/v [B,H,Tk,dh] -> out [B,H,Tq,dh]."""
+                  euclid: bool = False, pretransformed: bool = False, use_dma: bool = True,
+                  kv_mode: str = "auto") -> torch.Tensor:
+    """Fused GTA attention on packed reps.  q [B,H,Tq,dh], k/v [B,H,Tk,dh] -> out [B,H,Tq,dh].
+
+    kv_mode: 'prepass' = K/V rep pre-pass + lean attention kernel (two launches);
+             'fused'   = one kernel, rho_k applied inside the attention loop;
+             'auto'    = 'prepass' when several query tiles share each key tile, else 'fused'."""
     if scale is None:
         scale = q.shape[-1] ** -0.5
     flags = 0
@@ -171,6 +194,15 @@ def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: 
         flags |= native.FLAG_PRETRANSFORMED
     if not use_dma:
         flags |= native.FLAG_NO_DMA
+    if kv_mode == "prepass8":          # tuning knob: 8-wave (256-row) workgroups
+        flags |= native.FLAG_WG8
+        kv_mode = "prepass"
+    if kv_mode not in ("auto", "prepass", "fused"):
+        raise ValueError(f"kv_mode {kv_mode!r}")
+    if kv_mode == "auto":
+        kv_mode = "prepass" if q.shape[2] > 256 else "fused"
+    if kv_mode == "fused" or not use_dma:
+        flags |= native.FLAG_FUSED_KV
     Nq, Nk = _views(f_dims, packed, q, k)
     cfg = ({k_: int(v_) for k_, v_ in f_dims.items()}, int(so3_degree), Nq, Nk, float(scale), flags)
     if isinstance(trans_coeff, (int, float)):
@@ -199,5 +231,5 @@ def multihead_geometric_transform_attention(q, k, v, attn_fn=None, f_dims=None, 
         trans_coeff = None
     out = gta_attention(q, k, v, f_dims, packed, so3_degree=_so3_degree(f_dims, packed, reps),
                         trans_coeff=trans_coeff, tau=tau, scale=scale, v_transform=v_transform, euclid=euclid,
-                        use_dma=kwargs.get("use_dma", True))
+                        use_dma=kwargs.get("use_dma", True), kv_mode=kwargs.get("kv_mode", "auto"))
     return out, None

@@ -20,7 +20,11 @@ DTYPE_F32, DTYPE_BF16 = 0, 1
 FLAG_V_TRANSFORM = 1 << 0
 FLAG_EUCLID = 1 << 1
 FLAG_PRETRANSFORMED = 1 << 2
+FLAG_FUSED_KV = 1 << 3
+FLAG_KV_READY = 1 << 4
+FLAG_PREP_ONLY = 1 << 5
 FLAG_NO_DMA = 1 << 8
+FLAG_WG8 = 1 << 9
 VREP_STRIDE = 72
 VREP_INV, VREP_REP, VREP_D1, VREP_D2 = 0, 16, 32, 41
 MAX_VIEWS = 16
@@ -28,7 +32,7 @@ MAX_VIEWS = 16
 # every symbol include/gta_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (
     "gta_build_view_reps", "gta_build_so2_table", "gta_attn_fwd", "gta_attn_fwd_supported",
-    "gta_attn_fwd_launch_info", "gta_strerror", "gta_abi_version", "gta_sizeof_attn_desc",
+    "gta_attn_fwd_launch_info", "gta_attn_fwd_workspace_bytes", "gta_strerror", "gta_abi_version", "gta_sizeof_attn_desc",
 )
 
 
@@ -70,7 +74,9 @@ def lib():
             raise GtaError("GtaAttnDesc layout mismatch between gta_hip.h and gta_amd/native.py")
         L.gta_build_view_reps.argtypes = [c_void_p, c_int32, c_int32, c_void_p, c_void_p]
         L.gta_build_so2_table.argtypes = [c_void_p, c_int32, c_int32, c_float, c_float, c_int32, c_void_p, c_void_p]
-        L.gta_attn_fwd.argtypes = [ctypes.POINTER(GtaAttnDesc)] + [c_void_p] * 12
+        L.gta_attn_fwd.argtypes = [ctypes.POINTER(GtaAttnDesc)] + [c_void_p] * 12 + [c_int64, c_void_p]
+        L.gta_attn_fwd_workspace_bytes.argtypes = [ctypes.POINTER(GtaAttnDesc)]
+        L.gta_attn_fwd_workspace_bytes.restype = c_int64
         L.gta_attn_fwd_supported.argtypes = [ctypes.POINTER(GtaAttnDesc)]
         L.gta_attn_fwd_launch_info.argtypes = [ctypes.POINTER(GtaAttnDesc)] + [ctypes.POINTER(c_int32)] * 3
         if hasattr(L, "gta_attn_bwd"):
@@ -144,11 +150,19 @@ def make_desc(q, k, v, out, f_dims: dict, so3_degree: int, Nq: int, Nk: int, sca
     return d
 
 
-def attn_fwd(desc: GtaAttnDesc, q, k, v, vrep_q, vrep_k, cs_q, cs_k, trans_coeff, tau, out, lse):
-    _require_cuda(q, k, v, out)
+def attn_fwd(desc: GtaAttnDesc, q, k, v, vrep_q, vrep_k, cs_q, cs_k, trans_coeff, tau, out, lse,
+             workspace: Optional[torch.Tensor] = None):
+    """workspace: uint8 CUDA tensor of >= attn_fwd_workspace_bytes(desc) bytes selects the two-stage
+    plan (K/V pre-pass + lean attention kernel); None selects the single fused kernel."""
+    _require_cuda(q, k, v, out, workspace)
     check(lib().gta_attn_fwd(ctypes.byref(desc), _ptr(q), _ptr(k), _ptr(v), _ptr(vrep_q), _ptr(vrep_k),
                              _ptr(cs_q), _ptr(cs_k), _ptr(trans_coeff), _ptr(tau), _ptr(out), _ptr(lse),
-                             _stream()), "gta_attn_fwd")
+                             _ptr(workspace), 0 if workspace is None else workspace.numel(), _stream()),
+          "gta_attn_fwd")
+
+
+def attn_fwd_workspace_bytes(desc: GtaAttnDesc) -> int:
+    return int(lib().gta_attn_fwd_workspace_bytes(ctypes.byref(desc)))
 
 
 def attn_fwd_supported(desc: GtaAttnDesc) -> int:

@@ -35,6 +35,11 @@ extern "C" {
 #define GTA_FLAG_V_TRANSFORM   (1u << 0) /* gta.py: v_transform=True (default)                 */
 #define GTA_FLAG_EUCLID        (1u << 1) /* gta.py:146-156 + layers.py:213-224 (not fused yet) */
 #define GTA_FLAG_PRETRANSFORMED (1u << 2) /* q,k,v already carry rho; only rho_q^-1 on output   */
+#define GTA_FLAG_FUSED_KV      (1u << 3) /* force the single-kernel path (rho_k inside the loop)  */
+#define GTA_FLAG_PREP_ONLY     (1u << 5) /* two-stage plan: run only the K/V pre-pass (fills workspace) */
+#define GTA_FLAG_KV_READY      (1u << 4) /* workspace already holds K'/V' for these k,v,reps:     */
+                                         /* skip the pre-pass (several query sets, one key set)   */
+#define GTA_FLAG_WG8           (1u << 9) /* tuning: 8-wave (256-row) workgroups in the two-stage plan */
 #define GTA_FLAG_NO_DMA        (1u << 8) /* debug: stage K/V tiles through VGPRs, not LDS-DMA  */
 
 /* error codes */
@@ -110,7 +115,17 @@ int gta_attn_fwd(const GtaAttnDesc* desc,
                  const float* vrep_q, const float* vrep_k,
                  const float* cs_q, const float* cs_k,
                  const float* trans_coeff, const float* tau,
-                 void* out, float* lse, void* stream);
+                 void* out, float* lse,
+                 void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Two execution plans, same results:
+ *   workspace == NULL (or GTA_FLAG_FUSED_KV): ONE kernel; rho_k is applied to each K/V tile inside
+ *       the attention loop (re-done once per 128-row query tile).
+ *   workspace of >= gta_attn_fwd_workspace_bytes(desc) bytes: a K/V pre-pass writes K' = rho_k K,
+ *       V' = rho_k V once as bf16 tile images into the workspace, then a lean attention kernel
+ *       streams them.  The workspace content stays valid for other query sets against the same
+ *       keys (GTA_FLAG_KV_READY) and is what the backward consumes. */
+int64_t gta_attn_fwd_workspace_bytes(const GtaAttnDesc* desc);
 
 /* 0 when gta_attn_fwd has a fused kernel for this desc, else the error it would return. */
 int gta_attn_fwd_supported(const GtaAttnDesc* desc);

@@ -21,7 +21,7 @@ def err_stats(got: torch.Tensor, ref: torch.Tensor):
             "finite": bool(torch.isfinite(got).all())}
 
 
-def golden_forward(case, dtype, use_dma=True, builder="packed", device="cuda"):
+def golden_forward(case, dtype, use_dma=True, builder="packed", device="cuda", kv_mode="auto"):
     """Run one op_* fixture through the C ABI.  builder='packed': reference-style reps from the
     fixture are packed by gta_amd.pack_reps; builder='hip': reps are rebuilt on device from the
     fixture's poses/coords by gta_amd.reps (HIP rep builders)."""
@@ -41,7 +41,7 @@ def golden_forward(case, dtype, use_dma=True, builder="packed", device="cuda"):
     tc = torch.tensor([float(d["trans_coeff"])], device=device)
     out, _ = gta_amd.multihead_geometric_transform_attention(
         q, k, v, attn_fn=SimpleNamespace(scale=float(d["scale"])), f_dims=f_dims, reps=ex, trans_coeff=tc,
-        v_transform=meta["v_transform"], euclid=meta["euclid"], use_dma=use_dma)
+        v_transform=meta["v_transform"], euclid=meta["euclid"], use_dma=use_dma, kv_mode=kv_mode)
     torch.cuda.synchronize()
     return out.float().cpu(), torch.from_numpy(d["out"]).float(), meta
 
@@ -73,7 +73,7 @@ def oracle_forward(q, k, v, ex, ak, cross, trans_coeff, v_transform=True, dtype=
 
 
 def hip_forward(q, k, v, ex, ak, cross, trans_coeff, dtype, v_transform=True, use_dma=True, device="cuda",
-                return_lse=False):
+                return_lse=False, kv_mode="auto"):
     exd = {kk: vv.to(device) for kk, vv in ex.items()}
     gta_amd.pre_compute_reps_encoder(ak, exd)
     if cross:
@@ -82,6 +82,6 @@ def hip_forward(q, k, v, ex, ak, cross, trans_coeff, dtype, v_transform=True, us
     tc = torch.tensor([float(trans_coeff)], device=device) if ak["f_dims"].get("se3", 0) > 0 else None
     out = gta_amd.gta_attention(q.to(dtype).to(device), k.to(dtype).to(device), v.to(dtype).to(device),
                                 ak["f_dims"], packed, so3_degree=exd.get("gta_so3_degree", 0), trans_coeff=tc,
-                                v_transform=v_transform, use_dma=use_dma)
+                                v_transform=v_transform, use_dma=use_dma, kv_mode=kv_mode)
     torch.cuda.synchronize()
     return out

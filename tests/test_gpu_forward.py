@@ -26,11 +26,13 @@ def _check(got, ref, rel_max=REL_MAX, rel_rms=REL_RMS):
     assert st["rel_rms"] <= rel_rms, st
 
 
+@pytest.mark.parametrize("kv_mode", ["fused", "prepass"])
 @pytest.mark.parametrize("builder", ["packed", "hip"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", FUSED_CASES)
-def test_golden_fixture(case, dtype, builder):
-    got, ref, _ = C.golden_forward(case, dtype, True, builder)
+def test_golden_fixture(case, dtype, builder, kv_mode):
+    """Every fused-eligible reference fixture through both execution plans of gta_attn_fwd."""
+    got, ref, _ = C.golden_forward(case, dtype, True, builder, kv_mode=kv_mode)
     _check(got, ref)
 
 
@@ -38,3 +40,67 @@ def test_golden_fixture(case, dtype, builder):
 def test_golden_fixture_vgpr_staging(case):
     got, ref, _ = C.golden_forward(case, torch.bfloat16, False, "packed")
     _check(got, ref)
+
+
+SHAPES = {
+    # name: (B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3)   -- SURVEY 8 shapes at B small enough for the CPU oracle
+    "C1": (2, 4, 2, 64, 2, 64, {"se3": 32, "so2": 32}, 8, 0),
+    "CL-enc": (2, 6, 2, 300, 2, 300, {"se3": 32, "so2": 32}, 8, 0),
+    "CL-dec": (1, 6, 3, 853, 2, 300, {"se3": 32, "so2": 32}, 8, 0),
+    "MS-enc": (2, 8, 5, 256, 5, 256, {"triv": 0, "se3": 48, "so3": 24, "so2": 24}, 6, 2),
+    "MS-dec": (1, 8, 5, 512, 5, 256, {"triv": 0, "se3": 48, "so3": 24, "so2": 24}, 6, 2),
+    "DT": (1, 16, 1, 1024, 1, 1024, {"so2": 64}, 16, 0),
+    "ragged": (1, 3, 3, 37, 2, 45, {"triv": 8, "se3": 16, "so2": 8}, 2, 0),     # tails on both sides
+}
+
+
+@pytest.mark.parametrize("kv_mode", ["fused", "prepass", "prepass8"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", sorted(SHAPES))
+def test_baseline_shapes_vs_oracle(shape, dtype, kv_mode):
+    """HIP vs the CPU oracle (fp32) on seeded synthetic inputs at the BASELINE shapes."""
+    B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3 = SHAPES[shape]
+    q, k, v, ex, ak, cross = C.synth_inputs(B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, dtype, seed=3)
+    if dtype == torch.bfloat16:      # feed the oracle the same rounded inputs the kernel sees
+        q, k, v = q.bfloat16().float(), k.bfloat16().float(), v.bfloat16().float()
+    ref = C.oracle_forward(q, k, v, ex, ak, cross, 0.01)
+    got = C.hip_forward(q, k, v, ex, ak, cross, 0.01, dtype, kv_mode=kv_mode).float().cpu()
+    _check(got, ref)
+
+
+def test_lse_matches_logsumexp():
+    """The saved log-sum-exp (needed by backward) equals logsumexp of the scaled logits of q', k'."""
+    from oracle import gta_oracle as O
+    import gta_amd
+    B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3 = SHAPES["MS-enc"]
+    q, k, v, ex, ak, cross = C.synth_inputs(1, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, torch.float32, seed=4)
+    reps = O.encoder_reps(ak, ex)
+    qt, kt, _ = O.transform_qkv(q, k, v, f_dims, reps, 0.01)
+    ref = torch.logsumexp(qt @ kt.transpose(-1, -2) * 96 ** -0.5, -1)
+    exd = {kk: vv.cuda() for kk, vv in ex.items()}
+    gta_amd.pre_compute_reps_encoder(ak, exd)
+    packed = gta_amd.pack_reps(exd, f_dims)
+    from gta_amd import native
+    qd, kd, vd = q.cuda(), k.cuda(), v.cuda()
+    out = torch.empty_like(qd)
+    lse = torch.empty(1, H, Nq * Pq, device="cuda")
+    for flags in (native.FLAG_V_TRANSFORM | native.FLAG_FUSED_KV, native.FLAG_V_TRANSFORM):
+        desc = native.make_desc(qd, kd, vd, out, f_dims, so3, Nq, Nk, 96 ** -0.5, flags)
+        ws = None if flags & native.FLAG_FUSED_KV else torch.empty(native.attn_fwd_workspace_bytes(desc), device="cuda", dtype=torch.uint8)
+        native.attn_fwd(desc, qd, kd, vd, packed["vrep_q"], packed["vrep_k"], packed["cs_q"], packed["cs_k"],
+                        torch.tensor([0.01], device="cuda"), None, out, lse, ws)
+        torch.cuda.synchronize()
+        assert (lse.cpu() - ref).abs().max() < 2e-2
+
+
+def test_global_frame_invariance_full_size():
+    """Size-independent property: replacing every extrinsic E_n by E_n g leaves the
+    output unchanged -- checked on the device path at the headline shape, B=4, bf16."""
+    from oracle import gta_oracle as O
+    B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3 = SHAPES["MS-enc"]
+    q, k, v, ex, ak, cross = C.synth_inputs(4, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, torch.bfloat16, seed=5)
+    g = O.random_extrinsics(1, 2, torch.Generator().manual_seed(9))[:, 1:2]
+    ex2 = dict(ex, input_transforms=ex["input_transforms"] @ g)
+    a = C.hip_forward(q, k, v, ex, ak, cross, 1.0, torch.bfloat16, kv_mode="prepass").float().cpu()
+    b = C.hip_forward(q, k, v, ex2, ak, cross, 1.0, torch.bfloat16, kv_mode="prepass").float().cpu()
+    _check(b, a)

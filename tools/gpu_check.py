@@ -72,15 +72,14 @@ def goldens():
             print(f"{case:16s} skipped (not fused-eligible: {meta['f_dims']}, euclid={meta['euclid']})")
             continue
         for dtype in (torch.float32, torch.bfloat16):
-            for dma in (True, False):
+            for mode in ("fused", "vgpr", "prepass"):
                 for builder in ("packed", "hip"):
-                    if builder == "hip" and (not dma):
+                    dma = mode != "vgpr"
+                    if builder == "hip" and mode != "prepass":
                         continue
-                    if builder == "hip" and (meta.get("extra", {}).get("shared_freqs") is None) and False:
-                        continue
-                    tag = f"{case}/{str(dtype)[6:]}/{'dma' if dma else 'vgpr'}/{builder}"
+                    tag = f"{case}/{str(dtype)[6:]}/{mode}/{builder}"
                     try:
-                        got, ref, _ = C.golden_forward(case, dtype, dma, builder)
+                        got, ref, _ = C.golden_forward(case, dtype, dma, builder, kv_mode="prepass" if mode == "prepass" else "fused")
                         st = C.err_stats(got, ref)
                         rows.append(dict(tag=tag, **st))
                         print(f"{tag:44s} max_abs={st['max_abs']:.3e} ref_max={st['ref_max']:.2f} "
@@ -114,17 +113,17 @@ def oracle_shapes(quick):
         ref = C.oracle_forward(q, k, v, ex, ak, cross, 0.01)
         t_or = time.time() - t0
         ref64 = C.oracle_forward(q, k, v, ex, ak, cross, 0.01, dtype=torch.float64) if name in ("C1", "CL-enc") else None
-        for dtype in (torch.float32, torch.bfloat16):
+        for dtype, mode in ((torch.float32, "prepass"), (torch.bfloat16, "prepass"), (torch.bfloat16, "fused")):
             try:
-                got = C.hip_forward(q, k, v, ex, ak, cross, 0.01, dtype).float().cpu()
+                got = C.hip_forward(q, k, v, ex, ak, cross, 0.01, dtype, kv_mode=mode).float().cpu()
                 # compare against the oracle fed the same (rounded) inputs
                 if dtype == torch.bfloat16:
                     refd = C.oracle_forward(q.bfloat16().float(), k.bfloat16().float(), v.bfloat16().float(), ex, ak, cross, 0.01)
                 else:
                     refd = ref
                 st = C.err_stats(got, refd)
-                rows.append(dict(shape=name, dtype=str(dtype), **st))
-                print(f"{name:8s} {str(dtype)[6:]:9s} max_abs={st['max_abs']:.3e} ref_max={st['ref_max']:.2f} "
+                rows.append(dict(shape=name, dtype=str(dtype), mode=mode, **st))
+                print(f"{name:8s} {str(dtype)[6:]:9s} {mode:8s} max_abs={st['max_abs']:.3e} ref_max={st['ref_max']:.2f} "
                       f"rel_rms={st['rel_rms']:.3e} finite={st['finite']} (oracle {t_or:.2f}s)", flush=True)
             except Exception as e:  # noqa: BLE001
                 rows.append(dict(shape=name, dtype=str(dtype), error=repr(e)))
@@ -145,7 +144,8 @@ def timing(quick):
             if name == "C1" and B != 32:
                 continue
             for dtype in (torch.bfloat16, torch.float32):
-                for dma in (True, False):
+                for mode in ("prepass", "fused"):
+                    dma = mode
                     try:
                         q, k, v, ex, ak, cross = C.synth_inputs(B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, dtype, seed=2)
                         exd = {kk: vv.cuda() for kk, vv in ex.items()}
@@ -159,7 +159,7 @@ def timing(quick):
                         kd = k.to(dtype).cuda().permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
                         vd = v.to(dtype).cuda().permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
                         fn = lambda: gta_amd.gta_attention(qd, kd, vd, f_dims, packed, so3_degree=so3, trans_coeff=tc,
-                                                           use_dma=dma)
+                                                           kv_mode=mode)
                         for _ in range(3):
                             fn()
                         torch.cuda.synchronize()
@@ -176,7 +176,7 @@ def timing(quick):
                         tf = flops / (ms * 1e-3) / 1e12
                         rows.append(dict(shape=name, B=B, dtype=str(dtype), dma=dma, ms=ms, tflops=tf,
                                          mtok_s=B * Tq / (ms * 1e-3) / 1e6))
-                        print(f"{name:8s} B={B:3d} {str(dtype)[6:]:9s} {'dma ' if dma else 'vgpr'} {ms:8.3f} ms  "
+                        print(f"{name:8s} B={B:3d} {str(dtype)[6:]:9s} {mode:8s} {ms:8.3f} ms  "
                               f"{tf:7.1f} TFLOP/s ({100 * tf / 2500:.1f}% of bf16 MFMA peak)  "
                               f"{B * Tq / (ms * 1e-3) / 1e6:8.2f} Mtok/s", flush=True)
                     except Exception as e:  # noqa: BLE001
