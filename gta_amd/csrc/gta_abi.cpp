@@ -6,6 +6,7 @@
 
 #include "../../include/gta_hip.h"
 #include "gta_fwd_params.h"
+#include "gta_bwd_params.h"
 
 // chunk-descriptor constants (mirrors gta_common.h, which is device-only)
 #define HALF_ID 0u
@@ -18,6 +19,7 @@ int gta_fwd_dispatch(const GtaFwdParams& p, int dhp, int esz, bool dma, int n_wg
 long gta_fwd2_workspace_bytes(int B, int H, int Tk, int dhp);
 int gta_fwd2_lds_bytes(int dhp, int nq);
 int gta_fwd2_dispatch(GtaFwdParams& p, int dhp, int esz, bool run_prep, bool run_flash, int nw, hipStream_t stream);
+int gta_bwd_dispatch(const GtaBwdParams& p, int dhp, int esz, hipStream_t stream);
 
 namespace {
 
@@ -179,6 +181,98 @@ extern "C" int gta_attn_fwd(const GtaAttnDesc* d, const void* q, const void* k, 
         return GTA_OK;
     }
     rc = gta_fwd_dispatch(p, padded_dh(d->dh), esz, !(d->flags & GTA_FLAG_NO_DMA), (int)n_wg, (hipStream_t)stream);
+    if (rc) return fail(rc, rc == GTA_E_LAUNCH ? hipGetErrorString(hipGetLastError()) : "no kernel instance");
+    return GTA_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct BwdLayout { int64_t off_qimg, off_stats, off_dc, off_kv, total; int n_prep, n_dq, n_dkv; };
+BwdLayout bwd_layout(const GtaAttnDesc* d) {
+    BwdLayout L;
+    const int dhp = padded_dh(d->dh);
+    const int64_t n_qt = (d->Tq + 63) / 64, n_kt = (d->Tk + 63) / 64;
+    const int64_t stage = 2LL * 64 * dhp * 2;
+    L.n_prep = (int)(d->B * d->H * n_qt);
+    L.n_dq = d->B * d->H * ((d->Tq + 127) / 128);
+    L.n_dkv = d->B * d->H * ((d->Tk + 127) / 128);
+    auto al = [](int64_t x) { return (x + 255) & ~255LL; };
+    L.off_qimg = 0;
+    L.off_stats = al(L.off_qimg + (int64_t)d->B * d->H * n_qt * stage);
+    L.off_dc = al(L.off_stats + (int64_t)d->B * d->H * n_qt * 128 * 4);
+    L.off_kv = al(L.off_dc + (int64_t)(L.n_prep + L.n_dq + L.n_dkv) * 4);
+    L.total = al(L.off_kv + (int64_t)d->B * d->H * n_kt * stage);
+    return L;
+}
+}  // namespace
+
+extern "C" int64_t gta_attn_bwd_workspace_bytes(const GtaAttnDesc* desc) {
+    if (gta_attn_fwd_supported(desc)) return 0;
+    return bwd_layout(desc).total;
+}
+
+extern "C" int gta_attn_bwd(const GtaAttnDesc* d, const void* q, const void* k, const void* v, const void* out,
+                            const void* dout, const float* lse, const float* vrep_q, const float* vrep_k,
+                            const float* cs_q, const float* cs_k, const float* trans_coeff, const float* tau,
+                            const void* kv_images, void* dq, void* dk, void* dv, const int64_t* dqkv_stride,
+                            const int64_t* dout_stride, float* dtrans_coeff, void* workspace, int64_t workspace_bytes,
+                            void* stream) {
+    int rc = check_common(d);
+    if (rc) return rc;
+    if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || !dqkv_stride || !dout_stride || !workspace)
+        return fail(GTA_E_BADARG, "null argument");
+    if (d->flags & GTA_FLAG_PRETRANSFORMED) return fail(GTA_E_UNSUPPORTED, "backward of the pretransformed mode");
+    GtaBwdParams p;
+    memset(&p, 0, sizeof p);
+    rc = build_ctab(d, p.ctab);
+    if (rc) return rc;
+    const bool need_view = d->d_se3 > 0 || d->d_so3 > 0, need_cs = d->d_so2 > 0;
+    if (need_view && (!vrep_q || !vrep_k)) return fail(GTA_E_BADARG, "se3/so3 slabs need vrep_q and vrep_k");
+    if (need_cs && (!cs_q || !cs_k)) return fail(GTA_E_BADARG, "so2 slab needs cs_q and cs_k");
+    const int esz = d->dtype == GTA_DTYPE_BF16 ? 2 : 4;
+    for (int i = 0; i < 9; ++i) if ((dqkv_stride[i] * esz) % 16) return fail(GTA_E_BADARG, "gradient strides must keep rows 16-byte aligned");
+    for (int i = 0; i < 3; ++i) if ((dout_stride[i] * esz) % 16) return fail(GTA_E_BADARG, "dout strides must keep rows 16-byte aligned");
+    const BwdLayout L = bwd_layout(d);
+    if (workspace_bytes < L.total) return fail(GTA_E_BADARG, "workspace smaller than gta_attn_bwd_workspace_bytes()");
+    char* ws = (char*)workspace;
+    if (!kv_images) {     // recompute K'/V' images with the forward's pre-pass
+        GtaFwdParams f;
+        memset(&f, 0, sizeof f);
+        memcpy(f.ctab, p.ctab, sizeof f.ctab);
+        f.k = k; f.v = v; f.kp = ws + L.off_kv;
+        f.vrep_k = need_view ? vrep_k : nullptr; f.cs_k = need_cs ? cs_k : nullptr; f.trans_coeff = trans_coeff;
+        f.k_sb = d->k_stride[0]; f.k_sh = d->k_stride[1]; f.k_st = d->k_stride[2];
+        f.v_sb = d->v_stride[0]; f.v_sh = d->v_stride[1]; f.v_st = d->v_stride[2];
+        f.B = d->B; f.H = d->H; f.Tq = d->Tq; f.Tk = d->Tk; f.Nq = d->Nq; f.Nk = d->Nk;
+        f.Pq = d->Tq / d->Nq; f.Pk = d->Tk / d->Nk; f.invPq = 1.0f / f.Pq; f.invPk = 1.0f / f.Pk;
+        f.dh = d->dh; f.nso2 = d->d_so2 / 2; f.flags = d->flags; f.scale = d->scale;
+        rc = gta_fwd2_dispatch(f, padded_dh(d->dh), esz, true, false, 4, (hipStream_t)stream);
+        if (rc) return fail(rc, "K/V pre-pass launch failed");
+        kv_images = ws + L.off_kv;
+    }
+    p.q = q; p.k = k; p.v = v; p.out = out; p.dout = dout; p.lse = lse; p.dq = dq; p.dk = dk; p.dv = dv;
+    p.vrep_q = need_view ? vrep_q : nullptr; p.vrep_k = need_view ? vrep_k : nullptr;
+    p.cs_q = need_cs ? cs_q : nullptr; p.cs_k = need_cs ? cs_k : nullptr;
+    p.trans_coeff = trans_coeff; p.tau = tau;
+    p.kvimg = kv_images; p.qimg = ws + L.off_qimg; p.stats = (float*)(ws + L.off_stats);
+    p.dc_partial = (float*)(ws + L.off_dc); p.dtrans_coeff = (d->d_se3 > 0) ? dtrans_coeff : nullptr;
+    p.q_sb = d->q_stride[0]; p.q_sh = d->q_stride[1]; p.q_st = d->q_stride[2];
+    p.k_sb = d->k_stride[0]; p.k_sh = d->k_stride[1]; p.k_st = d->k_stride[2];
+    p.v_sb = d->v_stride[0]; p.v_sh = d->v_stride[1]; p.v_st = d->v_stride[2];
+    p.o_sb = d->o_stride[0]; p.o_sh = d->o_stride[1]; p.o_st = d->o_stride[2];
+    p.do_sb = dout_stride[0]; p.do_sh = dout_stride[1]; p.do_st = dout_stride[2];
+    p.dq_sb = dqkv_stride[0]; p.dq_sh = dqkv_stride[1]; p.dq_st = dqkv_stride[2];
+    p.dk_sb = dqkv_stride[3]; p.dk_sh = dqkv_stride[4]; p.dk_st = dqkv_stride[5];
+    p.dv_sb = dqkv_stride[6]; p.dv_sh = dqkv_stride[7]; p.dv_st = dqkv_stride[8];
+    p.dc_off_prep = 0; p.dc_off_dq = L.n_prep; p.dc_off_dkv = L.n_prep + L.n_dq; p.dc_total = L.n_prep + L.n_dq + L.n_dkv;
+    p.B = d->B; p.H = d->H; p.Tq = d->Tq; p.Tk = d->Tk; p.Nq = d->Nq; p.Nk = d->Nk;
+    p.Pq = d->Tq / d->Nq; p.Pk = d->Tk / d->Nk; p.invPq = 1.0f / (float)p.Pq; p.invPk = 1.0f / (float)p.Pk;
+    p.dh = d->dh; p.nso2 = d->d_so2 / 2; p.flags = d->flags; p.scale = d->scale;
+    if (d->H > 65535 || d->B > 65535) return fail(GTA_E_UNSUPPORTED, "B or H above 65535");
+    rc = gta_bwd_dispatch(p, padded_dh(d->dh), esz, (hipStream_t)stream);
     if (rc) return fail(rc, rc == GTA_E_LAUNCH ? hipGetErrorString(hipGetLastError()) : "no kernel instance");
     return GTA_OK;
 }

@@ -1,0 +1,807 @@
+// gta_bwd.hip -- backward of GTA attention for gfx950.
+//
+// The reference has no hand-written backward: autograd differentiates gta.py:92-279 and
+// layers.py:202-211, saving q', k', v' and the dense [B,H,Tq,Tk] attention matrix per layer.
+// Here, with A_q = (E_q.m)^T, B_k = inv(E_k).m, C_q = E_q.m (and D, R for so3/so2):
+//     q' = A_q q      k' = B_k k      v' = B_k v      o~ = softmax(c1 q' k'^T) v'      o = C_q o~
+//   do~ = C_q^T do  = A_q do          (C_q^T == A_q: same matrices as the Q transform)
+//   D   = rowsum(do~ . o~) = rowsum(do . o)
+//   dS  = P . (dP - D),  dP = do~ v'^T
+//   dq' = c1 dS k'      dk' = c1 dS^T q'      dv' = P^T do~
+//   dq  = A_q^T dq'     dk  = B_k^T dk'       dv  = B_k^T dv'
+//   d trans_coeff = sum over tokens / se3 blocks of the entries of A_q, B_k, C_q that carry c
+//                   (gta.py:40-44): dq'_3 (t_E . q_{0:3}) + (dk'_{0:3} . t_Einv) k_3 + (dv'.t_Einv) v_3
+//                   + (do_{0:3} . t_E) o_3,  t_M = M[0:3,3]
+// No gradient flows into the so3/so2 reps or the poses (gta.py:194-198 detach; data).
+//
+// Kernels (all tiles are the same rotation-swizzled bf16 "tile images" the forward streams):
+//   gta_bwd_prep_kernel  per 64-query tile: raw q, do, o -> LDS (LDS-DMA); rho on q (prescaled by
+//                        c1*log2e) and on do; writes Q''/dO~ images + [lse*log2e | D] per row
+//   gta_bwd_dq_kernel    128 query rows / workgroup, loops over K'/V' images (forward workspace):
+//                        S^T, dP^T = V' dO~^T, dS^T, dQ'^T += K'^T dS^T (K'^T by transpose-read);
+//                        epilogue applies A_q^T per chunk and stores dq
+//   gta_bwd_dkv_kernel   128 keys / workgroup (K'/V' fragments in VGPRs), loops over Q''/dO~ images:
+//                        S, P, dP, dS; dV'^T += dO~^T P, dK'^T += Q''^T dS (transpose-reads);
+//                        epilogue applies B_k^T per chunk and stores dk, dv
+//   gta_reduce_kernel    deterministic sum of the per-workgroup d trans_coeff partials
+#include "gta_common.h"
+#include "gta_fwd_params.h"
+#include "gta_bwd_params.h"
+#include "../../include/gta_hip.h"
+
+namespace {
+
+constexpr int BN = 64;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+template <int IMM>
+GTA_DEV u32x2_t lds_tr16_b64(uint32_t addr) {
+    u32x2_t v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(IMM));
+    return v;
+}
+GTA_DEV uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+// backward per-view records (floats).  q side:
+//   [0:16) A = (E.m)^T   [16:32) C = E.m   [32:44) D1  [44:84) D2  [84:96) D1^T  [96:136) D2^T
+//   [136:140) t_E = E[0:3,3] (unmasked), pad
+// k side:
+//   [0:16) B = inv(E).m  [16:32) B^T       [32:44) D1  [44:84) D2  [84:96) D1^T  [96:136) D2^T
+//   [136:140) t_Einv = inv(E)[0:3,3], pad
+#define BREC 140
+#define BREC_M 0
+#define BREC_MT 16
+#define BREC_D1 32
+#define BREC_D2 44
+#define BREC_D1T 84
+#define BREC_D2T 96
+#define BREC_T 136
+
+// side 0 = q (A, C from the "inv" slot), side 1 = k (B, B^T from the "rep" slot)
+GTA_DEV void stage_brec(float* rec, const float* vrep, long view0, int cnt, int side, float tc, int tid, int nthreads) {
+    for (int i = tid; i < cnt * BREC; i += nthreads) {
+        const int n = i / BREC, e = i - n * BREC;
+        const float* src = vrep + (view0 + n) * GTA_VREP_STRIDE;
+        const int slot = side == 0 ? GTA_VREP_INV : GTA_VREP_REP;
+        float val = 0.f;
+        if (e < 32) {
+            const int ee = e & 15, r = ee >> 2, c = ee & 3;
+            // q side: first = (E.m)^T, second = E.m ; k side: first = M.m, second = (M.m)^T
+            const bool transpose = (side == 0) ? (e < 16) : (e >= 16);
+            const int sr = transpose ? c : r, sc = transpose ? r : c;
+            const float m = (sr == 3) ? (sc == 3 ? 1.f : 0.f) : (sc == 3 ? tc : 1.f);
+            val = src[slot + sr * 4 + sc] * m;
+        } else if (e < BREC_D2) {
+            const int ee = e - BREC_D1, r = ee >> 2, c = ee & 3;
+            val = c < 3 ? src[GTA_VREP_D1 + r * 3 + c] : 0.f;
+        } else if (e < BREC_D1T) {
+            const int ee = e - BREC_D2, r = ee >> 3, c = ee & 7;
+            val = c < 5 ? src[GTA_VREP_D2 + r * 5 + c] : 0.f;
+        } else if (e < BREC_D2T) {
+            const int ee = e - BREC_D1T, r = ee >> 2, c = ee & 3;
+            val = c < 3 ? src[GTA_VREP_D1 + c * 3 + r] : 0.f;
+        } else if (e < BREC_T) {
+            const int ee = e - BREC_D2T, r = ee >> 3, c = ee & 7;
+            val = c < 5 ? src[GTA_VREP_D2 + c * 5 + r] : 0.f;
+        } else {
+            const int r = e - BREC_T;
+            val = r < 3 ? src[slot + r * 4 + 3] : 0.f;
+        }
+        rec[i] = val;
+    }
+}
+
+// raw rows of one 64-row tile -> LDS by LDS-DMA, rotation-swizzled (as the forward pre-pass)
+template <int U>
+GTA_DEV void dma_raw_tile(char* dst, const char* gbase, long row_stride_bytes, int row0, int n_rows_total,
+                          int real_units, int wave, int lane) {
+    constexpr int NI = BN * U / 256;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int u0 = (wave * NI + i) * 64, u = u0 + lane;
+        const int r = u / U, pos = u - r * U;
+        constexpr int tz = (U % 16 == 0) ? 4 : (U % 8 == 0) ? 3 : (U % 4 == 0) ? 2 : (U % 2 == 0) ? 1 : 0;
+        const int rot = (r >> (4 - tz)) & ((1 << tz) - 1);
+        int gu = pos - rot;
+        gu = gu < 0 ? gu + U : gu;
+        gu = gu < real_units ? gu : real_units - 1;
+        int gr = row0 + r;
+        gr = gr < n_rows_total ? gr : n_rows_total - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + (long)gr * row_stride_bytes + gu * 16),
+                                         (__attribute__((address_space(3))) void*)(dst + u0 * 16), 16, 0, 0);
+    }
+}
+template <int U, int ESZ>
+GTA_DEV void raw_chunk(const char* raw, int r, int c, float* x) {
+    if (ESZ == 2) {
+        unpack8(*reinterpret_cast<const u32x4_t*>(raw + (r * U + swz<U>(r, c)) * 16), x);
+    } else {
+        const f32x4_t a = *reinterpret_cast<const f32x4_t*>(raw + (r * U + swz<U>(r, 2 * c)) * 16);
+        const f32x4_t b = *reinterpret_cast<const f32x4_t*>(raw + (r * U + swz<U>(r, 2 * c + 1)) * 16);
+        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+    }
+}
+template <int ESZ>
+GTA_DEV void g_load_chunk(const char* rowptr, int c, float* x) {
+    if (ESZ == 2) {
+        unpack8(*reinterpret_cast<const u32x4_t*>(rowptr + c * 16), x);
+    } else {
+        const f32x4_t a = *reinterpret_cast<const f32x4_t*>(rowptr + c * 32);
+        const f32x4_t b = *reinterpret_cast<const f32x4_t*>(rowptr + c * 32 + 16);
+        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+    }
+}
+template <int ESZ>
+GTA_DEV void g_store_chunk(char* rowptr, int c, const float* x) {
+    if (ESZ == 2) {
+        *reinterpret_cast<u32x4_t*>(rowptr + c * 16) = pack8(x);
+    } else {
+        *reinterpret_cast<f32x4_t*>(rowptr + c * 32) = f32x4_t{x[0], x[1], x[2], x[3]};
+        *reinterpret_cast<f32x4_t*>(rowptr + c * 32 + 16) = f32x4_t{x[4], x[5], x[6], x[7]};
+    }
+}
+GTA_DEV u32x4_t pack_acc8(const f32x16_t& a, int t) {   // accumulator registers 8t..8t+7 -> bf16x8
+    u32x4_t w;
+    w.x = pack_bf16x2(a[8 * t + 0], a[8 * t + 1]); w.y = pack_bf16x2(a[8 * t + 2], a[8 * t + 3]);
+    w.z = pack_bf16x2(a[8 * t + 4], a[8 * t + 5]); w.w = pack_bf16x2(a[8 * t + 6], a[8 * t + 7]);
+    return w;
+}
+// workgroup sum of one float per thread (256 threads) -> returned to thread 0
+GTA_DEV float wg_sum256(float v, float* scratch /*>= 4 floats LDS*/, int tid) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    if ((tid & 63) == 0) scratch[tid >> 6] = v;
+    __syncthreads();
+    return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+}
+
+// ================================================================================================
+// 1. q-side pre-pass
+// ================================================================================================
+template <int DHP, int ESZ>
+struct BPrepSmem {
+    static constexpr int U = DHP * ESZ / 16;
+    static constexpr int RAW = BN * DHP * ESZ;
+    static constexpr int IMG = BN * DHP * 2;
+    static constexpr int OFF_REC = 0;
+    static constexpr int REC_BYTES = GTA_MAX_VIEWS * BREC * 4;
+    static constexpr int OFF_RQ = REC_BYTES;
+    static constexpr int OFF_RDO = OFF_RQ + RAW;
+    static constexpr int OFF_RO = OFF_RDO + RAW;
+    static constexpr int OFF_IQ = (ESZ == 2) ? OFF_RQ : OFF_RO + RAW;      // images in place for bf16 input
+    static constexpr int OFF_IDO = (ESZ == 2) ? OFF_RDO : OFF_IQ + IMG;
+    static constexpr int OFF_D = (ESZ == 2) ? OFF_RO + RAW : OFF_IDO + IMG;  // D[64] + 4 scratch floats
+    static constexpr int TOTAL = OFF_D + 64 * 4 + 16;
+};
+
+template <int DHP, int ESZ>
+__global__ __launch_bounds__(256) void gta_bwd_prep_kernel(const GtaBwdParams p) {
+    using S = BPrepSmem<DHP, ESZ>;
+    constexpr int CHP = DHP / 8, U = S::U, IMG = S::IMG;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int n_qt = gridDim.x;
+    const int ch_real = p.dh >> 3, real_units = p.dh * ESZ / 16;
+
+    const char* qg = (const char*)p.q + ((long)b * p.q_sb + (long)h * p.q_sh) * ESZ;
+    const char* dog = (const char*)p.dout + ((long)b * p.do_sb + (long)h * p.do_sh) * ESZ;
+    const char* og = (const char*)p.out + ((long)b * p.o_sb + (long)h * p.o_sh) * ESZ;
+    dma_raw_tile<U>(smem + S::OFF_RQ, qg, p.q_st * ESZ, j * BN, p.Tq, real_units, wave, lane);
+    dma_raw_tile<U>(smem + S::OFF_RDO, dog, p.do_st * ESZ, j * BN, p.Tq, real_units, wave, lane);
+    dma_raw_tile<U>(smem + S::OFF_RO, og, p.o_st * ESZ, j * BN, p.Tq, real_units, wave, lane);
+
+    float* rec = reinterpret_cast<float*>(smem + S::OFF_REC);
+    float* dsum = reinterpret_cast<float*>(smem + S::OFF_D);
+    const float tc = p.trans_coeff ? *p.trans_coeff : 1.0f;
+    if (p.vrep_q) stage_brec(rec, p.vrep_q, (long)b * p.Nq, p.Nq, 0, tc, tid, 256);
+    if (tid < 64) dsum[tid] = 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const float qscale = p.scale * LOG2E / (p.tau ? *p.tau : 1.0f);
+    const bool xo = (p.flags & GTA_FLAG_V_TRANSFORM) != 0;
+    const int r = lane;
+    const int t_raw = j * BN + r;
+    const bool valid = t_raw < p.Tq;
+    const int t = valid ? t_raw : p.Tq - 1;
+    const int n = view_of(t, p.Pq, p.invPq);
+    const float* rc = rec + n * BREC;
+    float dpart = 0.f, dcpart = 0.f;
+#pragma unroll
+    for (int it = 0; it < CHP / 4; ++it) {
+        const int c = wave + 4 * it;
+        float x[2][8];
+        if (c < ch_real && valid) {
+            const uint32_t desc = p.ctab[c];
+            float o8[8];
+            raw_chunk<U, ESZ>(smem + S::OFF_RQ, r, c, x[0]);
+            raw_chunk<U, ESZ>(smem + S::OFF_RDO, r, c, x[1]);
+            raw_chunk<U, ESZ>(smem + S::OFF_RO, r, c, o8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dpart += x[1][i] * o8[i];
+            if (desc && xo && !(desc & GTA_CHUNK_SO3)) {     // d trans_coeff through C_q = E.m (output rep)
+                const float t0 = rc[BREC_T], t1 = rc[BREC_T + 1], t2 = rc[BREC_T + 2];
+                if (cd_lo(desc) == GTA_HALF_SE3) dcpart += (x[1][0] * t0 + x[1][1] * t1 + x[1][2] * t2) * o8[3];
+                if (cd_hi(desc) == GTA_HALF_SE3) dcpart += (x[1][4] * t0 + x[1][5] * t1 + x[1][6] * t2) * o8[7];
+            }
+            if (desc) {
+                f32x2_t cs[4];
+                if (p.cs_q) load_cs(desc, p.cs_q + ((long)b * p.Tq + t) * 2 * p.nso2, cs);
+                if (xo) chunk_apply<false, 2>(desc, rc + BREC_M, rc + BREC_D1, rc + BREC_D2, cs, x);   // q and do: same A_q
+                else    chunk_apply<false, 1>(desc, rc + BREC_M, rc + BREC_D1, rc + BREC_D2, cs, x);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[0][i] *= qscale;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { x[0][i] = 0.f; x[1][i] = 0.f; }
+        }
+        const int off = (r * CHP + swz<CHP>(r, c)) * 16;
+        *reinterpret_cast<u32x4_t*>(smem + S::OFF_IQ + off) = pack8(x[0]);
+        *reinterpret_cast<u32x4_t*>(smem + S::OFF_IDO + off) = pack8(x[1]);
+    }
+    atomicAdd(&dsum[r], dpart);
+    const float dc_wg = wg_sum256(dcpart, dsum + 64, tid);      // (includes a __syncthreads)
+    __syncthreads();
+    const long tile = ((long)b * p.H + h) * n_qt + j;
+    char* gimg = (char*)p.qimg + tile * (2L * IMG);
+    constexpr int PIECES = IMG / 1024;
+#pragma unroll
+    for (int i = 0; i < (2 * PIECES + 3) / 4; ++i) {
+        const int piece = wave + 4 * i;
+        if (piece < 2 * PIECES) {
+            const char* src = (piece < PIECES ? smem + S::OFF_IQ + piece * 1024 : smem + S::OFF_IDO + (piece - PIECES) * 1024) + lane * 16;
+            *reinterpret_cast<u32x4_t*>(gimg + piece * 1024 + lane * 16) = *reinterpret_cast<const u32x4_t*>(src);
+        }
+    }
+    // per-row statistics: [lse * log2e | D]; rows past Tq get lse = +big so that P == 0 there
+    float* st = p.stats + tile * 128;
+    if (tid < 64) {
+        const int tt = j * BN + tid;
+        st[tid] = tt < p.Tq ? p.lse[((long)b * p.H + h) * p.Tq + tt] * LOG2E : 1e30f;
+        st[64 + tid] = tt < p.Tq ? dsum[tid] : 0.f;
+    }
+    if (tid == 0) p.dc_partial[p.dc_off_prep + tile] = dc_wg;
+}
+
+// ================================================================================================
+// 2. dQ
+// ================================================================================================
+constexpr int NSTAGE = 3;
+template <int DHP>
+struct DqSmem {
+    static constexpr int CHP = DHP / 8;
+    static constexpr int IMG = BN * DHP * 2;
+    static constexpr int STAGE = 2 * IMG;
+    static constexpr int RING = NSTAGE * STAGE;
+    static constexpr int OROW = DHP + 4;
+    static constexpr int OST = 128 * OROW * 4;
+    static_assert(OST <= RING, "dQ staging must fit the ring");
+    static constexpr int OFF_RING = 0;
+    static constexpr int OFF_SCR = RING;                   // 8 floats of reduction scratch
+    static constexpr int OFF_REC = RING + 32;
+    static int total(int nviews) { return OFF_REC + nviews * BREC * 4; }
+};
+
+template <int BYTES>
+GTA_DEV void dma_linear4(char* dst, const char* src, int wave, int lane) {     // 4 waves, 1 KiB pieces
+    constexpr int PER_WAVE = BYTES / 1024 / 4;
+    static_assert(BYTES % 4096 == 0, "piece split");
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int piece = wave * PER_WAVE + i;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+    }
+}
+
+template <int DHP, int ESZ>
+__global__ __launch_bounds__(256, 2) void gta_bwd_dq_kernel(const GtaBwdParams p) {
+    using S = DqSmem<DHP>;
+    constexpr int CHP = S::CHP, KS = DHP / 16, DB = DHP / 32, BM = 128;
+    constexpr int DMA_PER_WAVE = S::STAGE / 1024 / 4;
+    constexpr int ITEMS = 2 * CHP / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    int w;
+    {
+        const int nwg = gridDim.x, L = blockIdx.x;
+        const int xcd = L & 7, idx = L >> 3, q8 = nwg >> 3, r8 = nwg & 7;
+        w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int n_q128 = (p.Tq + BM - 1) / BM;
+    const int bh = w / n_q128, qt = w - bh * n_q128;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int q0 = qt * BM;
+    const int n_tiles = (p.Tk + BN - 1) / BN;
+    const int n_qt64 = (p.Tq + BN - 1) / BN;
+    const int ch_real = p.dh >> 3;
+    char* ring = smem + S::OFF_RING;
+    float* rec = reinterpret_cast<float*>(smem + S::OFF_REC);
+    const char* kvimg = (const char*)p.kvimg + ((long)b * p.H + h) * n_tiles * (long)S::STAGE;
+
+    // Q''/dO~ images of this workgroup's two 64-row tiles -> ring stages 1,2 ; K'/V' tile 0 -> stage 0
+    const long qtile0 = ((long)b * p.H + h) * n_qt64 + 2 * qt;
+    const int n_my_qt = (2 * qt + 1 < n_qt64) ? 2 : 1;
+    dma_linear4<S::STAGE>(ring, kvimg, wave, lane);
+    dma_linear4<S::STAGE>(ring + S::STAGE, (const char*)p.qimg + qtile0 * S::STAGE, wave, lane);
+    if (n_my_qt == 2) dma_linear4<S::STAGE>(ring + 2 * S::STAGE, (const char*)p.qimg + (qtile0 + 1) * S::STAGE, wave, lane);
+
+    const int t_last = (q0 + BM - 1 < p.Tq ? q0 + BM - 1 : p.Tq - 1);
+    const int n_first = q0 / p.Pq;
+    const int n_cnt = t_last / p.Pq - n_first + 1;
+    const float tc = p.trans_coeff ? *p.trans_coeff : 1.0f;
+    if (p.vrep_q) stage_brec(rec, p.vrep_q, (long)b * p.Nq + n_first, n_cnt, 0, tc, tid, 256);
+    // per-row statistics of my query row
+    const int my_row = wave * 32 + l31;                 // 0..127 in the workgroup
+    const int my_tile = my_row >> 6;
+    float lse2 = 1e30f, Drow = 0.f;
+    if (my_tile < n_my_qt) {
+        const float* st = p.stats + (qtile0 + my_tile) * 128;
+        lse2 = st[my_row & 63];
+        Drow = st[64 + (my_row & 63)];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    bf16x8_t qf[KS], dof[KS];
+    {
+        const char* qi = ring + (1 + my_tile) * S::STAGE;
+        const int r = my_row & 63;
+        if (my_tile < n_my_qt) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int off = (r * CHP + swz<CHP>(r, 2 * ks + lh)) * 16;
+                qf[ks] = *reinterpret_cast<const bf16x8_t*>(qi + off);
+                dof[ks] = *reinterpret_cast<const bf16x8_t*>(qi + S::IMG + off);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const u32x4_t z = {0, 0, 0, 0};
+                qf[ks] = __builtin_bit_cast(bf16x8_t, z);
+                dof[ks] = __builtin_bit_cast(bf16x8_t, z);
+            }
+        }
+    }
+    __syncthreads();
+    if (n_tiles > 1) dma_linear4<S::STAGE>(ring + S::STAGE, kvimg + (long)S::STAGE, wave, lane);
+
+    f32x16_t dq[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dq[d][i] = 0.f;
+
+    int koff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) koff[ks] = (l31 * CHP + swz<CHP>(l31, 2 * ks + lh)) * 16;
+    const int g16 = lane >> 4, p16 = lane & 15;
+    int voff[DB][2];
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+        const int u = 4 * d + 2 * (g16 & 1) + ((p16 & 3) >> 1);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int r = 4 * lh + (p16 >> 2) + 8 * hf;
+            voff[d][hf] = (r * CHP + swz<CHP>(r, u)) * 16 + (p16 & 1) * 8;
+        }
+    }
+
+    for (int j = 0; j < n_tiles; ++j) {
+        if (j + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
+        else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (j + 2 < n_tiles) dma_linear4<S::STAGE>(ring + ((j + 2) % NSTAGE) * S::STAGE, kvimg + (long)(j + 2) * S::STAGE, wave, lane);
+        const char* kf = ring + (j % NSTAGE) * S::STAGE;
+        const char* vf = kf + S::IMG;
+
+        f32x16_t s0, s1, e0, e1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; e0[i] = 0.f; e1[i] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(kf + koff[ks]);
+            const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(kf + koff[ks] + 32 * CHP * 16);
+            const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(vf + koff[ks]);
+            const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(vf + koff[ks] + 32 * CHP * 16);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[ks], s0, 0, 0, 0);     // S^T  = K' Q''^T
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[ks], s1, 0, 0, 0);
+            e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, dof[ks], e0, 0, 0, 0);    // dP^T = V' dO~^T
+            e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, dof[ks], e1, 0, 0, 0);
+        }
+        // P = exp2(S - lse2);  dS = P (dP - D);  keys past Tk contribute nothing
+        const bool tail = (j == n_tiles - 1) && (p.Tk & (BN - 1));
+        const int kbase = j * BN + 4 * lh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float p0 = __builtin_amdgcn_exp2f(s0[r] - lse2), p1 = __builtin_amdgcn_exp2f(s1[r] - lse2);
+            if (tail) {
+                const int key = kbase + (r & 3) + 8 * (r >> 2);
+                if (key >= p.Tk) p0 = 0.f;
+                if (key + 32 >= p.Tk) p1 = 0.f;
+            }
+            s0[r] = p0 * (e0[r] - Drow);
+            s1[r] = p1 * (e1[r] - Drow);
+        }
+        bf16x8_t dsf[2][2];
+        dsf[0][0] = __builtin_bit_cast(bf16x8_t, pack_acc8(s0, 0)); dsf[0][1] = __builtin_bit_cast(bf16x8_t, pack_acc8(s0, 1));
+        dsf[1][0] = __builtin_bit_cast(bf16x8_t, pack_acc8(s1, 0)); dsf[1][1] = __builtin_bit_cast(bf16x8_t, pack_acc8(s1, 1));
+
+        // dQ'^T += K'^T dS^T   (A = K'^T by transpose-read of the K' image)
+        const uint32_t kbase_l = lds_addr(kf);
+        constexpr int SL = 16 * CHP * 16;
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+            const uint32_t a0 = kbase_l + voff[d][0], a1 = kbase_l + voff[d][1];
+            u32x2_t lo[4], hi[4];
+            lo[0] = lds_tr16_b64<0>(a0);      hi[0] = lds_tr16_b64<0>(a1);
+            lo[1] = lds_tr16_b64<SL>(a0);     hi[1] = lds_tr16_b64<SL>(a1);
+            lo[2] = lds_tr16_b64<2 * SL>(a0); hi[2] = lds_tr16_b64<2 * SL>(a1);
+            lo[3] = lds_tr16_b64<3 * SL>(a0); hi[3] = lds_tr16_b64<3 * SL>(a1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                const u32x4_t av = {lo[sl].x, lo[sl].y, hi[sl].x, hi[sl].y};
+                dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av), dsf[sl >> 1][sl & 1], dq[d], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: dq = A_q^T (c1 dQ') ; d trans_coeff through A_q ----
+    const float c1 = p.scale / (p.tau ? *p.tau : 1.0f);
+    __syncthreads();
+    float* ost = reinterpret_cast<float*>(smem + S::OFF_RING);
+    {
+        const int r = wave * 32 + l31;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4_t v = {dq[d][4 * g] * c1, dq[d][4 * g + 1] * c1, dq[d][4 * g + 2] * c1, dq[d][4 * g + 3] * c1};
+                *reinterpret_cast<f32x4_t*>(ost + r * S::OROW + 32 * d + 8 * g + 4 * lh) = v;
+            }
+    }
+    __syncthreads();
+    const char* qg = (const char*)p.q + ((long)b * p.q_sb + (long)h * p.q_sh) * ESZ;
+    char* dqg = (char*)p.dq + ((long)b * p.dq_sb + (long)h * p.dq_sh) * ESZ;
+    float dcpart = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int item = wave + 4 * it;
+        const int c = item >> 1;
+        const int r = lane + 64 * (item & 1);
+        const int t = q0 + r;
+        if (c < ch_real && t < p.Tq) {
+            const uint32_t desc = p.ctab[c];
+            float x[1][8];
+            const f32x4_t a = *reinterpret_cast<const f32x4_t*>(ost + r * S::OROW + 8 * c);
+            const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(ost + r * S::OROW + 8 * c + 4);
+            x[0][0] = a.x; x[0][1] = a.y; x[0][2] = a.z; x[0][3] = a.w;
+            x[0][4] = bb.x; x[0][5] = bb.y; x[0][6] = bb.z; x[0][7] = bb.w;
+            if (desc) {
+                const int n = view_of(t, p.Pq, p.invPq) - n_first;
+                const float* rc = rec + n * BREC;
+                if (!(desc & GTA_CHUNK_SO3) && (cd_lo(desc) == GTA_HALF_SE3 || cd_hi(desc) == GTA_HALF_SE3)) {
+                    float q8[8];
+                    g_load_chunk<ESZ>(qg + (long)t * p.q_st * ESZ, c, q8);
+                    const float t0 = rc[BREC_T], t1 = rc[BREC_T + 1], t2 = rc[BREC_T + 2];
+                    if (cd_lo(desc) == GTA_HALF_SE3) dcpart += x[0][3] * (t0 * q8[0] + t1 * q8[1] + t2 * q8[2]);
+                    if (cd_hi(desc) == GTA_HALF_SE3) dcpart += x[0][7] * (t0 * q8[4] + t1 * q8[5] + t2 * q8[6]);
+                }
+                f32x2_t cs[4];
+                if (p.cs_q) load_cs(desc, p.cs_q + ((long)b * p.Tq + t) * 2 * p.nso2, cs);
+                // A_q^T = E.m (record slot MT), D^T, R^T
+                chunk_apply<true, 1>(desc, rc + BREC_MT, rc + BREC_D1T, rc + BREC_D2T, cs, x);
+            }
+            g_store_chunk<ESZ>(dqg + (long)t * p.dq_st * ESZ, c, x[0]);
+        }
+    }
+    const float dc_wg = wg_sum256(dcpart, reinterpret_cast<float*>(smem + S::OFF_SCR), tid);
+    if (tid == 0) p.dc_partial[p.dc_off_dq + w] = dc_wg;
+}
+
+// ================================================================================================
+// 3. dK, dV
+// ================================================================================================
+template <int DHP>
+struct DkvSmem {
+    static constexpr int CHP = DHP / 8;
+    static constexpr int IMG = BN * DHP * 2;
+    static constexpr int STAGE = 2 * IMG;                  // Q'' image + dO~ image of one 64-row tile
+    static constexpr int RING = NSTAGE * STAGE;
+    static constexpr int OFF_KV = 0;                       // this workgroup's two K'/V' tiles (resident)
+    static constexpr int OFF_RING = 2 * STAGE;
+    static constexpr int OFF_STATS = OFF_RING + RING;      // [2][128] floats
+    static constexpr int OFF_SCR = OFF_STATS + 2 * 128 * 4;
+    static constexpr int OFF_REC = OFF_SCR + 32;
+    static constexpr int OROW = DHP + 4;
+    static constexpr int OST = 128 * OROW * 4;             // staging of dK' (then dV'): 128 keys
+    static_assert(OST <= RING, "staging must fit the ring");
+    static int total(int nviews) { return OFF_REC + nviews * BREC * 4; }
+};
+
+template <int DHP, int ESZ>
+__global__ __launch_bounds__(256, 1) void gta_bwd_dkv_kernel(const GtaBwdParams p) {
+    using S = DkvSmem<DHP>;
+    constexpr int CHP = S::CHP, KS = DHP / 16, DB = DHP / 32, BK = 128;
+    constexpr int DMA_PER_WAVE = S::STAGE / 1024 / 4;
+    constexpr int ITEMS = 2 * CHP / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    int w;
+    {
+        const int nwg = gridDim.x, L = blockIdx.x;
+        const int xcd = L & 7, idx = L >> 3, q8 = nwg >> 3, r8 = nwg & 7;
+        w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int n_k128 = (p.Tk + BK - 1) / BK;
+    const int bh = w / n_k128, kt = w - bh * n_k128;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int k0 = kt * BK;
+    const int n_kt64 = (p.Tk + BN - 1) / BN;
+    const int n_qt = (p.Tq + BN - 1) / BN;
+    const int ch_real = p.dh >> 3;
+    char* ring = smem + S::OFF_RING;
+    float* stats = reinterpret_cast<float*>(smem + S::OFF_STATS);
+    float* rec = reinterpret_cast<float*>(smem + S::OFF_REC);
+
+    const long ktile0 = ((long)b * p.H + h) * n_kt64 + 2 * kt;
+    const int n_my_kt = (2 * kt + 1 < n_kt64) ? 2 : 1;
+    const char* qimg = (const char*)p.qimg + ((long)b * p.H + h) * n_qt * (long)S::STAGE;
+    const float* gstats = p.stats + ((long)b * p.H + h) * n_qt * 128;
+    dma_linear4<S::STAGE>(smem + S::OFF_KV, (const char*)p.kvimg + ktile0 * S::STAGE, wave, lane);
+    if (n_my_kt == 2) dma_linear4<S::STAGE>(smem + S::OFF_KV + S::STAGE, (const char*)p.kvimg + (ktile0 + 1) * S::STAGE, wave, lane);
+    dma_linear4<S::STAGE>(ring, qimg, wave, lane);
+
+    const int t_last = (k0 + BK - 1 < p.Tk ? k0 + BK - 1 : p.Tk - 1);
+    const int n_first = k0 / p.Pk;
+    const int n_cnt = t_last / p.Pk - n_first + 1;
+    const float tc = p.trans_coeff ? *p.trans_coeff : 1.0f;
+    if (p.vrep_k) stage_brec(rec, p.vrep_k, (long)b * p.Nk + n_first, n_cnt, 1, tc, tid, 256);
+    if (tid < 128) stats[tid] = gstats[tid];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // this wave's 32 keys: K' and V' fragments (MFMA B operands) stay in VGPRs
+    const int my_key = wave * 32 + l31;                 // 0..127
+    const int my_kt = my_key >> 6;
+    bf16x8_t kfr[KS], vfr[KS];
+    {
+        const char* ki = smem + S::OFF_KV + my_kt * S::STAGE;
+        const int r = my_key & 63;
+        if (my_kt < n_my_kt) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int off = (r * CHP + swz<CHP>(r, 2 * ks + lh)) * 16;
+                kfr[ks] = *reinterpret_cast<const bf16x8_t*>(ki + off);
+                vfr[ks] = *reinterpret_cast<const bf16x8_t*>(ki + S::IMG + off);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const u32x4_t z = {0, 0, 0, 0};
+                kfr[ks] = __builtin_bit_cast(bf16x8_t, z);
+                vfr[ks] = __builtin_bit_cast(bf16x8_t, z);
+            }
+        }
+    }
+    if (n_qt > 1) dma_linear4<S::STAGE>(ring + S::STAGE, qimg + (long)S::STAGE, wave, lane);
+
+    f32x16_t dk[DB], dv[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dk[d][i] = 0.f; dv[d][i] = 0.f; }
+
+    int koff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) koff[ks] = (l31 * CHP + swz<CHP>(l31, 2 * ks + lh)) * 16;
+    const int g16 = lane >> 4, p16 = lane & 15;
+    int voff[DB][2];
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+        const int u = 4 * d + 2 * (g16 & 1) + ((p16 & 3) >> 1);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int r = 4 * lh + (p16 >> 2) + 8 * hf;
+            voff[d][hf] = (r * CHP + swz<CHP>(r, u)) * 16 + (p16 & 1) * 8;
+        }
+    }
+
+    for (int j = 0; j < n_qt; ++j) {
+        // statistics of tile j+1: fetched now, written to LDS at the end of this iteration
+        // (every thread issues exactly one load so the counted vmcnt below is wave-uniform)
+        float st_next = 0.f;
+        if (j + 1 < n_qt) st_next = gstats[(long)(j + 1) * 128 + (tid & 127)];
+        if (j + 1 < n_qt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE + 1) : "memory");
+        else              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (j + 2 < n_qt) dma_linear4<S::STAGE>(ring + ((j + 2) % NSTAGE) * S::STAGE, qimg + (long)(j + 2) * S::STAGE, wave, lane);
+        const char* qi = ring + (j % NSTAGE) * S::STAGE;       // Q'' image
+        const char* di = qi + S::IMG;                           // dO~ image
+        const float* stj = stats + (j & 1) * 128;
+        constexpr int SL = 16 * CHP * 16;
+
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {                        // 32 query rows at a time
+            f32x16_t s, e;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[i] = 0.f; e[i] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(qi + koff[ks] + qb * 32 * CHP * 16);
+                const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(di + koff[ks] + qb * 32 * CHP * 16);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, kfr[ks], s, 0, 0, 0);    // S  = Q'' K'^T
+                e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, vfr[ks], e, 0, 0, 0);    // dP = dO~ V'^T
+            }
+            // register r <-> query row 32qb + 8(r>>2) + 4lh + (r&3): statistics come as float4 groups
+            f32x16_t ds;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(stj + 32 * qb + 8 * g + 4 * lh);
+                const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(stj + 64 + 32 * qb + 8 * g + 4 * lh);
+                const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float pv = __builtin_amdgcn_exp2f(s[4 * g + i] - ll[i]);
+                    s[4 * g + i] = pv;
+                    ds[4 * g + i] = pv * (e[4 * g + i] - dd[i]);
+                }
+            }
+            bf16x8_t pf[2], dsf[2];
+            pf[0] = __builtin_bit_cast(bf16x8_t, pack_acc8(s, 0));   pf[1] = __builtin_bit_cast(bf16x8_t, pack_acc8(s, 1));
+            dsf[0] = __builtin_bit_cast(bf16x8_t, pack_acc8(ds, 0)); dsf[1] = __builtin_bit_cast(bf16x8_t, pack_acc8(ds, 1));
+            // dV'^T += dO~^T P ; dK'^T += Q''^T dS   (A operands by transpose-read of the row-major images)
+            const uint32_t qb_l = lds_addr(qi) + qb * 32 * CHP * 16, db_l = lds_addr(di) + qb * 32 * CHP * 16;
+#pragma unroll
+            for (int d = 0; d < DB; ++d) {
+                u32x2_t qlo[2], qhi[2], dlo[2], dhi[2];
+                qlo[0] = lds_tr16_b64<0>(qb_l + voff[d][0]);  qhi[0] = lds_tr16_b64<0>(qb_l + voff[d][1]);
+                qlo[1] = lds_tr16_b64<SL>(qb_l + voff[d][0]); qhi[1] = lds_tr16_b64<SL>(qb_l + voff[d][1]);
+                dlo[0] = lds_tr16_b64<0>(db_l + voff[d][0]);  dhi[0] = lds_tr16_b64<0>(db_l + voff[d][1]);
+                dlo[1] = lds_tr16_b64<SL>(db_l + voff[d][0]); dhi[1] = lds_tr16_b64<SL>(db_l + voff[d][1]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const u32x4_t aq = {qlo[t].x, qlo[t].y, qhi[t].x, qhi[t].y};
+                    const u32x4_t ad = {dlo[t].x, dlo[t].y, dhi[t].x, dhi[t].y};
+                    dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ad), pf[t], dv[d], 0, 0, 0);
+                    dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, aq), dsf[t], dk[d], 0, 0, 0);
+                }
+            }
+        }
+        if (j + 1 < n_qt && tid < 128) stats[((j + 1) & 1) * 128 + tid] = st_next;
+    }
+
+    // ---- epilogue: dk = B_k^T (ln2 dK'), dv = B_k^T dV' ; d trans_coeff through B_k ----
+    const bool xv = (p.flags & GTA_FLAG_V_TRANSFORM) != 0;
+    const char* kg = (const char*)p.k + ((long)b * p.k_sb + (long)h * p.k_sh) * ESZ;
+    const char* vg = (const char*)p.v + ((long)b * p.v_sb + (long)h * p.v_sh) * ESZ;
+    char* dkg = (char*)p.dk + ((long)b * p.dk_sb + (long)h * p.dk_sh) * ESZ;
+    char* dvg = (char*)p.dv + ((long)b * p.dv_sb + (long)h * p.dv_sh) * ESZ;
+    float* ost = reinterpret_cast<float*>(smem + S::OFF_RING);
+    float dcpart = 0.f;
+#pragma unroll 1
+    for (int which = 0; which < 2; ++which) {            // 0: dK, 1: dV
+        __syncthreads();
+        {
+            const int r = wave * 32 + l31;
+            const float sc = which == 0 ? LN2 : 1.0f;
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x16_t& acc = which == 0 ? dk[d] : dv[d];
+                    const f32x4_t v = {acc[4 * g] * sc, acc[4 * g + 1] * sc, acc[4 * g + 2] * sc, acc[4 * g + 3] * sc};
+                    *reinterpret_cast<f32x4_t*>(ost + r * S::OROW + 32 * d + 8 * g + 4 * lh) = v;
+                }
+        }
+        __syncthreads();
+        const bool xf = which == 0 || xv;
+        const char* rawg = which == 0 ? kg : vg;
+        const long raw_st = (which == 0 ? p.k_st : p.v_st) * ESZ;
+        char* outg = which == 0 ? dkg : dvg;
+        const long out_st = (which == 0 ? p.dk_st : p.dv_st) * ESZ;
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int item = wave + 4 * it;
+            const int c = item >> 1;
+            const int r = lane + 64 * (item & 1);
+            const int t = k0 + r;
+            if (c < ch_real && t < p.Tk) {
+                const uint32_t desc = p.ctab[c];
+                float x[1][8];
+                const f32x4_t a = *reinterpret_cast<const f32x4_t*>(ost + r * S::OROW + 8 * c);
+                const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(ost + r * S::OROW + 8 * c + 4);
+                x[0][0] = a.x; x[0][1] = a.y; x[0][2] = a.z; x[0][3] = a.w;
+                x[0][4] = bb.x; x[0][5] = bb.y; x[0][6] = bb.z; x[0][7] = bb.w;
+                if (desc && xf) {
+                    const int n = view_of(t, p.Pk, p.invPk) - n_first;
+                    const float* rc = rec + n * BREC;
+                    if (!(desc & GTA_CHUNK_SO3) && (cd_lo(desc) == GTA_HALF_SE3 || cd_hi(desc) == GTA_HALF_SE3)) {
+                        float r8[8];
+                        g_load_chunk<ESZ>(rawg + (long)t * raw_st, c, r8);
+                        const float t0 = rc[BREC_T], t1 = rc[BREC_T + 1], t2 = rc[BREC_T + 2];
+                        if (cd_lo(desc) == GTA_HALF_SE3) dcpart += (x[0][0] * t0 + x[0][1] * t1 + x[0][2] * t2) * r8[3];
+                        if (cd_hi(desc) == GTA_HALF_SE3) dcpart += (x[0][4] * t0 + x[0][5] * t1 + x[0][6] * t2) * r8[7];
+                    }
+                    f32x2_t cs[4];
+                    if (p.cs_k) load_cs(desc, p.cs_k + ((long)b * p.Tk + t) * 2 * p.nso2, cs);
+                    chunk_apply<true, 1>(desc, rc + BREC_MT, rc + BREC_D1T, rc + BREC_D2T, cs, x);
+                }
+                g_store_chunk<ESZ>(outg + (long)t * out_st, c, x[0]);
+            }
+        }
+    }
+    const float dc_wg = wg_sum256(dcpart, reinterpret_cast<float*>(smem + S::OFF_SCR), tid);
+    if (tid == 0) p.dc_partial[p.dc_off_dkv + w] = dc_wg;
+}
+
+__global__ void gta_reduce_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+    __shared__ float sm[256];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += part[i];     // fixed order per thread: deterministic
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = sm[0];
+}
+
+template <typename K>
+int set_lds(K kern, int bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess
+               ? GTA_OK : GTA_E_LAUNCH;
+}
+
+template <int DHP, int ESZ>
+int run_bwd(const GtaBwdParams& p, hipStream_t stream) {
+    const int n_qt = (p.Tq + BN - 1) / BN;
+    static bool attr = false;
+    if (!attr) {
+        constexpr int lds_prep0 = BPrepSmem<DHP, ESZ>::TOTAL;
+        if (set_lds(&gta_bwd_prep_kernel<DHP, ESZ>, lds_prep0)) return GTA_E_LAUNCH;
+        if (set_lds(&gta_bwd_dq_kernel<DHP, ESZ>, DqSmem<DHP>::total(GTA_MAX_VIEWS))) return GTA_E_LAUNCH;
+        if (set_lds(&gta_bwd_dkv_kernel<DHP, ESZ>, DkvSmem<DHP>::total(GTA_MAX_VIEWS))) return GTA_E_LAUNCH;
+        attr = true;
+    }
+    constexpr int lds_prep = BPrepSmem<DHP, ESZ>::TOTAL;
+    hipLaunchKernelGGL((gta_bwd_prep_kernel<DHP, ESZ>), dim3(n_qt, p.H, p.B), dim3(256), lds_prep, stream, p);
+    const int n_dq = p.B * p.H * ((p.Tq + 127) / 128);
+    hipLaunchKernelGGL((gta_bwd_dq_kernel<DHP, ESZ>), dim3(n_dq), dim3(256), DqSmem<DHP>::total(p.vrep_q ? p.Nq : 0), stream, p);
+    const int n_dkv = p.B * p.H * ((p.Tk + 127) / 128);
+    hipLaunchKernelGGL((gta_bwd_dkv_kernel<DHP, ESZ>), dim3(n_dkv), dim3(256), DkvSmem<DHP>::total(p.vrep_k ? p.Nk : 0), stream, p);
+    if (p.dtrans_coeff)
+        hipLaunchKernelGGL(gta_reduce_kernel, dim3(1), dim3(256), 0, stream, p.dc_partial, p.dc_total, p.dtrans_coeff);
+    return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH;
+}
+
+}  // namespace
+
+int gta_bwd_dispatch(const GtaBwdParams& p, int dhp, int esz, hipStream_t stream) {
+#define GTA_CASEB(D) case D: return esz == 2 ? run_bwd<D, 2>(p, stream) : run_bwd<D, 4>(p, stream);
+    switch (dhp) {
+        GTA_CASEB(32)
+        GTA_CASEB(64)
+        GTA_CASEB(96)
+        GTA_CASEB(128)
+    }
+#undef GTA_CASEB
+    return GTA_E_UNSUPPORTED;
+}

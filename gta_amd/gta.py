@@ -155,6 +155,7 @@ class _GtaAttn(torch.autograd.Function):
             if _GtaAttn.flash_events is not None:
                 _GtaAttn.flash_events[1].record()
         ctx.cfg = cfg
+        ctx.kv_images = ws          # K'/V' tile images of the two-stage plan: reused by the backward
         ctx.save_for_backward(q, k, v, out, lse, tc, ta, vrep_q, vrep_k, cs_q, cs_k)
         ctx.tc_shape = None if trans_coeff is None else trans_coeff.shape
         ctx.tc_dtype = None if trans_coeff is None else trans_coeff.dtype
@@ -166,7 +167,8 @@ class _GtaAttn(torch.autograd.Function):
         q, k, v, out, lse, tc, ta, vrep_q, vrep_k, cs_q, cs_k = ctx.saved_tensors
         if ta is not None and ctx.needs_input_grad[4]:
             raise native.GtaError("gradient w.r.t. the adjustable softmax temperature is not implemented")
-        dq, dk, dv, dtc = _bw.attn_bwd(ctx.cfg, q, k, v, out, dout, lse, tc, ta, vrep_q, vrep_k, cs_q, cs_k)
+        dq, dk, dv, dtc = _bw.attn_bwd(ctx.cfg, q, k, v, out, dout, lse, tc, ta, vrep_q, vrep_k, cs_q, cs_k,
+                                       kv_images=ctx.kv_images)
         if ctx.tc_shape is not None and dtc is not None:
             dtc = dtc.reshape(ctx.tc_shape).to(ctx.tc_dtype)
         else:

@@ -32,7 +32,8 @@ MAX_VIEWS = 16
 # every symbol include/gta_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (
     "gta_build_view_reps", "gta_build_so2_table", "gta_attn_fwd", "gta_attn_fwd_supported",
-    "gta_attn_fwd_launch_info", "gta_attn_fwd_workspace_bytes", "gta_strerror", "gta_abi_version", "gta_sizeof_attn_desc",
+    "gta_attn_fwd_launch_info", "gta_attn_fwd_workspace_bytes", "gta_attn_bwd", "gta_attn_bwd_workspace_bytes",
+    "gta_strerror", "gta_abi_version", "gta_sizeof_attn_desc",
 )
 
 
@@ -79,10 +80,10 @@ def lib():
         L.gta_attn_fwd_workspace_bytes.restype = c_int64
         L.gta_attn_fwd_supported.argtypes = [ctypes.POINTER(GtaAttnDesc)]
         L.gta_attn_fwd_launch_info.argtypes = [ctypes.POINTER(GtaAttnDesc)] + [ctypes.POINTER(c_int32)] * 3
-        if hasattr(L, "gta_attn_bwd"):
-            L.gta_attn_bwd.argtypes = [ctypes.POINTER(GtaAttnDesc)] + [c_void_p] * 19
-            L.gta_attn_bwd_workspace_bytes.argtypes = [ctypes.POINTER(GtaAttnDesc)]
-            L.gta_attn_bwd_workspace_bytes.restype = c_int64
+        L.gta_attn_bwd.argtypes = ([ctypes.POINTER(GtaAttnDesc)] + [c_void_p] * 16
+                                   + [ctypes.POINTER(c_int64), ctypes.POINTER(c_int64), c_void_p, c_void_p, c_int64, c_void_p])
+        L.gta_attn_bwd_workspace_bytes.argtypes = [ctypes.POINTER(GtaAttnDesc)]
+        L.gta_attn_bwd_workspace_bytes.restype = c_int64
         _lib = L
     return _lib
 
@@ -174,3 +175,19 @@ def launch_info(desc: GtaAttnDesc):
     check(lib().gta_attn_fwd_launch_info(ctypes.byref(desc), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)),
           "gta_attn_fwd_launch_info")
     return {"lds_bytes": a.value, "workgroups": b.value, "threads": c.value}
+
+
+def attn_bwd_workspace_bytes(desc: GtaAttnDesc) -> int:
+    return int(lib().gta_attn_bwd_workspace_bytes(ctypes.byref(desc)))
+
+
+def attn_bwd(desc: GtaAttnDesc, q, k, v, out, dout, lse, vrep_q, vrep_k, cs_q, cs_k, trans_coeff, tau, kv_images,
+             dq, dk, dv, dtrans_coeff, workspace):
+    """All tensors [B,H,T,dh] views (unit channel stride); dq/dk/dv/dout strides are passed explicitly."""
+    _require_cuda(q, k, v, out, dout, dq, dk, dv, workspace)
+    gs = (c_int64 * 9)(*(list(dq.stride()[:3]) + list(dk.stride()[:3]) + list(dv.stride()[:3])))
+    ds = (c_int64 * 3)(*dout.stride()[:3])
+    check(lib().gta_attn_bwd(ctypes.byref(desc), _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(dout), _ptr(lse),
+                             _ptr(vrep_q), _ptr(vrep_k), _ptr(cs_q), _ptr(cs_k), _ptr(trans_coeff), _ptr(tau),
+                             _ptr(kv_images), _ptr(dq), _ptr(dk), _ptr(dv), gs, ds, _ptr(dtrans_coeff),
+                             _ptr(workspace), workspace.numel(), _stream()), "gta_attn_bwd")

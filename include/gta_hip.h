@@ -127,6 +127,27 @@ int gta_attn_fwd(const GtaAttnDesc* desc,
  *       keys (GTA_FLAG_KV_READY) and is what the backward consumes. */
 int64_t gta_attn_fwd_workspace_bytes(const GtaAttnDesc* desc);
 
+/* -------------------------------------------------------------------------------------------
+ * Backward  (replaces PyTorch autograd over gta.py:92-279 + layers.py:202-211)
+ *   inputs : q, k, v (as given to the forward; strides from desc), out and lse from the forward,
+ *            dout [B,H,Tq,dh] with element strides dout_stride[3] (b,h,t), reps as in the forward.
+ *   kv_images: the forward's workspace (K'/V' tile images) or NULL -> recomputed here.
+ *   outputs: dq, dk, dv with element strides dqkv_stride[9] = dq(b,h,t), dk(b,h,t), dv(b,h,t);
+ *            dtrans_coeff [1] fp32 (d loss / d trans_coeff, layers.py:191) or NULL.
+ *   No gradient is produced for the reps/poses (gta.py:194-198 detaches them; poses are data) nor
+ *   for tau (GTA_E_UNSUPPORTED when desc asks for it is the caller's concern).
+ * ------------------------------------------------------------------------------------------- */
+int64_t gta_attn_bwd_workspace_bytes(const GtaAttnDesc* desc);
+int gta_attn_bwd(const GtaAttnDesc* desc,
+                 const void* q, const void* k, const void* v, const void* out, const void* dout,
+                 const float* lse,
+                 const float* vrep_q, const float* vrep_k, const float* cs_q, const float* cs_k,
+                 const float* trans_coeff, const float* tau,
+                 const void* kv_images,
+                 void* dq, void* dk, void* dv, const int64_t* dqkv_stride, const int64_t* dout_stride,
+                 float* dtrans_coeff,
+                 void* workspace, int64_t workspace_bytes, void* stream);
+
 /* 0 when gta_attn_fwd has a fused kernel for this desc, else the error it would return. */
 int gta_attn_fwd_supported(const GtaAttnDesc* desc);
 

@@ -1,0 +1,94 @@
+"""GPU parity tests of the backward kernels: dq, dk, dv and d trans_coeff vs the reference fixtures
+(autograd of the reference's own code) and vs autograd through the CPU oracle at the BASELINE shapes.
+Tolerances are relative to each gradient's own magnitude (bf16 MFMA products, fp32 accumulation)."""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+import gta_amd
+from tests import _golden as G
+from tests import _hip_cases as C
+
+pytestmark = pytest.mark.gpu
+
+REL_MAX = 4e-2
+REL_RMS = 2e-2
+FUSED_CASES = [c for c in G.list_cases("op_") if C.FUSED_OK(G.load("op_" + c)[1])]
+
+
+def _check(got, ref, name, rel_max=REL_MAX, rel_rms=REL_RMS):
+    st = C.err_stats(got, ref)
+    assert st["finite"], (name, st)
+    assert st["max_abs"] <= rel_max * st["ref_max"] + 1e-6, (name, st)
+    assert st["rel_rms"] <= rel_rms, (name, st)
+
+
+@pytest.mark.parametrize("kv_mode", ["prepass", "fused"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", FUSED_CASES)
+def test_golden_gradients(case, dtype, kv_mode):
+    d, meta = G.load("op_" + case)
+    ex = G.extras_of(d, torch.float32, "cuda")
+    q, k, v = (torch.from_numpy(d[n]).to(dtype).cuda().requires_grad_() for n in "qkv")
+    tc = torch.tensor([float(d["trans_coeff"])], device="cuda", requires_grad=True)
+    out, _ = gta_amd.multihead_geometric_transform_attention(
+        q, k, v, attn_fn=SimpleNamespace(scale=float(d["scale"])), f_dims=meta["f_dims"], reps=ex, trans_coeff=tc,
+        v_transform=meta["v_transform"], kv_mode=kv_mode)
+    (out.float() * torch.from_numpy(d["w"]).float().cuda()).sum().backward()
+    torch.cuda.synchronize()
+    for name, t in (("dq", q), ("dk", k), ("dv", v)):
+        _check(t.grad.float().cpu(), torch.from_numpy(d[name]).float(), name)
+    if meta["f_dims"].get("se3", 0) > 0:
+        ref = float(d["dtrans_coeff"][0])
+        got = float(tc.grad.item())
+        scale = max(1.0, abs(ref), float(torch.from_numpy(d["dq"]).abs().sum()) * 1e-2)
+        assert abs(got - ref) <= 5e-2 * scale, (got, ref)
+
+
+SHAPES = {
+    "C1": (2, 4, 2, 64, 2, 64, {"se3": 32, "so2": 32}, 8, 0),
+    "CL-enc": (1, 6, 2, 300, 2, 300, {"se3": 32, "so2": 32}, 8, 0),
+    "CL-dec": (1, 6, 3, 853, 2, 300, {"se3": 32, "so2": 32}, 8, 0),
+    "MS-enc": (1, 8, 5, 256, 5, 256, {"triv": 0, "se3": 48, "so3": 24, "so2": 24}, 6, 2),
+    "MS-dec": (1, 8, 5, 512, 5, 256, {"triv": 0, "se3": 48, "so3": 24, "so2": 24}, 6, 2),
+    "ragged": (1, 3, 3, 37, 2, 45, {"triv": 8, "se3": 16, "so2": 8}, 2, 0),
+}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", sorted(SHAPES))
+def test_gradients_vs_oracle_autograd(shape, dtype):
+    from oracle import gta_oracle as O
+    B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3 = SHAPES[shape]
+    q, k, v, ex, ak, cross = C.synth_inputs(B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, dtype, seed=7)
+    if dtype == torch.bfloat16:
+        q, k, v = q.bfloat16().float(), k.bfloat16().float(), v.bfloat16().float()
+    g = torch.Generator().manual_seed(11)
+    w = torch.randn(q.shape, generator=g)
+    # oracle
+    qo, ko, vo = (t.clone().requires_grad_() for t in (q, k, v))
+    tco = torch.tensor([0.37], requires_grad=True)
+    reps = O.encoder_reps(ak, ex)
+    if cross:
+        reps = O.decoder_reps(ak, ex, reps)
+    out_o, _ = O.gta_attention(qo, ko, vo, f_dims, reps, tco)
+    (out_o * w).sum().backward()
+    # HIP
+    exd = {kk: vv.cuda() for kk, vv in ex.items()}
+    gta_amd.pre_compute_reps_encoder(ak, exd)
+    if cross:
+        gta_amd.pre_compute_reps_decoder(ak, exd)
+    packed = gta_amd.pack_reps(exd, f_dims)
+    qd, kd, vd = (t.to(dtype).cuda().requires_grad_() for t in (q, k, v))
+    tcd = torch.tensor([0.37], device="cuda", requires_grad=True)
+    out = gta_amd.gta_attention(qd, kd, vd, f_dims, packed, so3_degree=exd.get("gta_so3_degree", 0),
+                                trans_coeff=tcd if f_dims.get("se3", 0) > 0 else None)
+    (out.float() * w.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    _check(out.float().cpu(), out_o.detach(), "out", 2.5e-2, 1.2e-2)
+    for name, a, b in (("dq", qd, qo), ("dk", kd, ko), ("dv", vd, vo)):
+        _check(a.grad.float().cpu(), b.grad, name)
+    if f_dims.get("se3", 0) > 0:
+        ref, got = float(tco.grad.item()), float(tcd.grad.item())
+        assert abs(got - ref) <= 3e-2 * max(1.0, abs(ref)), (got, ref)
