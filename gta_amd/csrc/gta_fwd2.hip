@@ -17,6 +17,12 @@
 //                        O^T = V'^T P^T on v_mfma_f32_32x32x16_bf16; V'^T operands come from the
 //                        row-major V' image with ds_read_b64_tr_b16; online softmax in registers.
 //                        Epilogue: O/l -> LDS -> rho_q^-1 per chunk (gta.py:246-276) -> out, LSE.
+// Measured dead ends (r01, profiles/r01/README.md): an explicit ping-pong of the 8-wave kernel (M segment
+// = PV(j-1)+QK(j), V segment = softmax, wave groups one segment apart, 4..6-stage ring, all operands
+// prefetched) ran the MFMA-only stretches at full rate (355 cycles / 12 MFMAs) but gained nothing
+// end to end (280 us vs 243 us for two 4-wave workgroups per CU): LDS-read issue, LDS-DMA issue
+// (~100+ cycles per 1-KiB piece for the issuing wave) and two barriers per tile ate the overlap.
+#include <type_traits>
 #include "gta_common.h"
 #include "gta_fwd_params.h"
 #include "../../include/gta_hip.h"
@@ -303,9 +309,11 @@ GTA_DEV void dma_stage(char* ring, int st, const char* img, int wave, int lane) 
     }
 }
 
-template <int DHP, int ESZ, int NW>
+template <int DHP, int ESZ, int NW, int LAYOUT>
 __global__ __launch_bounds__(64 * NW, 2) void gta_fwd2_kernel(const GtaFwdParams p) {
     using S = Smem2<DHP, NW>;
+    // chunk descriptor: a compile-time constant for the shipped layouts (c is constant per unrolled item)
+#define GTA_DESC(c) (LAYOUT == GTA_LAYOUT_GENERIC ? p.ctab[c] : gta_layout_desc(LAYOUT, c))
     constexpr int CHP = S::CHP, KS = DHP / 16, DB = DHP / 32, BM = S::BM, NT = S::NT;
     constexpr int DMA_PER_WAVE = S::STAGE / 1024 / NW;
     constexpr int QITEMS = (BM / 64) * CHP / NW;         // (row group, chunk) items per wave = CHP/2
@@ -348,21 +356,32 @@ __global__ __launch_bounds__(64 * NW, 2) void gta_fwd2_kernel(const GtaFwdParams
     u32x4_t qraw[QITEMS][RAWN];
     f32x2_t qcs[QITEMS][4];
     int qt_row[QITEMS];
-#pragma unroll
-    for (int it = 0; it < QITEMS; ++it) {
-        const int item = wave + NW * it;                               // wave-uniform
-        const int c = item / (BM / 64);
-        const int r = lane + 64 * (item % (BM / 64));
-        int t = q0 + r;
+    // item map: wave -> (row group rg = wave % RG, chunk parity par = wave / RG); item it -> chunk 2*it+par.
+    // par takes two values: each gets its own straight-line code path in which c is a constant.
+    constexpr int RG = BM / 64;
+    static_assert(NW == 2 * RG && QITEMS * 2 == CHP, "item map assumes two chunk parities");
+    const int rg = wave % RG, par = wave / RG;
+    const int my_r = lane + 64 * rg;
+    {
+        int t = q0 + my_r;
         t = t < p.Tq ? t : p.Tq - 1;
-        qt_row[it] = t;
-        if (c < ch_real && !GTA_DBG(32u)) {
-            const char* rp = qg + (long)t * q_rs + c * 8 * ESZ;
 #pragma unroll
-            for (int k2 = 0; k2 < RAWN; ++k2) qraw[it][k2] = *reinterpret_cast<const u32x4_t*>(rp + 16 * k2);
-            if (p.cs_q) load_cs(p.ctab[c], p.cs_q + ((long)b * p.Tq + t) * 2 * p.nso2, qcs[it]);
-        }
+        for (int it = 0; it < QITEMS; ++it) qt_row[it] = t;
     }
+    auto load_items = [&](auto PARC) {
+        constexpr int PAR = decltype(PARC)::value;
+#pragma unroll
+        for (int it = 0; it < QITEMS; ++it) {
+            const int c = 2 * it + PAR;
+            if (c < ch_real && !GTA_DBG(32u)) {
+                const char* rp = qg + (long)qt_row[it] * q_rs + c * 8 * ESZ;
+#pragma unroll
+                for (int k2 = 0; k2 < RAWN; ++k2) qraw[it][k2] = *reinterpret_cast<const u32x4_t*>(rp + 16 * k2);
+                if (p.cs_q) load_cs(GTA_DESC(c), p.cs_q + ((long)b * p.Tq + qt_row[it]) * 2 * p.nso2, qcs[it]);
+            }
+        }
+    };
+    if (par) load_items(std::integral_constant<int, 1>{}); else load_items(std::integral_constant<int, 0>{});
     // views touched by this query tile: records are staged relative to n_first
     const int t_last = (q0 + BM - 1 < p.Tq ? q0 + BM - 1 : p.Tq - 1);
     const int n_first = q0 / p.Pq;
@@ -373,16 +392,16 @@ __global__ __launch_bounds__(64 * NW, 2) void gta_fwd2_kernel(const GtaFwdParams
     GTA_STAMP(1);
     // ---- Q: rho, prescale, bf16 -> LDS ----
     const float qscale = p.scale * LOG2E / (p.tau ? *p.tau : 1.0f);
-    {
+    auto xform_items = [&](auto PARC) {
+        constexpr int PAR = decltype(PARC)::value;
         char* qs = smem + S::OFF_QS;
+        const int r = my_r;
 #pragma unroll
         for (int it = 0; it < QITEMS; ++it) {
-            const int item = wave + NW * it;
-            const int c = item / (BM / 64);
-            const int r = lane + 64 * (item % (BM / 64));
+            const int c = 2 * it + PAR;
             float x[1][8];
             if (c < ch_real) {
-                const uint32_t desc = p.ctab[c];
+                const uint32_t desc = GTA_DESC(c);
                 if (ESZ == 2) {
                     unpack8(qraw[it][0], x[0]);
                 } else {
@@ -405,7 +424,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gta_fwd2_kernel(const GtaFwdParams
             }
             *reinterpret_cast<u32x4_t*>(qs + (r * CHP + swz<CHP>(r, c)) * 16) = pack8(x[0]);
         }
-    }
+    };
+    if (par) xform_items(std::integral_constant<int, 1>{}); else xform_items(std::integral_constant<int, 0>{});
     __syncthreads();      // (also drains tile 0's DMA: harmless)
     bf16x8_t qf[KS];
     {
@@ -615,26 +635,41 @@ __global__ __launch_bounds__(64 * NW, 2) void gta_fwd2_kernel(const GtaFwdParams
                 }
         }
         __syncthreads();
+        // rho_q^-1 on one (row, chunk) item and the store
+        auto out_item = [&](const uint32_t desc, const int c, const int r, const int t, const f32x2_t* cs) {
+            float x[1][8];
+            const f32x4_t a = *reinterpret_cast<const f32x4_t*>(ost + r * S::OROW + 8 * c);
+            const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(ost + r * S::OROW + 8 * c + 4);
+            x[0][0] = a.x; x[0][1] = a.y; x[0][2] = a.z; x[0][3] = a.w;
+            x[0][4] = bb.x; x[0][5] = bb.y; x[0][6] = bb.z; x[0][7] = bb.w;
+            if (xo && desc) {
+                const int n = view_of(t, p.Pq, p.invPq) - n_first;
+                const float* rec = qrec + n * GTA_QREC;
+                chunk_apply<true, 1>(desc, rec + GTA_QREC_O, rec + GTA_QREC_D1T, rec + GTA_QREC_D2T, cs, x);
+            }
+            if (!GTA_DBG(64u) || x[0][0] == 123.f) gstore_chunk2<ESZ>(og + (long)t * o_rs, c, x[0]);
+        };
+        if constexpr (SAMEMAP) {
+            // same item map as the prologue: c = 2*it + par is a constant in each code path, and the
+            // per-token (cos,sin) registers loaded there are reused
+            auto out_items = [&](auto PARC) {
+                constexpr int PAR = decltype(PARC)::value;
+                const int t = q0 + my_r;
 #pragma unroll
-        for (int it = 0; it < EITEMS; ++it) {
-            const int item = wave + NW * it;
-            const int c = item / (S::OST_ROWS / 64);
-            const int r = lane + 64 * (item % (S::OST_ROWS / 64));
-            const int t = q0 + pass * S::OST_ROWS + r;
-            if (c < ch_real && t < p.Tq) {
-                const uint32_t desc = p.ctab[c];
-                float x[1][8];
-                const f32x4_t a = *reinterpret_cast<const f32x4_t*>(ost + r * S::OROW + 8 * c);
-                const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(ost + r * S::OROW + 8 * c + 4);
-                x[0][0] = a.x; x[0][1] = a.y; x[0][2] = a.z; x[0][3] = a.w;
-                x[0][4] = bb.x; x[0][5] = bb.y; x[0][6] = bb.z; x[0][7] = bb.w;
-                if (xo && desc) {
-                    const int n = view_of(t, p.Pq, p.invPq) - n_first;
-                    const float* rec = qrec + n * GTA_QREC;
-                    chunk_apply<true, 1>(desc, rec + GTA_QREC_O, rec + GTA_QREC_D1T, rec + GTA_QREC_D2T,
-                                         SAMEMAP ? qcs[it] : ocs[it], x);
+                for (int it = 0; it < QITEMS; ++it) {
+                    const int c = 2 * it + PAR;
+                    if (c < ch_real && t < p.Tq) out_item(GTA_DESC(c), c, my_r, t, qcs[it]);
                 }
-                if (!GTA_DBG(64u) || x[0][0] == 123.f) gstore_chunk2<ESZ>(og + (long)t * o_rs, c, x[0]);
+            };
+            if (par) out_items(std::integral_constant<int, 1>{}); else out_items(std::integral_constant<int, 0>{});
+        } else {
+#pragma unroll
+            for (int it = 0; it < EITEMS; ++it) {
+                const int item = wave + NW * it;
+                const int c = item / (S::OST_ROWS / 64);
+                const int r = lane + 64 * (item % (S::OST_ROWS / 64));
+                const int t = q0 + pass * S::OST_ROWS + r;
+                if (c < ch_real && t < p.Tq) out_item(p.ctab[c], c, r, t, ocs[it]);
             }
         }
     }
@@ -655,18 +690,18 @@ int launch_prep(const GtaFwdParams& p, hipStream_t stream) {
     hipLaunchKernelGGL((gta_kv_prep_kernel<DHP, ESZ>), dim3(n_tiles, p.H, p.B), dim3(256), S::TOTAL, stream, p);
     return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH;
 }
-template <int DHP, int ESZ, int NW>
+template <int DHP, int ESZ, int NW, int LAYOUT>
 int launch_fwd2(const GtaFwdParams& p, hipStream_t stream) {
     using S = Smem2<DHP, NW>;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gta_fwd2_kernel<DHP, ESZ, NW>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gta_fwd2_kernel<DHP, ESZ, NW, LAYOUT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, S::total(GTA_MAX_VIEWS)) != hipSuccess)
             return GTA_E_LAUNCH;
         attr_set = true;
     }
     const long n_wg = (long)p.B * p.H * p.n_qtiles;
-    hipLaunchKernelGGL((gta_fwd2_kernel<DHP, ESZ, NW>), dim3((unsigned)n_wg), dim3(64 * NW), S::total(p.vrep_q ? p.Nq : 0),
+    hipLaunchKernelGGL((gta_fwd2_kernel<DHP, ESZ, NW, LAYOUT>), dim3((unsigned)n_wg), dim3(64 * NW), S::total(p.vrep_q ? p.Nq : 0),
                        stream, p);
     return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH;
 }
@@ -689,14 +724,37 @@ int gta_fwd2_lds_bytes(int dhp, int nq) {
 
 // prep (unless the caller says K'/V' images are already in the workspace) + flash.
 // nw = waves per workgroup of the flash kernel: 4 (128 query rows, two workgroups share a CU) or 8.
+// which compile-time layout (if any) the run-time chunk table is
+static int layout_of(const GtaFwdParams& p, int dhp) {
+    const int ch = p.dh / 8;
+    if (p.dh != dhp) return GTA_LAYOUT_GENERIC;
+    for (int L : {GTA_LAYOUT_MS, GTA_LAYOUT_CL, GTA_LAYOUT_SO2}) {
+        if ((L == GTA_LAYOUT_MS && dhp != 96) || (L == GTA_LAYOUT_CL && dhp != 64)) continue;
+        bool same = true;
+        for (int c = 0; c < ch; ++c) same = same && p.ctab[c] == gta_layout_desc(L, c);
+        if (same) return L;
+    }
+    return GTA_LAYOUT_GENERIC;
+}
+
+template <int DHP, int ESZ>
+static int launch_flash(const GtaFwdParams& p, int nw, hipStream_t stream) {
+    if (nw == 8) return launch_fwd2<DHP, ESZ, 8, GTA_LAYOUT_GENERIC>(p, stream);
+    switch (layout_of(p, DHP)) {
+        case GTA_LAYOUT_MS:  if (DHP == 96) return launch_fwd2<DHP, ESZ, 4, (DHP == 96 ? GTA_LAYOUT_MS : GTA_LAYOUT_GENERIC)>(p, stream); break;
+        case GTA_LAYOUT_CL:  if (DHP == 64) return launch_fwd2<DHP, ESZ, 4, (DHP == 64 ? GTA_LAYOUT_CL : GTA_LAYOUT_GENERIC)>(p, stream); break;
+        case GTA_LAYOUT_SO2: return launch_fwd2<DHP, ESZ, 4, GTA_LAYOUT_SO2>(p, stream);
+    }
+    return launch_fwd2<DHP, ESZ, 4, GTA_LAYOUT_GENERIC>(p, stream);
+}
+
 int gta_fwd2_dispatch(GtaFwdParams& p, int dhp, int esz, bool run_prep, bool run_flash, int nw, hipStream_t stream) {
     p.n_qtiles = (p.Tq + 32 * nw - 1) / (32 * nw);
     int rc = GTA_OK;
-#define GTA_FLASH(D, E) (nw == 8 ? launch_fwd2<D, E, 8>(p, stream) : launch_fwd2<D, E, 4>(p, stream))
 #define GTA_CASE2(D)                                                                    \
     case D:                                                                             \
         if (run_prep) rc = (esz == 2) ? launch_prep<D, 2>(p, stream) : launch_prep<D, 4>(p, stream); \
-        if (rc == GTA_OK && run_flash) rc = (esz == 2) ? GTA_FLASH(D, 2) : GTA_FLASH(D, 4);         \
+        if (rc == GTA_OK && run_flash) rc = (esz == 2) ? launch_flash<D, 2>(p, nw, stream) : launch_flash<D, 4>(p, nw, stream); \
         return rc;
     switch (dhp) {
         GTA_CASE2(32)
@@ -705,6 +763,5 @@ int gta_fwd2_dispatch(GtaFwdParams& p, int dhp, int esz, bool run_prep, bool run
         GTA_CASE2(128)
     }
 #undef GTA_CASE2
-#undef GTA_FLASH
     return GTA_E_UNSUPPORTED;
 }

@@ -117,18 +117,34 @@ if __name__ == "__main__":
         ws = torch.empty(native.attn_fwd_workspace_bytes(desc), device="cuda", dtype=torch.uint8)
         raw_call(q, k, v, packed, MS, L, VT, ws)[0]()
         fn, _ = raw_call(q, k, v, packed, MS, L, VT | native.FLAG_KV_READY, ws)
-        nwg = B * 8 * 10
-        for dbg in (0, 31):
+        for nw8 in (0, 1):
+          nwg = B * 8 * (5 if nw8 else 10)
+          fn, _ = raw_call(q, k, v, packed, MS, L, VT | native.FLAG_KV_READY | (native.FLAG_WG8 if nw8 else 0), ws)
+          for dbg in (0,):
             os.environ["GTA_DBG"] = str(dbg)
             for _ in range(3):
                 fn()
-            prof = torch.zeros(nwg, 8, dtype=torch.int64, device="cuda")
+            prof = torch.zeros(nwg * 3, 8, dtype=torch.int64, device="cuda")
             native.lib().gta_debug_set_profile_buffer(ctypes.c_void_p(prof.data_ptr()))
             torch.cuda.synchronize()
             fn()
             torch.cuda.synchronize()
             native.lib().gta_debug_set_profile_buffer(None)
-            P = prof.cpu().double()
+            Pall = prof.cpu().double()
+            P = Pall[:nwg]
+            seg = Pall[nwg:].reshape(nwg, 2, 8)
+            print(f"== {'8-wave ping-pong' if nw8 else '4-wave'}: per-wave loop segments, cycles summed over 20 tiles (first wave | last wave)")
+            for i, nm in enumerate(["QK^T MFMAs", "softmax", "PV (+K reads issue)", "barrier", "vmcnt wait"]):
+                print(f"   {nm:26s} {seg[:,0,i].mean():9.0f} | {seg[:,1,i].mean():9.0f}   per tile {seg[:,0,i].mean()/20:7.0f} | {seg[:,1,i].mean()/20:7.0f}")
+            xcc = P[:, 5].long(); ww = P[:, 6].long()
+            nq = 5 if nw8 else 10
+            import collections
+            by_grp = collections.defaultdict(set)
+            for i in range(nwg):
+                by_grp[int(ww[i]) // nq].add(int(xcc[i]))
+            hist = collections.Counter(len(v) for v in by_grp.values())
+            print(f"   XCC ids seen: {sorted(set(xcc.tolist()))};  #XCDs per (b,h) group -> #groups: {dict(hist)}")
+            print(f"   blockIdx 0..15 -> xcc {xcc[:16].tolist()}  w {ww[:16].tolist()}")
             t0 = P[:, 0].min()
             names = ["start->reps+Qloads landed", "Q rho+stage+frags", "main loop", "epilogue"]
             print(f"dbg={dbg}: kernel span {(P[:,4].max()-t0)/1e2:.1f} us (100 MHz s_memtime ticks assumed)")
@@ -137,8 +153,8 @@ if __name__ == "__main__":
                 print(f"   {nm:28s} mean {d.mean():9.0f} ticks  min {d.min():9.0f} max {d.max():9.0f}")
             st = (P[:, 0] - t0)
             order = torch.argsort(st)
-            print("   start offsets (ticks) of WGs sorted: ", [int(st[order[i]]) for i in (0, 255, 511, 512, 767, 1023, 1024, 1535, 2047, 2559)])
-            print("   end   offsets (ticks)             : ", [int((P[order[i], 4] - t0)) for i in (0, 255, 511, 512, 767, 1023, 1024, 1535, 2047, 2559)])
+            pass
+            pass
         os.environ["GTA_DBG"] = "0"
     if which in ("all", "others"):
         report("MS-dec", B, 8, 5, 512, 5, 256, MS, 6, 2)
