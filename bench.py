@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=10,
+                    help="extra (untimed-for-`value`) forward+backward steps reported as fwd_bwd_* fields; 0 = skip")
     ap.add_argument("--kv-mode", dest="kv_mode", default="prepass", choices=["prepass", "fused"],
                     help="execution plan of gta_attn_fwd (see include/gta_hip.h)")
     args = ap.parse_args()
@@ -157,7 +159,34 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps      # fused kernel only (same stream)
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps      # attention kernel only (same stream)
+
+    # forward + backward of the operator (gta_attn_bwd: q-side pre-pass, dQ, dK/dV), reported beside the headline
+    fwd_bwd_ms = None
+    if args.train_steps > 0:
+        qg, kg, vg = (t.detach().clone().requires_grad_() for t in (q, k, v))
+        tcg = tc.detach().clone().requires_grad_() if tc is not None else None
+        ex = dict(exd)
+        gta_amd.pre_compute_reps_encoder(ak, ex)
+        if cross:
+            gta_amd.pre_compute_reps_decoder(ak, ex)
+        packed = gta_amd.pack_reps(ex, f_dims)
+        w = torch.randn_like(q)
+
+        def train_step():
+            out = gta_amd.gta_attention(qg, kg, vg, f_dims, packed, so3_degree=ex.get("gta_so3_degree", 0), trans_coeff=tcg)
+            out.backward(w)
+            qg.grad = kg.grad = vg.grad = None
+        for _ in range(3):
+            train_step()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.train_steps):
+            train_step()
+        e1.record()
+        torch.cuda.synchronize()
+        fwd_bwd_ms = e0.elapsed_time(e1) / args.train_steps
     flops = 4.0 * B * H * Tq * Tk * dh                               # QK^T + PV, 2 flop/MAC
     alg_bytes = (2 * Tq + 2 * Tk) * H * dh * q.element_size() * B    # read Q,K,V once, write O once
     achieved = flops / (kern_ms * 1e-3) / 1e12
@@ -181,6 +210,11 @@ def main():
                          "algorithmic_bytes": alg_bytes,
                          "hbm_frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
         }
+        if fwd_bwd_ms is not None:
+            line["fwd_bwd"] = {"ms_per_step": fwd_bwd_ms, "mtokens_s_per_gpu": B * Tq / (fwd_bwd_ms * 1e-3) / 1e6,
+                               "tflops": 3.5 * flops / (fwd_bwd_ms * 1e-3) / 1e12,
+                               "note": "operator forward + backward (5 GEMMs + 2 recomputed = 3.5x forward flops), "
+                                       "not part of `value`"}
         if not args.no_cpu_baseline and n == 1:
             line["cpu_baseline"] = cpu_baseline(args.workload, 99)
         print(json.dumps(line), flush=True)

@@ -751,13 +751,16 @@ __global__ __launch_bounds__(256, 1) void gta_bwd_dkv_kernel(const GtaBwdParams 
     if (tid == 0) p.dc_partial[p.dc_off_dkv + w] = dc_wg;
 }
 
-__global__ void gta_reduce_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
-    __shared__ float sm[256];
-    float acc = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) acc += part[i];     // fixed order per thread: deterministic
-    sm[threadIdx.x] = acc;
+// deterministic two-level sum: 1024 threads each take a fixed strided subset, then a fixed tree
+__global__ __launch_bounds__(1024) void gta_reduce_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+    __shared__ float sm[1024];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;                 // 4 independent loads in flight per thread
+    int i = threadIdx.x;
+    for (; i + 3 * 1024 < n; i += 4 * 1024) { a0 += part[i]; a1 += part[i + 1024]; a2 += part[i + 2048]; a3 += part[i + 3072]; }
+    for (; i < n; i += 1024) a0 += part[i];
+    sm[threadIdx.x] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    for (int o = 128; o >= 1; o >>= 1) {
+    for (int o = 512; o >= 1; o >>= 1) {
         if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
         __syncthreads();
     }
@@ -788,7 +791,7 @@ int run_bwd(const GtaBwdParams& p, hipStream_t stream) {
     const int n_dkv = p.B * p.H * ((p.Tk + 127) / 128);
     hipLaunchKernelGGL((gta_bwd_dkv_kernel<DHP, ESZ>), dim3(n_dkv), dim3(256), DkvSmem<DHP>::total(p.vrep_k ? p.Nk : 0), stream, p);
     if (p.dtrans_coeff)
-        hipLaunchKernelGGL(gta_reduce_kernel, dim3(1), dim3(256), 0, stream, p.dc_partial, p.dc_total, p.dtrans_coeff);
+        hipLaunchKernelGGL(gta_reduce_kernel, dim3(1), dim3(1024), 0, stream, p.dc_partial, p.dc_total, p.dtrans_coeff);
     return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH;
 }
 

@@ -133,9 +133,10 @@ if __name__ == "__main__":
             Pall = prof.cpu().double()
             P = Pall[:nwg]
             seg = Pall[nwg:].reshape(nwg, 2, 8)
-            print(f"== {'8-wave ping-pong' if nw8 else '4-wave'}: per-wave loop segments, cycles summed over 20 tiles (first wave | last wave)")
-            for i, nm in enumerate(["QK^T MFMAs", "softmax", "PV (+K reads issue)", "barrier", "vmcnt wait"]):
-                print(f"   {nm:26s} {seg[:,0,i].mean():9.0f} | {seg[:,1,i].mean():9.0f}   per tile {seg[:,0,i].mean()/20:7.0f} | {seg[:,1,i].mean()/20:7.0f}")
+            print(f"== {'8-wave' if nw8 else '4-wave'} attention kernel")
+            if seg.abs().sum() > 0:
+                for i, nm in enumerate(["QK^T MFMAs", "softmax", "PV (+K reads issue)", "barrier", "vmcnt wait"]):
+                    print(f"   {nm:26s} {seg[:,0,i].mean():9.0f} | {seg[:,1,i].mean():9.0f}   per tile {seg[:,0,i].mean()/20:7.0f} | {seg[:,1,i].mean()/20:7.0f}")
             xcc = P[:, 5].long(); ww = P[:, 6].long()
             nq = 5 if nw8 else 10
             import collections
