@@ -36,6 +36,10 @@ int build_ctab(const GtaAttnDesc* d, uint32_t* ctab) {
         return fail(GTA_E_LAYOUT, "negative slab size");
     if (d->d_triv + d->d_se3 + d->d_so3 + d->d_so2 + d->d_t2 != d->dh)
         return fail(GTA_E_LAYOUT, "f_dims do not sum to dh");
+    if (d->flags & GTA_FLAG_EUCLID) {
+        if (d->d_se3 % 3) return fail(GTA_E_LAYOUT, "under euclid_sim the se3 slab holds 3-vectors (gta.py:147)");
+        return fail(GTA_E_UNSUPPORTED, "euclid similarity has no fused kernel (gta_rep_apply + gta_attn_fwd_plain)");
+    }
     if (d->d_se3 % 4) return fail(GTA_E_LAYOUT, "se3 slab must be a multiple of 4 channels (gta.py:161)");
     if (d->d_so2 % 4) return fail(GTA_E_LAYOUT, "so2 slab must be 4*nfreqs channels (gta.py:212-214)");
     if (d->d_t2 % 3) return fail(GTA_E_LAYOUT, "t2 slab must be a multiple of 3 channels (gta.py:231)");
@@ -111,10 +115,12 @@ extern "C" const char* gta_strerror(int code) {
 }
 
 extern "C" int gta_attn_fwd_supported(const GtaAttnDesc* desc) {
-    int rc = check_common(desc);
-    if (rc) return rc;
+    if (!desc) return fail(GTA_E_BADARG, "null descriptor");
+    if (desc->abi_version != GTA_ABI_VERSION) return fail(GTA_E_BADARG, "abi_version mismatch");
     uint32_t ctab[16];
-    return build_ctab(desc, ctab);
+    int rc = build_ctab(desc, ctab);      // layout first: "no fused kernel" must not be masked by a stride complaint
+    if (rc) return rc;
+    return check_common(desc);
 }
 
 extern "C" int64_t gta_attn_fwd_workspace_bytes(const GtaAttnDesc* desc) {
@@ -273,6 +279,38 @@ extern "C" int gta_attn_bwd(const GtaAttnDesc* d, const void* q, const void* k, 
     p.dh = d->dh; p.nso2 = d->d_so2 / 2; p.flags = d->flags; p.scale = d->scale;
     if (d->H > 65535 || d->B > 65535) return fail(GTA_E_UNSUPPORTED, "B or H above 65535");
     rc = gta_bwd_dispatch(p, padded_dh(d->dh), esz, (hipStream_t)stream);
+    if (rc) return fail(rc, rc == GTA_E_LAUNCH ? hipGetErrorString(hipGetLastError()) : "no kernel instance");
+    return GTA_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// plain attention (identity layout) with an optional key bias: the attention stage of the generic path
+// ---------------------------------------------------------------------------------------------
+extern "C" int gta_attn_fwd_plain(const GtaAttnDesc* d, const void* q, const void* k, const void* v,
+                                  const float* key_bias, int64_t bias_pitch, const float* tau, void* out, float* lse,
+                                  void* stream) {
+    if (!d || !q || !k || !v || !out) return fail(GTA_E_BADARG, "null argument");
+    if (d->abi_version != GTA_ABI_VERSION) return fail(GTA_E_BADARG, "abi_version mismatch");
+    if (d->dtype != GTA_DTYPE_F32 && d->dtype != GTA_DTYPE_BF16) return fail(GTA_E_BADARG, "bad dtype");
+    if (d->B <= 0 || d->H <= 0 || d->Tq <= 0 || d->Tk <= 0 || d->dh <= 0) return fail(GTA_E_BADARG, "non-positive size");
+    const int dhp = (d->dh + 7) / 8 * 8;
+    if (dhp != d->dh || d->dh > 128) return fail(GTA_E_UNSUPPORTED, "plain attention needs dh % 8 == 0 and dh <= 128 (pad the channels)");
+    if (key_bias && (bias_pitch % 64 || bias_pitch < d->Tk)) return fail(GTA_E_BADARG, "bias_pitch must be a multiple of 64 >= Tk");
+    const int esz = d->dtype == GTA_DTYPE_BF16 ? 2 : 4;
+    GtaFwdParams p;
+    memset(&p, 0, sizeof p);
+    p.q = q; p.k = k; p.v = v; p.o = out; p.lse = lse; p.tau = tau;
+    p.kbias = key_bias; p.kbias_pitch = bias_pitch;
+    p.q_sb = d->q_stride[0]; p.q_sh = d->q_stride[1]; p.q_st = d->q_stride[2];
+    p.k_sb = d->k_stride[0]; p.k_sh = d->k_stride[1]; p.k_st = d->k_stride[2];
+    p.v_sb = d->v_stride[0]; p.v_sh = d->v_stride[1]; p.v_st = d->v_stride[2];
+    p.o_sb = d->o_stride[0]; p.o_sh = d->o_stride[1]; p.o_st = d->o_stride[2];
+    p.B = d->B; p.H = d->H; p.Tq = d->Tq; p.Tk = d->Tk; p.Nq = 1; p.Nk = 1; p.Pq = d->Tq; p.Pk = d->Tk;
+    p.invPq = 1.0f / p.Pq; p.invPk = 1.0f / p.Pk;
+    p.dh = d->dh; p.nso2 = 0; p.n_qtiles = (d->Tq + 127) / 128; p.flags = 0; p.scale = d->scale;
+    const long n_wg = (long)d->B * d->H * p.n_qtiles;
+    int rc = gta_fwd_dispatch(p, padded_dh(d->dh), esz, true, (int)n_wg, (hipStream_t)stream);
     if (rc) return fail(rc, rc == GTA_E_LAUNCH ? hipGetErrorString(hipGetLastError()) : "no kernel instance");
     return GTA_OK;
 }

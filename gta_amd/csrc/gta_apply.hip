@@ -1,0 +1,151 @@
+// gta_apply.hip -- generic rho application for ANY f_dims layout (ablation paths of the reference):
+// t2 slab (gta.py:221-238,272-274), euclid similarity (gta.py:146-156,251-253; layers.py:213-224),
+// so3 of degree 1, unaligned slabs.  One thread per (batch, head, token) row, block by block straight
+// from/to global memory -- correctness path, HBM-bound at best; the shipped configs never come here.
+//   mode 0: q side      q' = blockdiag((E_q.m)^T | D(R_q) | R(th_q) | (T_q^-1)^T) q      (euclid: affine inv(E_q).m)
+//   mode 1: k side      k' = blockdiag(inv(E_k).m | D(R_k) | R(th_k) | T_k) k  (also v)  (euclid: affine inv(E_k).m)
+//   mode 2: output      o  = blockdiag(E_q.m | D(R_q)^T | R(th_q)^T | T_q^-1) o~        (euclid: affine E_q.m)
+#include "gta_common.h"
+#include "../../include/gta_hip.h"
+
+namespace {
+
+struct ApplyParams {
+    const void* x; void* y;
+    long x_sb, x_sh, x_st, y_sb, y_sh, y_st;
+    const float *vrep, *cs, *coord, *trans_coeff;
+    float* key_bias; float bias_scale; long bias_pitch;
+    int B, H, T, N, P;
+    int d_triv, d_se3, d_so3, d_so2, d_t2, L;
+    int mode, euclid, esz;
+};
+
+template <int ESZ> GTA_DEV float ld(const char* p, int i) {
+    if (ESZ == 4) return reinterpret_cast<const float*>(p)[i];
+    return __uint_as_float((uint32_t)reinterpret_cast<const uint16_t*>(p)[i] << 16);
+}
+template <int ESZ> GTA_DEV void st(char* p, int i, float v) {
+    if (ESZ == 4) { reinterpret_cast<float*>(p)[i] = v; return; }
+    reinterpret_cast<uint16_t*>(p)[i] = (uint16_t)(pack_bf16x2(v, 0.f) & 0xffffu);
+}
+
+template <int ESZ>
+__global__ void gta_apply_kernel(const ApplyParams p) {
+    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)p.B * p.H * p.T;
+    if (row >= total) return;
+    const int t = (int)(row % p.T);
+    const int h = (int)((row / p.T) % p.H);
+    const int b = (int)(row / ((long)p.T * p.H));
+    const char* x = (const char*)p.x + ((long)b * p.x_sb + (long)h * p.x_sh + (long)t * p.x_st) * ESZ;
+    char* y = (char*)p.y + ((long)b * p.y_sb + (long)h * p.y_sh + (long)t * p.y_st) * ESZ;
+    const float tc = p.trans_coeff ? *p.trans_coeff : 1.0f;
+    const int n = t / p.P;
+    const float* vr = p.vrep ? p.vrep + ((long)b * p.N + n) * GTA_VREP_STRIDE : nullptr;
+    float sq = 0.f;
+    int ch = 0;
+    for (int i = 0; i < p.d_triv; ++i, ++ch) { const float v = ld<ESZ>(x, ch); st<ESZ>(y, ch, v); sq += v * v; }
+    if (p.d_se3 > 0) {
+        // matrix used: mode 0 non-euclid: (E.m)^T ; mode 0 euclid: inv(E).m ; mode 1: inv(E).m ; mode 2: E.m
+        float M[16];
+        const bool use_inv_slot = (p.mode == 2) || (p.mode == 0 && !p.euclid);     // "inv" slot holds E
+        const float* src = vr + (use_inv_slot ? GTA_VREP_INV : GTA_VREP_REP);
+        for (int r = 0; r < 4; ++r)
+            for (int c = 0; c < 4; ++c) {
+                const float m = (r == 3) ? (c == 3 ? 1.f : 0.f) : (c == 3 ? tc : 1.f);
+                const float v = src[r * 4 + c] * m;
+                if (p.mode == 0 && !p.euclid) M[c * 4 + r] = v; else M[r * 4 + c] = v;
+            }
+        if (p.euclid) {
+            for (int blk = 0; blk < p.d_se3 / 3; ++blk, ch += 3) {
+                const float a = ld<ESZ>(x, ch), bb = ld<ESZ>(x, ch + 1), c = ld<ESZ>(x, ch + 2);
+                for (int r = 0; r < 3; ++r) {
+                    const float v = M[r * 4] * a + M[r * 4 + 1] * bb + M[r * 4 + 2] * c + M[r * 4 + 3];   // homogenisation
+                    st<ESZ>(y, ch + r, v); sq += v * v;
+                }
+            }
+        } else {
+            for (int blk = 0; blk < p.d_se3 / 4; ++blk, ch += 4) {
+                const float a = ld<ESZ>(x, ch), bb = ld<ESZ>(x, ch + 1), c = ld<ESZ>(x, ch + 2), d = ld<ESZ>(x, ch + 3);
+                for (int r = 0; r < 4; ++r) {
+                    const float v = M[r * 4] * a + M[r * 4 + 1] * bb + M[r * 4 + 2] * c + M[r * 4 + 3] * d;
+                    st<ESZ>(y, ch + r, v); sq += v * v;
+                }
+            }
+        }
+    }
+    if (p.d_so3 > 0) {
+        const int tot = p.L >= 2 ? 8 : 3;
+        for (int g = 0; g < p.d_so3 / tot; ++g) {
+            for (int l = 1; l <= p.L; ++l) {
+                const int dim = 2 * l + 1;
+                const float* D = vr + (l == 1 ? GTA_VREP_D1 : GTA_VREP_D2);
+                float in[5];
+                for (int i = 0; i < dim; ++i) in[i] = ld<ESZ>(x, ch + i);
+                for (int r = 0; r < dim; ++r) {
+                    float v = 0.f;
+                    for (int c = 0; c < dim; ++c) v += (p.mode == 2 ? D[c * dim + r] : D[r * dim + c]) * in[c];
+                    st<ESZ>(y, ch + r, v); sq += v * v;
+                }
+                ch += dim;
+            }
+        }
+    }
+    if (p.d_so2 > 0) {
+        const int nblk = p.d_so2 / 2;
+        const float* cs = p.cs + ((long)b * p.T + t) * 2 * nblk;
+        for (int blk = 0; blk < nblk; ++blk, ch += 2) {
+            const float c = cs[2 * blk], s = (p.mode == 2 ? -1.f : 1.f) * cs[2 * blk + 1];
+            const float a = ld<ESZ>(x, ch), bb = ld<ESZ>(x, ch + 1);
+            const float v0 = c * a - s * bb, v1 = s * a + c * bb;
+            st<ESZ>(y, ch, v0); st<ESZ>(y, ch + 1, v1); sq += v0 * v0 + v1 * v1;
+        }
+    }
+    if (p.d_t2 > 0) {
+        const float cx = p.coord[((long)b * p.T + t) * 2], cy = p.coord[((long)b * p.T + t) * 2 + 1];
+        for (int blk = 0; blk < p.d_t2 / 3; ++blk, ch += 3) {
+            const float a = ld<ESZ>(x, ch), bb = ld<ESZ>(x, ch + 1), c = ld<ESZ>(x, ch + 2);
+            float v0, v1, v2;
+            if (p.mode == 0)      { v0 = a - cx * c; v1 = bb - cy * c; v2 = c; }                   // (T^-1)^T
+            else if (p.mode == 1) { v0 = a; v1 = bb; v2 = cx * a + cy * bb + c; }                  // T
+            else                  { v0 = a; v1 = bb; v2 = c - cx * a - cy * bb; }                  // T^-1
+            st<ESZ>(y, ch, v0); st<ESZ>(y, ch + 1, v1); st<ESZ>(y, ch + 2, v2); sq += v0 * v0 + v1 * v1 + v2 * v2;
+        }
+    }
+    if (p.key_bias) p.key_bias[((long)b * p.H + h) * p.bias_pitch + t] = -0.5f * p.bias_scale * sq;
+}
+
+}  // namespace
+
+extern "C" int gta_rep_apply(const GtaAttnDesc* d, int32_t mode, const void* x, const int64_t* x_stride,
+                             const float* vrep, const float* cs, const float* coord, const float* trans_coeff,
+                             void* y, const int64_t* y_stride, float* key_bias, float bias_scale, int64_t bias_pitch,
+                             void* stream) {
+    if (!d || !x || !y || !x_stride || !y_stride || mode < 0 || mode > 2) return GTA_E_BADARG;
+    if (d->abi_version != GTA_ABI_VERSION) return GTA_E_BADARG;
+    if (d->d_triv + d->d_se3 + d->d_so3 + d->d_so2 + d->d_t2 != d->dh) return GTA_E_LAYOUT;
+    const bool euclid = (d->flags & GTA_FLAG_EUCLID) != 0;
+    if (d->d_se3 % (euclid ? 3 : 4) || d->d_so2 % 2 || d->d_t2 % 3) return GTA_E_LAYOUT;
+    if (d->d_so3 > 0 && (d->so3_degree < 1 || d->so3_degree > 2 || d->d_so3 % (d->so3_degree == 2 ? 8 : 3))) return GTA_E_UNSUPPORTED;
+    if ((d->d_se3 > 0 || d->d_so3 > 0) && !vrep) return GTA_E_BADARG;
+    if (d->d_so2 > 0 && !cs) return GTA_E_BADARG;
+    if (d->d_t2 > 0 && !coord) return GTA_E_BADARG;
+    ApplyParams p;
+    p.x = x; p.y = y;
+    p.x_sb = x_stride[0]; p.x_sh = x_stride[1]; p.x_st = x_stride[2];
+    p.y_sb = y_stride[0]; p.y_sh = y_stride[1]; p.y_st = y_stride[2];
+    p.vrep = vrep; p.cs = cs; p.coord = coord; p.trans_coeff = trans_coeff;
+    p.key_bias = key_bias; p.bias_scale = bias_scale; p.bias_pitch = bias_pitch;
+    p.B = d->B; p.H = d->H;
+    p.T = mode == 1 ? d->Tk : d->Tq;
+    p.N = mode == 1 ? d->Nk : d->Nq;
+    p.P = p.T / p.N;
+    p.d_triv = d->d_triv; p.d_se3 = d->d_se3; p.d_so3 = d->d_so3; p.d_so2 = d->d_so2; p.d_t2 = d->d_t2; p.L = d->so3_degree;
+    p.mode = mode; p.euclid = euclid ? 1 : 0; p.esz = d->dtype == GTA_DTYPE_BF16 ? 2 : 4;
+    const long total = (long)p.B * p.H * p.T;
+    const int th = 256;
+    const unsigned nb = (unsigned)((total + th - 1) / th);
+    if (p.esz == 2) hipLaunchKernelGGL(gta_apply_kernel<2>, dim3(nb), dim3(th), 0, (hipStream_t)stream, p);
+    else            hipLaunchKernelGGL(gta_apply_kernel<4>, dim3(nb), dim3(th), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH;
+}

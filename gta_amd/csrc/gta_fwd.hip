@@ -350,6 +350,17 @@ __global__ __launch_bounds__(NTHREADS, (DHP <= 96 ? 2 : 1)) void gta_fwd_kernel(
                 s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[ks], s1, 0, 0, 0);
             }
         }
+        if (p.kbias) {     // additive per-key bias (euclid: -scale |k'|^2 / 2), given before the temperature
+            const float bsc = LOG2E / (p.tau ? *p.tau : 1.0f);
+            const float* kb = p.kbias + ((long)b * p.H + h) * p.kbias_pitch + j * BN + 4 * lh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(kb + 8 * g);
+                const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(kb + 32 + 8 * g);
+                s0[4 * g] += bsc * b0.x; s0[4 * g + 1] += bsc * b0.y; s0[4 * g + 2] += bsc * b0.z; s0[4 * g + 3] += bsc * b0.w;
+                s1[4 * g] += bsc * b1.x; s1[4 * g + 1] += bsc * b1.y; s1[4 * g + 2] += bsc * b1.z; s1[4 * g + 3] += bsc * b1.w;
+            }
+        }
         // mask keys past Tk (last tile only): key = j*64 + 32*kb + (r&3) + 8*(r>>2) + 4*lh
         if (j == n_tiles - 1 && (p.Tk & (BN - 1))) {
             const int kbase = j * BN + 4 * lh;

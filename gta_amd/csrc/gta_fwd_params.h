@@ -8,6 +8,7 @@ struct GtaFwdParams {
     const float* vrep_q; const float* vrep_k;   // [B,N,GTA_VREP_STRIDE]
     const float* cs_q; const float* cs_k;       // [B,T,nso2,2] (cos,sin)
     const float* trans_coeff; const float* tau; // device scalars or null
+    const float* kbias; long kbias_pitch;       // optional additive per-key bias (log2 units), [B,H,pitch]
     long q_sb, q_sh, q_st, k_sb, k_sh, k_st, v_sb, v_sh, v_st, o_sb, o_sh, o_st;  // element strides
     int B, H, Tq, Tk, Nq, Nk, Pq, Pk;           // P* = tokens per view
     float invPq, invPk;

@@ -83,6 +83,14 @@ def pack_reps(reps: dict, f_dims: dict) -> dict:
                                        reps.get(f"se3rep_{side}"), Ds)
                 reps[key + "_src"] = src
             out[f"vrep_{side}"] = reps[key]
+    if f_dims.get("t2", 0) > 0:
+        # make_T2mats (gta.py:72-89): T = [[1,0,0],[0,1,0],[cx,cy,1]] -> the kernel wants (cx, cy) per token
+        for side in ("q", "k"):
+            key = f"gta_coord_{side}"
+            if key not in reps:
+                T = reps[f"t2rep_{side}"]
+                reps[key] = torch.stack([T[..., 2, 0], T[..., 2, 1]], -1).detach().float().contiguous()
+            out[f"coord_{side}"] = reps[key]
     if need_so2:
         for side in ("q", "k"):
             key = f"gta_cs_{side}"
@@ -176,6 +184,46 @@ class _GtaAttn(torch.autograd.Function):
         return dq, dk, dv, dtc, None, None, None, None, None, None, None
 
 
+def _generic_forward(q, k, v, f_dims, packed, so3_degree, trans_coeff, tau, scale, v_transform, euclid):
+    """Ablation layouts the fused kernels refuse (t2 slab, euclid similarity, so3 degree 1, unaligned
+    slabs): generic rho-apply kernels around the plain attention kernel.  Forward only."""
+    if any(t is not None and torch.is_tensor(t) and t.requires_grad and torch.is_grad_enabled()
+           for t in (q, k, v, trans_coeff)):
+        raise native.GtaError("backward is not built for this f_dims layout / euclid_sim (forward-only generic path)")
+    dt = q.dtype
+    if dt not in (torch.float32, torch.bfloat16):
+        raise native.GtaError(f"unsupported dtype {dt}")
+    k, v = k.to(dt), v.to(dt)
+    B, H, Tq, dh = q.shape
+    Tk = k.shape[2]
+    Nq, Nk = _views(f_dims, packed, q, k)
+    flags = (native.FLAG_V_TRANSFORM if v_transform else 0) | (native.FLAG_EUCLID if euclid else 0)
+    dhp = (dh + 7) // 8 * 8                                    # the attention kernel works on 8-channel chunks
+    mk = lambda T: torch.zeros(B, T, H, dhp, device=q.device, dtype=dt).permute(0, 2, 1, 3)
+    qp, kp, vp, op = mk(Tq), mk(Tk), mk(Tk), mk(Tq)
+    out = torch.empty(B, Tq, H, dh, device=q.device, dtype=dt).permute(0, 2, 1, 3)
+    desc = native.make_desc(q, k, v, out, f_dims, so3_degree, Nq, Nk, scale, flags)
+    tc = trans_coeff.detach().float().reshape(-1) if torch.is_tensor(trans_coeff) else None
+    ta = tau.detach().float().reshape(-1) if torch.is_tensor(tau) else None
+    pitch = (Tk + 63) // 64 * 64
+    kbias = torch.zeros(B, H, pitch, device=q.device, dtype=torch.float32) if euclid else None
+    vq, vk = packed.get("vrep_q"), packed.get("vrep_k")
+    native.rep_apply(desc, 0, q, vq, packed.get("cs_q"), packed.get("coord_q"), tc, qp[..., :dh])
+    native.rep_apply(desc, 1, k, vk, packed.get("cs_k"), packed.get("coord_k"), tc, kp[..., :dh], kbias, scale)
+    if v_transform:
+        native.rep_apply(desc, 1, v, vk, packed.get("cs_k"), packed.get("coord_k"), tc, vp[..., :dh])
+    else:
+        vp[..., :dh] = v
+    pdesc = native.make_desc(qp, kp, vp, op, {"triv": dhp}, 0, 1, 1, scale, 0)
+    lse = torch.empty(B, H, Tq, device=q.device, dtype=torch.float32)
+    native.attn_fwd_plain(pdesc, qp, kp, vp, kbias, ta, op, lse)
+    if v_transform:
+        native.rep_apply(desc, 2, op[..., :dh], vq, packed.get("cs_q"), packed.get("coord_q"), tc, out)
+    else:
+        out.copy_(op[..., :dh])
+    return out
+
+
 def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: int = 0,
                   trans_coeff=None, tau=None, scale: Optional[float] = None, v_transform: bool = True,
                   euclid: bool = False, pretransformed: bool = False, use_dma: bool = True,
@@ -206,6 +254,10 @@ def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: 
     if kv_mode == "fused" or not use_dma:
         flags |= native.FLAG_FUSED_KV
     Nq, Nk = _views(f_dims, packed, q, k)
+    if q.is_cuda and not pretransformed:
+        probe = native.make_desc(q, k, v, q, f_dims, so3_degree, Nq, Nk, scale, flags)
+        if native.attn_fwd_supported(probe) == -3:       # GTA_E_UNSUPPORTED: valid request, no fused kernel
+            return _generic_forward(q, k, v, f_dims, packed, so3_degree, trans_coeff, tau, scale, v_transform, euclid)
     cfg = ({k_: int(v_) for k_, v_ in f_dims.items()}, int(so3_degree), Nq, Nk, float(scale), flags)
     if isinstance(trans_coeff, (int, float)):
         trans_coeff = torch.tensor([float(trans_coeff)], device=q.device, dtype=torch.float32)

@@ -33,6 +33,7 @@ MAX_VIEWS = 16
 ABI_SYMBOLS = (
     "gta_build_view_reps", "gta_build_so2_table", "gta_attn_fwd", "gta_attn_fwd_supported",
     "gta_attn_fwd_launch_info", "gta_attn_fwd_workspace_bytes", "gta_attn_bwd", "gta_attn_bwd_workspace_bytes",
+    "gta_rep_apply", "gta_attn_fwd_plain",
     "gta_strerror", "gta_abi_version", "gta_sizeof_attn_desc",
 )
 
@@ -84,6 +85,10 @@ def lib():
                                    + [ctypes.POINTER(c_int64), ctypes.POINTER(c_int64), c_void_p, c_void_p, c_int64, c_void_p])
         L.gta_attn_bwd_workspace_bytes.argtypes = [ctypes.POINTER(GtaAttnDesc)]
         L.gta_attn_bwd_workspace_bytes.restype = c_int64
+        L.gta_rep_apply.argtypes = [ctypes.POINTER(GtaAttnDesc), c_int32, c_void_p, ctypes.POINTER(c_int64), c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int64), c_void_p, c_float, c_int64, c_void_p]
+        L.gta_attn_fwd_plain.argtypes = [ctypes.POINTER(GtaAttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                         c_void_p, c_void_p, c_void_p, c_void_p]
         _lib = L
     return _lib
 
@@ -191,3 +196,20 @@ def attn_bwd(desc: GtaAttnDesc, q, k, v, out, dout, lse, vrep_q, vrep_k, cs_q, c
                              _ptr(vrep_q), _ptr(vrep_k), _ptr(cs_q), _ptr(cs_k), _ptr(trans_coeff), _ptr(tau),
                              _ptr(kv_images), _ptr(dq), _ptr(dk), _ptr(dv), gs, ds, _ptr(dtrans_coeff),
                              _ptr(workspace), workspace.numel(), _stream()), "gta_attn_bwd")
+
+
+def rep_apply(desc: GtaAttnDesc, mode: int, x, vrep, cs, coord, trans_coeff, y, key_bias=None, bias_scale=0.0):
+    """Generic rho application (any layout / t2 / euclid): x, y are [B,H,T,dh] views."""
+    _require_cuda(x, y)
+    xs = (c_int64 * 3)(*x.stride()[:3])
+    ys = (c_int64 * 3)(*y.stride()[:3])
+    check(lib().gta_rep_apply(ctypes.byref(desc), int(mode), _ptr(x), xs, _ptr(vrep), _ptr(cs), _ptr(coord),
+                              _ptr(trans_coeff), _ptr(y), ys, _ptr(key_bias), float(bias_scale),
+                              0 if key_bias is None else key_bias.shape[-1], _stream()), "gta_rep_apply")
+
+
+def attn_fwd_plain(desc: GtaAttnDesc, q, k, v, key_bias, tau, out, lse):
+    _require_cuda(q, k, v, out)
+    check(lib().gta_attn_fwd_plain(ctypes.byref(desc), _ptr(q), _ptr(k), _ptr(v), _ptr(key_bias),
+                                   0 if key_bias is None else key_bias.shape[-1], _ptr(tau), _ptr(out), _ptr(lse),
+                                   _stream()), "gta_attn_fwd_plain")

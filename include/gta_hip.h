@@ -148,6 +148,28 @@ int gta_attn_bwd(const GtaAttnDesc* desc,
                  float* dtrans_coeff,
                  void* workspace, int64_t workspace_bytes, void* stream);
 
+/* -------------------------------------------------------------------------------------------
+ * Generic path for the reference's ablations (any f_dims layout): t2 slab (gta.py:221-238,272-274),
+ * euclid similarity (GTA_FLAG_EUCLID; gta.py:146-156,251-253 + EuclidAttnFn layers.py:213-224),
+ * so3 of degree 1, unaligned slabs.  Forward only.  Usage: q' = apply(mode 0), k' = apply(mode 1)
+ * (+ key_bias under euclid), v' = apply(mode 1), o~ = gta_attn_fwd_plain(q',k',v',key_bias),
+ * o = apply(mode 2).
+ *   x, y: [B,H,T,dh] through x_stride/y_stride (b,h,t), dtype from desc; T,N = Tq,Nq (modes 0,2) or Tk,Nk.
+ *   coord [B,T,2]: the token coordinates of the t2 slab (make_T2mats, gta.py:72-89) or NULL.
+ *   key_bias (mode 1, or NULL): [B,H,bias_pitch] <- -0.5 * bias_scale * |y|^2 per token.
+ * ------------------------------------------------------------------------------------------- */
+int gta_rep_apply(const GtaAttnDesc* desc, int32_t mode, const void* x, const int64_t* x_stride,
+                  const float* vrep, const float* cs, const float* coord, const float* trans_coeff,
+                  void* y, const int64_t* y_stride, float* key_bias, float bias_scale, int64_t bias_pitch,
+                  void* stream);
+
+/* softmax((scale * q k^T + key_bias) / tau) v with no rep at all (the fused kernel on an identity layout).
+ * key_bias: [B,H,bias_pitch] fp32, added to scale*q.k BEFORE the division by tau; bias_pitch a multiple of 64 >= Tk; or NULL.
+ * Only desc->{dtype,B,H,Tq,Tk,dh,scale,*_stride} are read. */
+int gta_attn_fwd_plain(const GtaAttnDesc* desc, const void* q, const void* k, const void* v,
+                       const float* key_bias, int64_t bias_pitch, const float* tau,
+                       void* out, float* lse, void* stream);
+
 /* 0 when gta_attn_fwd has a fused kernel for this desc, else the error it would return. */
 int gta_attn_fwd_supported(const GtaAttnDesc* desc);
 

@@ -48,6 +48,9 @@ def test_descriptor_validation_without_gpu():
     d = _desc()
     d.flags |= native.FLAG_EUCLID
     assert ok(d) == -3
+    d = _desc(14, {"se3": 6, "so2": 8}, 0)          # the euclid fixture's layout: 3-vectors
+    d.flags |= native.FLAG_EUCLID
+    assert ok(d) == -3
     assert b"euclid" in native.lib().gta_strerror(-3)
     assert native.launch_info(_desc()) == {"lds_bytes": 86784, "workgroups": 2 * 8 * 10, "threads": 256}  # fp32
     assert native.launch_info(_desc(dtype=native.DTYPE_BF16))["lds_bytes"] == 64256      # bf16: 2 WGs per CU
