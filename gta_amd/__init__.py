@@ -6,7 +6,7 @@ the ``Attention``/``Transformer`` blocks of ``source/layers.py`` + the rep build
 is hand-written HIP for gfx950 behind the C ABI in ``include/gta_hip.h``.
 """
 from .gta import (multihead_geometric_transform_attention, make_2dcoord, make_SO2mats,  # noqa: F401
-                  pack_reps, gta_attention)
+                  pack_reps, gta_attention, multihead_vecrep_attention, attention_map)
 from .layers import Attention, Transformer, PreNorm, FeedForward, JaxLinear, ViTLinear  # noqa: F401
 from .reps import pre_compute_reps_encoder, pre_compute_reps_decoder  # noqa: F401
 

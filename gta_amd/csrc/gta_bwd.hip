@@ -519,8 +519,10 @@ struct DkvSmem {
     static constexpr int IMG = BN * DHP * 2;
     static constexpr int STAGE = 2 * IMG;                  // Q'' image + dO~ image of one 64-row tile
     static constexpr int RING = NSTAGE * STAGE;
-    static constexpr int OFF_KV = 0;                       // this workgroup's two K'/V' tiles (resident)
-    static constexpr int OFF_RING = 2 * STAGE;
+    // this workgroup's two K'/V' tiles are only needed until their fragments sit in VGPRs: they alias
+    // ring stages 1..2, so the kernel needs just the ring and two workgroups share a CU
+    static constexpr int OFF_RING = 0;
+    static constexpr int OFF_KV = STAGE;
     static constexpr int OFF_STATS = OFF_RING + RING;      // [2][128] floats
     static constexpr int OFF_SCR = OFF_STATS + 2 * 128 * 4;
     static constexpr int OFF_REC = OFF_SCR + 32;
@@ -531,7 +533,7 @@ struct DkvSmem {
 };
 
 template <int DHP, int ESZ>
-__global__ __launch_bounds__(256, 1) void gta_bwd_dkv_kernel(const GtaBwdParams p) {
+__global__ __launch_bounds__(256, 2) void gta_bwd_dkv_kernel(const GtaBwdParams p) {
     using S = DkvSmem<DHP>;
     constexpr int CHP = S::CHP, KS = DHP / 16, DB = DHP / 32, BK = 128;
     constexpr int DMA_PER_WAVE = S::STAGE / 1024 / 4;
@@ -598,6 +600,7 @@ __global__ __launch_bounds__(256, 1) void gta_bwd_dkv_kernel(const GtaBwdParams 
             }
         }
     }
+    __syncthreads();      // every wave holds its K'/V' fragments: ring stages 1..2 are free
     if (n_qt > 1) dma_linear4<S::STAGE>(ring + S::STAGE, qimg + (long)S::STAGE, wave, lane);
 
     f32x16_t dk[DB], dv[DB];

@@ -287,3 +287,43 @@ def multihead_geometric_transform_attention(q, k, v, attn_fn=None, f_dims=None, 
                         trans_coeff=trans_coeff, tau=tau, scale=scale, v_transform=v_transform, euclid=euclid,
                         use_dma=kwargs.get("use_dma", True), kv_mode=kwargs.get("kv_mode", "auto"))
     return out, None
+
+
+def multihead_vecrep_attention(q, k, v, attn_fn=None, extras=None, **kwargs):
+    """Drop-in for gta.py:282-298 (the ``elementwise_mul`` ablation): elementwise per-token vectors
+    around plain softmax attention.  The products are torch elementwise ops, the attention is the
+    fused kernel on an identity layout; everything is differentiable.  Returns ``(out, None)``."""
+    scale = getattr(attn_fn, "scale", None)
+    dh = q.shape[-1]
+    qq = extras["vecrep_q"][:, None].to(q.dtype) * q
+    kk = extras["vecrep_k"][:, None].to(q.dtype) * k
+    vv = extras["vecrep_k"][:, None].to(q.dtype) * v
+    out = gta_attention(qq, kk, vv, {"triv": dh}, {}, scale=scale, tau=kwargs.get("tau"), v_transform=False)
+    return extras["vecinvrep_q"][:, None].to(q.dtype) * out, None
+
+
+def attention_map(q, k, f_dims, packed, *, so3_degree=0, trans_coeff=None, tau=None, scale=None, euclid=False):
+    """Dense softmax matrix [B,H,Tq,Tk] (what the reference returns as ``attn``, layers.py:207-211,441-442).
+    Materialising it is the point of the request, so after the HIP rho-apply kernels the matrix itself is
+    one batched GEMM + softmax in PyTorch-ROCm.  No gradient."""
+    with torch.no_grad():
+        if scale is None:
+            scale = q.shape[-1] ** -0.5
+        dt = q.dtype
+        B, H, Tq, dh = q.shape
+        Tk = k.shape[2]
+        Nq, Nk = _views(f_dims, packed, q, k)
+        flags = native.FLAG_V_TRANSFORM | (native.FLAG_EUCLID if euclid else 0)
+        qp = torch.empty(B, H, Tq, dh, device=q.device, dtype=dt)
+        kp = torch.empty(B, H, Tk, dh, device=q.device, dtype=dt)
+        desc = native.make_desc(q, k.to(dt), k.to(dt), qp, f_dims, so3_degree, Nq, Nk, scale, flags)
+        tc = trans_coeff.detach().float().reshape(-1) if torch.is_tensor(trans_coeff) else (
+            torch.tensor([float(trans_coeff)], device=q.device) if trans_coeff is not None else None)
+        kb = torch.zeros(B, H, (Tk + 63) // 64 * 64, device=q.device) if euclid else None
+        native.rep_apply(desc, 0, q, packed.get("vrep_q"), packed.get("cs_q"), packed.get("coord_q"), tc, qp)
+        native.rep_apply(desc, 1, k.to(dt), packed.get("vrep_k"), packed.get("cs_k"), packed.get("coord_k"), tc, kp, kb, scale)
+        sim = torch.matmul(qp.float(), kp.float().transpose(-1, -2)) * scale
+        if euclid:
+            sim = sim + kb[..., None, :Tk]
+        t = float(tau.item()) if torch.is_tensor(tau) else (tau or 1.0)
+        return torch.softmax(sim / t, dim=-1)

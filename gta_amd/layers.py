@@ -89,16 +89,15 @@ class Attention(nn.Module):
         self.method_args = attn_args["method"]["args"]
         if self.method != "gta":
             raise NotImplementedError(f"attention method {self.method!r}: only 'gta' is built (see DESIGN.md)")
-        if self.method_args.get("elementwise_mul", False):
-            raise NotImplementedError("elementwise_mul (vecrep) ablation is not built")
+        self.elementwise_mul = self.method_args.get("elementwise_mul", False)
         if self.method_args.get("rpe", False):
             raise NotImplementedError("rpe baseline is not built")
         use_bias = self.method_args.get("use_bias", False)
         self.f_dims = dict(self.method_args["f_dims"])
         if sum(self.f_dims.values()) != dim_head:
             raise ValueError(f"f_dims {self.f_dims} must sum to dim_head={dim_head}")
-        if self.f_dims.get("se3", 0) > 0:
-            self.trans_coeff = nn.Parameter(torch.tensor([0.01]))        # layers.py:191
+        if self.f_dims.get("se3", 0) > 0 and not self.elementwise_mul:
+            self.trans_coeff = nn.Parameter(torch.tensor([0.01]))        # layers.py:188-193
         else:
             self.trans_coeff = None
         if attn_args.get("softmax") == "adjustable":
@@ -111,14 +110,15 @@ class Attention(nn.Module):
             self.to_kv = linear_module(kv_dim, 2 * inner_dim, bias=use_bias)
         else:
             self.to_qkv = linear_module(dim, 3 * inner_dim, bias=use_bias)
+        if self.elementwise_mul:                                          # layers.py:265-270
+            freqs = self.f_dims.get("so2", 0) // 4
+            self.rep_to_vec = nn.Linear(16 + 2 * freqs * 2 * 2, inner_dim // heads)
         self.to_out = nn.Sequential(linear_module(inner_dim, dim), nn.Dropout(dropout)) if project_out \
             else nn.Identity()
 
     def forward(self, x, z=None, return_attmap=False, extras=None):
         if extras is None:
             raise ValueError("GTA attention needs `extras` (the reps dict)")
-        if return_attmap:
-            raise NotImplementedError("return_attmap needs the dense attention matrix; not built yet")
         B, Tq, _ = x.shape
         H, dh = self.heads, self.dim_head
         if z is None:
@@ -128,6 +128,17 @@ class Attention(nn.Module):
             q = self.to_q(x).view(B, Tq, H, dh).permute(0, 2, 1, 3)      # layers.py:391-392
             kv = self.to_kv(z).view(B, z.shape[1], 2, H, dh)
             k, v = (kv[:, :, i].permute(0, 2, 1, 3) for i in range(2))
+        tau = self.attend.tau if self.attend is not None else None
+        if self.elementwise_mul:                                          # layers.py:410-419
+            ex = dict(vecrep_q=self.rep_to_vec(extras["flattened_rep_q"]), vecrep_k=self.rep_to_vec(extras["flattened_rep_k"]),
+                      vecinvrep_q=self.rep_to_vec(extras["flattened_invrep_q"]))
+            out, _ = _gta.multihead_vecrep_attention(q, k, v, attn_fn=self, extras=ex, tau=tau)
+            out = out.permute(0, 2, 1, 3).reshape(B, Tq, H * dh)
+            out = self.to_out(out)
+            if return_attmap:
+                return out, _gta.attention_map(ex["vecrep_q"][:, None] * q, ex["vecrep_k"][:, None] * k, {"triv": dh}, {},
+                                               tau=tau, scale=self.scale)
+            return out
         packed = _gta.pack_reps(extras, self.f_dims)
         out = _gta.gta_attention(
             q, k, v, self.f_dims, packed,
@@ -135,7 +146,12 @@ class Attention(nn.Module):
             trans_coeff=self.trans_coeff, tau=self.attend.tau if self.attend is not None else None,
             scale=self.scale, v_transform=self.method_args.get("v_transform", True), euclid=self.euclid)
         out = out.permute(0, 2, 1, 3).reshape(B, Tq, H * dh)              # free: out is [B,Tq,H,dh] in memory
-        return self.to_out(out)
+        out = self.to_out(out)
+        if return_attmap:                                                  # layers.py:441-442
+            attn = _gta.attention_map(q, k, self.f_dims, packed, so3_degree=_gta._so3_degree(self.f_dims, packed, extras),
+                                      trans_coeff=self.trans_coeff, tau=tau, scale=self.scale, euclid=self.euclid)
+            return out, attn
+        return out
 
 
 class Transformer(nn.Module):

@@ -39,6 +39,23 @@ def _check(attn_kwargs):
     return f
 
 
+def _flattened(vrep, cs, T):
+    """``flattened_rep`` / ``flattened_invrep`` of the elementwise_mul ablation (encoder.py:200-243):
+    per token [ so2 blocks (c,-s,s,c) | E^T (16) ] and [ (c,s,-s,c) | E (16) ]."""
+    import torch
+    parts, iparts = [], []
+    if cs is not None:
+        c, s = cs[..., 0], cs[..., 1]
+        parts.append(torch.stack([c, -s, s, c], -1).flatten(-2, -1))
+        iparts.append(torch.stack([c, s, -s, c], -1).flatten(-2, -1))
+    if vrep is not None:
+        B, N = vrep.shape[:2]
+        E = vrep[..., native.VREP_INV:native.VREP_INV + 16].reshape(B, N, 4, 4).repeat_interleave(T // N, 1)
+        parts.append(E.transpose(-1, -2).reshape(B, T, 16))
+        iparts.append(E.reshape(B, T, 16))
+    return torch.cat(parts, -1), torch.cat(iparts, -1)
+
+
 def pre_compute_reps_encoder(attn_kwargs: dict, extras: dict) -> dict:
     """encoder.py:183-265: reps of the input views, q-side == k-side."""
     f = _check(attn_kwargs)
@@ -48,6 +65,11 @@ def pre_compute_reps_encoder(attn_kwargs: dict, extras: dict) -> dict:
         L = attn_kwargs.get("so3", 0) if f.get("so3", 0) > 0 else 0
         extras["gta_vrep_q"] = extras["gta_vrep_k"] = native.build_view_reps(extras["input_transforms"], L)
         extras["gta_so3_degree"] = L
+    if attn_kwargs.get("elementwise_mul", False):
+        T = extras["input_coord"].reshape(extras["input_coord"].shape[0], -1, 2).shape[1]
+        fr, fi = _flattened(extras.get("gta_vrep_q") if f.get("se3", 0) > 0 else None, extras.get("gta_cs_q"), T)
+        extras["flattened_rep_q"] = extras["flattened_rep_k"] = fr
+        extras["flattened_invrep_q"] = fi
     return extras
 
 
@@ -64,4 +86,8 @@ def pre_compute_reps_decoder(attn_kwargs: dict, extras: dict) -> dict:
         if "gta_vrep_k" not in extras:
             extras["gta_vrep_k"] = native.build_view_reps(extras["input_transforms"], L)
         extras["gta_so3_degree"] = L
+    if attn_kwargs.get("elementwise_mul", False):
+        T = extras["target_coord"].reshape(extras["target_coord"].shape[0], -1, 2).shape[1]
+        fr, fi = _flattened(extras.get("gta_vrep_q") if f.get("se3", 0) > 0 else None, extras.get("gta_cs_q"), T)
+        extras["flattened_rep_q"], extras["flattened_invrep_q"] = fr, fi     # *_k stays the encoder's
     return extras

@@ -53,3 +53,53 @@ def test_generic_path_is_forward_only():
     with pytest.raises(native.GtaError):
         gta_amd.multihead_geometric_transform_attention(q, k, v, attn_fn=SimpleNamespace(scale=float(d["scale"])),
                                                         f_dims=meta["f_dims"], reps=ex, trans_coeff=None)
+
+
+@pytest.mark.parametrize("case", ["cl_cross", "ms_self", "euclid", "t2"])
+def test_attention_map_matches_reference(case):
+    """return_attmap: the dense matrix against the fixture's `attn` (the reference's own softmax matrix)."""
+    d, meta = G.load("op_" + case)
+    ex = G.extras_of(d, torch.float32, "cuda")
+    q, k = (torch.from_numpy(d[n]).float().cuda() for n in "qk")
+    packed = gta_amd.pack_reps(ex, meta["f_dims"])
+    L = len(ex["so3rep_q"]) if "so3rep_q" in ex else 0
+    attn = gta_amd.attention_map(q, k, meta["f_dims"], packed, so3_degree=L,
+                                 trans_coeff=float(d["trans_coeff"]) if meta["f_dims"].get("se3", 0) > 0 else None,
+                                 scale=float(d["scale"]), euclid=meta["euclid"])
+    ref = torch.from_numpy(d["attn"]).float()
+    assert (attn.cpu() - ref).abs().max() < 2e-5
+    assert (attn.sum(-1).cpu() - 1).abs().max() < 1e-5
+
+
+def test_vecrep_attention_forward_backward():
+    """elementwise_mul ablation (gta.py:282-298) vs the oracle, gradients included."""
+    from oracle import gta_oracle as O
+    g = torch.Generator().manual_seed(3)
+    B, H, Tq, Tk, dh = 2, 3, 70, 90, 32
+    q, k, v = (torch.randn(B, H, T, dh, generator=g) for T in (Tq, Tk, Tk))
+    vq, vk, vi = torch.randn(B, Tq, dh, generator=g), torch.randn(B, Tk, dh, generator=g), torch.randn(B, Tq, dh, generator=g)
+    w = torch.randn(B, H, Tq, dh, generator=g)
+    qo, ko, vo = (t.clone().requires_grad_() for t in (q, k, v))
+    ref, _ = O.vecrep_attention(qo, ko, vo, vq, vk, vi, dh ** -0.5)
+    (ref * w).sum().backward()
+    qd, kd, vd = (t.cuda().requires_grad_() for t in (q, k, v))
+    out, _ = gta_amd.multihead_vecrep_attention(qd, kd, vd, attn_fn=SimpleNamespace(scale=dh ** -0.5),
+                                                extras=dict(vecrep_q=vq.cuda(), vecrep_k=vk.cuda(), vecinvrep_q=vi.cuda()))
+    (out * w.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    for name, a, b in (("out", out.detach(), ref.detach()), ("dq", qd.grad, qo.grad), ("dk", kd.grad, ko.grad), ("dv", vd.grad, vo.grad)):
+        st = C.err_stats(a.cpu(), b)
+        assert st["finite"] and st["rel_rms"] < 2e-2, (name, st)
+
+
+def test_elementwise_mul_module_runs_and_trains():
+    ak = {"f_dims": {"se3": 16, "so2": 16}, "so2": 4, "so3": 0, "max_freq_h": 1, "max_freq_w": 1, "elementwise_mul": True}
+    att = gta_amd.Attention(48, heads=2, dim_head=32, attn_args={"method": {"name": "gta", "args": ak}}).cuda()
+    assert att.trans_coeff is None and att.rep_to_vec.in_features == 16 + 2 * 4 * 2 * 2
+    q, k, v, ex, _, _ = C.synth_inputs(2, 2, 2, 20, 2, 20, {"se3": 16, "so2": 16}, 4, 0, torch.float32, seed=1)
+    exd = {kk: vv.cuda() for kk, vv in ex.items()}
+    gta_amd.pre_compute_reps_encoder(ak, exd)
+    x = torch.randn(2, 40, 48, device="cuda", requires_grad=True)
+    y, attn = att(x, extras=exd, return_attmap=True)
+    y.sum().backward()
+    assert torch.isfinite(y).all() and torch.isfinite(x.grad).all() and attn.shape == (2, 2, 40, 40)
