@@ -50,6 +50,13 @@ GTA_DEV u32x2_t lds_tr16_b64(uint32_t addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(IMM));
     return v;
 }
+// same read into the accumulator file (MFMA A operands may live there; keeps the arch VGPRs for the softmax)
+template <int IMM>
+GTA_DEV u32x2_t lds_tr16_b64_acc(uint32_t addr) {
+    u32x2_t v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=a"(v) : "v"(addr), "i"(IMM));
+    return v;
+}
 GTA_DEV uint32_t lds_addr(const void* p) {
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
 }
@@ -270,11 +277,17 @@ __global__ __launch_bounds__(256) void gta_kv_prep_kernel(const GtaFwdParams p) 
 // ================================================================================================
 // 2. lean flash kernel
 // ================================================================================================
+// 4 waves per workgroup; every wave owns RB blocks of 32 query rows and re-uses each K'/V' fragment it
+// reads from LDS for all of them.  Measured (profiles/r01): with RB = 1 and eight waves per CU the kernel
+// is bound by LDS fragment reads (~35 cycles per ds_read_b128 under load, 8 x 24 KB per tile per CU --
+// as long as all the MFMAs of the tile).  RB = 2 halves the LDS bytes per MFMA and runs one wave per SIMD
+// with the whole 512-entry register file, so one block's softmax VALU can issue under the other's MFMAs.
 constexpr int NSTAGE = 3;
 
-template <int DHP, int NW>
+template <int DHP, int RB>
 struct Smem2 {
-    static constexpr int BM = 32 * NW;
+    static constexpr int NW = 4;
+    static constexpr int BM = 32 * NW * RB;             // 128 or 256 query rows per workgroup
     static constexpr int NT = 64 * NW;
     static constexpr int CHP = DHP / 8;
     static constexpr int IMG = BN * DHP * 2;            // one K' or V' tile image
@@ -286,6 +299,7 @@ struct Smem2 {
     static constexpr int OST_BYTES = OST_ROWS * OROW * 4;
     static_assert(QS_BYTES <= RING_BYTES - STAGE, "Q staging must fit ring stages 1..");
     static_assert(OST_BYTES <= RING_BYTES, "O staging must fit the ring");
+    static_assert(OST_ROWS == 128, "the epilogue item map assumes 128-row passes");
     // layout: [ring | q-side rep records (runtime size: Nq records)]
     static constexpr int OFF_RING = 0;
     static constexpr int OFF_QS = STAGE;
@@ -294,12 +308,12 @@ struct Smem2 {
 };
 
 // issue the LDS-DMA of one K'/V' tile image pair (STAGE bytes, linear) into ring stage `st`
-template <int DHP, int NW>
+template <int DHP, int RB>
 GTA_DEV void dma_stage(char* ring, int st, const char* img, int wave, int lane) {
-    using S = Smem2<DHP, NW>;
+    using S = Smem2<DHP, RB>;
     constexpr int PIECES = S::STAGE / 1024;             // 1 KiB per wave-instruction
-    constexpr int PER_WAVE = PIECES / NW;
-    static_assert(PIECES % NW == 0, "stage must split evenly over the waves");
+    constexpr int PER_WAVE = PIECES / 4;
+    static_assert(PIECES % 4 == 0, "stage must split evenly over the waves");
 #pragma unroll
     for (int i = 0; i < PER_WAVE; ++i) {
         const int piece = wave * PER_WAVE + i;
@@ -309,14 +323,88 @@ GTA_DEV void dma_stage(char* ring, int st, const char* img, int wave, int lane) 
     }
 }
 
-template <int DHP, int ESZ, int NW, int LAYOUT>
-__global__ __launch_bounds__(64 * NW, 2) void gta_fwd2_kernel(const GtaFwdParams p) {
-    using S = Smem2<DHP, NW>;
+// online softmax of one 32-row block's tile (S in log2 units), O rescale, P -> bf16 MFMA B fragments.
+// key of register r = kbase + (r&3) + 8(r>>2) (+32 for s1); keys >= Tk are masked when `tail`.
+template <int DHP>
+GTA_DEV void softmax_tile(f32x16_t& s0, f32x16_t& s1, float& m_run, float& l_run, f32x16_t (&oacc)[DHP / 32],
+                          bf16x8_t (&pf)[2][2], bool tail, int kbase, int Tk) {
+    if (tail) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kbase + (r & 3) + 8 * (r >> 2);
+            if (key >= Tk) s0[r] = -1e30f;
+            if (key + 32 >= Tk) s1[r] = -1e30f;
+        }
+    }
+    float mx = s0[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s0[r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s1[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_new); rs += s0[r]; }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s1[r] = __builtin_amdgcn_exp2f(s1[r] - m_new); rs += s1[r]; }
+    l_run = l_run * alpha + rs;
+#pragma unroll
+    for (int d = 0; d < DHP / 32; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
+    u32x4_t ww;
+    ww.x = pack_bf16x2(s0[0], s0[1]); ww.y = pack_bf16x2(s0[2], s0[3]);
+    ww.z = pack_bf16x2(s0[4], s0[5]); ww.w = pack_bf16x2(s0[6], s0[7]);
+    pf[0][0] = __builtin_bit_cast(bf16x8_t, ww);
+    ww.x = pack_bf16x2(s0[8], s0[9]); ww.y = pack_bf16x2(s0[10], s0[11]);
+    ww.z = pack_bf16x2(s0[12], s0[13]); ww.w = pack_bf16x2(s0[14], s0[15]);
+    pf[0][1] = __builtin_bit_cast(bf16x8_t, ww);
+    ww.x = pack_bf16x2(s1[0], s1[1]); ww.y = pack_bf16x2(s1[2], s1[3]);
+    ww.z = pack_bf16x2(s1[4], s1[5]); ww.w = pack_bf16x2(s1[6], s1[7]);
+    pf[1][0] = __builtin_bit_cast(bf16x8_t, ww);
+    ww.x = pack_bf16x2(s1[8], s1[9]); ww.y = pack_bf16x2(s1[10], s1[11]);
+    ww.z = pack_bf16x2(s1[12], s1[13]); ww.w = pack_bf16x2(s1[14], s1[15]);
+    pf[1][1] = __builtin_bit_cast(bf16x8_t, ww);
+}
+
+// transpose-reads of one 16-key slab of V' for all DB channel blocks (2*DB reads)
+template <int DHP, int SLAB>
+GTA_DEV void pv_reads_slab(uint32_t vbase, const int (&voff)[DHP / 32][2], u32x2_t (&vlo)[DHP / 32], u32x2_t (&vhi)[DHP / 32]) {
+    constexpr int OFF = SLAB * 16 * (DHP / 8) * 16;
+#pragma unroll
+    for (int d = 0; d < DHP / 32; ++d) {
+        vlo[d] = lds_tr16_b64<OFF>(vbase + voff[d][0]);
+        vhi[d] = lds_tr16_b64<OFF>(vbase + voff[d][1]);
+    }
+}
+// SLAB-major PV for RB row blocks: one slab's fragments multiply into RB*DB independent accumulators
+// (a chain on one accumulator would run at the dependent latency instead of the issue rate)
+template <int DHP, int RB>
+GTA_DEV void pv_mfma_slab(const u32x2_t (&vlo)[DHP / 32], const u32x2_t (&vhi)[DHP / 32], const bf16x8_t (&pf)[RB][2][2],
+                          int kb, int t, f32x16_t (&oacc)[RB][DHP / 32]) {
+#pragma unroll
+    for (int d = 0; d < DHP / 32; ++d) {
+        const u32x4_t av = {vlo[d].x, vlo[d].y, vhi[d].x, vhi[d].y};
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+            oacc[rb][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av), pf[rb][kb][t], oacc[rb][d], 0, 0, 0);
+    }
+}
+
+template <int DHP, int ESZ, int RB, int LAYOUT>
+__global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const GtaFwdParams p) {
+    using S = Smem2<DHP, RB>;
     // chunk descriptor: a compile-time constant for the shipped layouts (c is constant per unrolled item)
 #define GTA_DESC(c) (LAYOUT == GTA_LAYOUT_GENERIC ? p.ctab[c] : gta_layout_desc(LAYOUT, c))
-    constexpr int CHP = S::CHP, KS = DHP / 16, DB = DHP / 32, BM = S::BM, NT = S::NT;
+    constexpr int NW = 4, CHP = S::CHP, KS = DHP / 16, DB = DHP / 32, BM = S::BM, NT = S::NT;
     constexpr int DMA_PER_WAVE = S::STAGE / 1024 / NW;
-    constexpr int QITEMS = (BM / 64) * CHP / NW;         // (row group, chunk) items per wave = CHP/2
+    constexpr int RG = BM / 64;                      // 64-row groups of the Q tile (lane == row staging)
+    constexpr int NPAR = NW / RG;                    // chunk parities: 2 (RB = 1) or 1 (RB = 2)
+    constexpr int QITEMS = CHP / NPAR;               // (row group, chunk) items per wave in the prologue
+    static_assert(NPAR * RG == NW && QITEMS * NPAR == CHP, "prologue item map");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -349,39 +437,32 @@ __global__ __launch_bounds__(64 * NW, 2) void gta_fwd2_kernel(const GtaFwdParams
 #define GTA_STAMP(k) do { } while (0)
 #endif
     GTA_STAMP(0);
-    dma_stage<DHP, NW>(ring, 0, kvimg, wave, lane);                   // tile 0 on its way
+    dma_stage<DHP, RB>(ring, 0, kvimg, wave, lane);                   // tile 0 on its way
 
-    // ---- issue every prologue global load up front (one latency exposure, not one per item) ----
+    // ---- prologue: every global load is issued up front (one latency exposure, not one per item).
+    // item map: wave -> (row group rg = wave % RG, chunk parity par = wave / RG); item it -> chunk
+    // NPAR*it + par: a constant in each of the NPAR straight-line code paths.
     constexpr int RAWN = ESZ == 2 ? 1 : 2;
     u32x4_t qraw[QITEMS][RAWN];
     f32x2_t qcs[QITEMS][4];
-    int qt_row[QITEMS];
-    // item map: wave -> (row group rg = wave % RG, chunk parity par = wave / RG); item it -> chunk 2*it+par.
-    // par takes two values: each gets its own straight-line code path in which c is a constant.
-    constexpr int RG = BM / 64;
-    static_assert(NW == 2 * RG && QITEMS * 2 == CHP, "item map assumes two chunk parities");
     const int rg = wave % RG, par = wave / RG;
     const int my_r = lane + 64 * rg;
-    {
-        int t = q0 + my_r;
-        t = t < p.Tq ? t : p.Tq - 1;
-#pragma unroll
-        for (int it = 0; it < QITEMS; ++it) qt_row[it] = t;
-    }
+    int my_t = q0 + my_r;
+    my_t = my_t < p.Tq ? my_t : p.Tq - 1;
     auto load_items = [&](auto PARC) {
         constexpr int PAR = decltype(PARC)::value;
 #pragma unroll
         for (int it = 0; it < QITEMS; ++it) {
-            const int c = 2 * it + PAR;
+            const int c = NPAR * it + PAR;
             if (c < ch_real && !GTA_DBG(32u)) {
-                const char* rp = qg + (long)qt_row[it] * q_rs + c * 8 * ESZ;
+                const char* rp = qg + (long)my_t * q_rs + c * 8 * ESZ;
 #pragma unroll
                 for (int k2 = 0; k2 < RAWN; ++k2) qraw[it][k2] = *reinterpret_cast<const u32x4_t*>(rp + 16 * k2);
-                if (p.cs_q) load_cs(GTA_DESC(c), p.cs_q + ((long)b * p.Tq + qt_row[it]) * 2 * p.nso2, qcs[it]);
+                if (p.cs_q) load_cs(GTA_DESC(c), p.cs_q + ((long)b * p.Tq + my_t) * 2 * p.nso2, qcs[it]);
             }
         }
     };
-    if (par) load_items(std::integral_constant<int, 1>{}); else load_items(std::integral_constant<int, 0>{});
+    if (NPAR == 2 && par) load_items(std::integral_constant<int, 1>{}); else load_items(std::integral_constant<int, 0>{});
     // views touched by this query tile: records are staged relative to n_first
     const int t_last = (q0 + BM - 1 < p.Tq ? q0 + BM - 1 : p.Tq - 1);
     const int n_first = q0 / p.Pq;
@@ -398,7 +479,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gta_fwd2_kernel(const GtaFwdParams
         const int r = my_r;
 #pragma unroll
         for (int it = 0; it < QITEMS; ++it) {
-            const int c = 2 * it + PAR;
+            const int c = NPAR * it + PAR;
             float x[1][8];
             if (c < ch_real) {
                 const uint32_t desc = GTA_DESC(c);
@@ -412,7 +493,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gta_fwd2_kernel(const GtaFwdParams
                     }
                 }
                 if (desc) {
-                    const int n = view_of(qt_row[it], p.Pq, p.invPq) - n_first;
+                    const int n = view_of(my_t, p.Pq, p.invPq) - n_first;
                     const float* rec = qrec + n * GTA_QREC;
                     chunk_apply<false, 1>(desc, rec + GTA_QREC_A, rec + GTA_QREC_D1, rec + GTA_QREC_D2, qcs[it], x);
                 }
@@ -425,26 +506,33 @@ __global__ __launch_bounds__(64 * NW, 2) void gta_fwd2_kernel(const GtaFwdParams
             *reinterpret_cast<u32x4_t*>(qs + (r * CHP + swz<CHP>(r, c)) * 16) = pack8(x[0]);
         }
     };
-    if (par) xform_items(std::integral_constant<int, 1>{}); else xform_items(std::integral_constant<int, 0>{});
+    if (NPAR == 2 && par) xform_items(std::integral_constant<int, 1>{}); else xform_items(std::integral_constant<int, 0>{});
     __syncthreads();      // (also drains tile 0's DMA: harmless)
-    bf16x8_t qf[KS];
+    bf16x8_t qf[RB][KS];
     {
         const char* qs = smem + S::OFF_QS;
-        const int r = wave * 32 + l31;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            qf[ks] = *reinterpret_cast<const bf16x8_t*>(qs + (r * CHP + swz<CHP>(r, 2 * ks + lh)) * 16);
+        for (int rb = 0; rb < RB; ++rb) {
+            const int r = wave * (32 * RB) + 32 * rb + l31;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                qf[rb][ks] = *reinterpret_cast<const bf16x8_t*>(qs + (r * CHP + swz<CHP>(r, 2 * ks + lh)) * 16);
+        }
     }
     __syncthreads();      // Q staging (ring stages 1..2) is free again
-    if (n_tiles > 1) dma_stage<DHP, NW>(ring, 1, kvimg + (long)S::STAGE, wave, lane);
+    if (n_tiles > 1) dma_stage<DHP, RB>(ring, 1, kvimg + (long)S::STAGE, wave, lane);
     GTA_STAMP(2);
 
-    f32x16_t oacc[DB];
+    f32x16_t oacc[RB][DB];
+    float m_run[RB], l_run[RB];
 #pragma unroll
-    for (int d = 0; d < DB; ++d)
+    for (int rb = 0; rb < RB; ++rb) {
+        m_run[rb] = -1e30f; l_run[rb] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[rb][d][i] = 0.f;
+    }
 
     // lane-constant LDS offsets.  The rotation swizzle has period 16 rows, so a fragment of rows
     // r + 16m sits at the same in-row position: per-slab offsets are compile-time immediates.
@@ -462,26 +550,21 @@ __global__ __launch_bounds__(64 * NW, 2) void gta_fwd2_kernel(const GtaFwdParams
             voff[d][hf] = (r * CHP + swz<CHP>(r, u)) * 16 + (p16 & 1) * 8;
         }
     }
+    const bool has_tail = (p.Tk & (BN - 1)) != 0;
 
     for (int j = 0; j < n_tiles; ++j) {
         // tile j has landed (only tile j+1's pieces may still be in flight), everyone is past tile j-1
-        const bool dbg_nodma = GTA_DBG(1u);
-        if (!dbg_nodma) {
-            if (j + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
-            else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        if (!GTA_DBG(2u)) __builtin_amdgcn_s_barrier();
-        if (!dbg_nodma && j + 2 < n_tiles)
-            dma_stage<DHP, NW>(ring, (j + 2) % NSTAGE, kvimg + (long)(j + 2) * S::STAGE, wave, lane);
+        if (j + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
+        else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (j + 2 < n_tiles) dma_stage<DHP, RB>(ring, (j + 2) % NSTAGE, kvimg + (long)(j + 2) * S::STAGE, wave, lane);
 
-        const char* kf = ring + (dbg_nodma ? 0 : (j % NSTAGE)) * S::STAGE;
+        const char* kf = ring + (j % NSTAGE) * S::STAGE;
         const char* vf = kf + S::IMG;
 
-        // ---- S^T = K' Q'^T : every fragment read is issued before the first MFMA ----
-        f32x16_t s0, s1;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
-        if (!GTA_DBG(16u)) {
+        // ---- S^T = K' Q'^T for the RB row blocks: each K' fragment is read once and used RB times ----
+        f32x16_t s[RB][2];
+        {
             bf16x8_t ka[KS], kb2[KS];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -490,191 +573,741 @@ __global__ __launch_bounds__(64 * NW, 2) void gta_fwd2_kernel(const GtaFwdParams
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], qf[ks], s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2[ks], qf[ks], s1, 0, 0, 0);
+            for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { s[rb][0][i] = 0.f; s[rb][1][i] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    s[rb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], qf[rb][ks], s[rb][0], 0, 0, 0);
+                    s[rb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2[ks], qf[rb][ks], s[rb][1], 0, 0, 0);
+                }
             }
         }
-        // V' block 0 transpose-reads fly under the softmax
+        // V' slab 0 transpose-reads fly under the softmax
         const uint32_t vbase = lds_addr(vf);
-        constexpr int SL = 16 * CHP * 16;                     // bytes between 16-key slabs
-        u32x2_t vlo[DB][4], vhi[DB][4];
-        const bool dbg_nopv = GTA_DBG(8u);
-        if (!dbg_nopv) {
-            const uint32_t a0 = vbase + voff[0][0], a1 = vbase + voff[0][1];
-            vlo[0][0] = lds_tr16_b64<0>(a0);      vhi[0][0] = lds_tr16_b64<0>(a1);
-            vlo[0][1] = lds_tr16_b64<SL>(a0);     vhi[0][1] = lds_tr16_b64<SL>(a1);
-            vlo[0][2] = lds_tr16_b64<2 * SL>(a0); vhi[0][2] = lds_tr16_b64<2 * SL>(a1);
-            vlo[0][3] = lds_tr16_b64<3 * SL>(a0); vhi[0][3] = lds_tr16_b64<3 * SL>(a1);
-        }
-        if (j == n_tiles - 1 && (p.Tk & (BN - 1))) {
-            const int kbase = j * BN + 4 * lh;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kbase + (r & 3) + 8 * (r >> 2);
-                if (key >= p.Tk) s0[r] = -1e30f;
-                if (key + 32 >= p.Tk) s1[r] = -1e30f;
-            }
-        }
+        u32x2_t v0l[DB], v0h[DB], v1l[DB], v1h[DB], v2l[DB], v2h[DB], v3l[DB], v3h[DB];
+        pv_reads_slab<DHP, 0>(vbase, voff, v0l, v0h);
 
-        // ---- online softmax ----
-        if (GTA_DBG(4u)) {     // ablation: no max / exp / rescale
+        // ---- online softmax per row block (the scheduler may run block 0's VALU under block 1's MFMAs) ----
+        bf16x8_t pf[RB][2][2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s0[r] *= 1e-3f; s1[r] *= 1e-3f; }
-            l_run += s0[0];
-        } else {
-        float mx = s0[0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s0[r]);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s1[r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        float rs = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_new); rs += s0[r]; }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s1[r] = __builtin_amdgcn_exp2f(s1[r] - m_new); rs += s1[r]; }
-        l_run = l_run * alpha + rs;
-#pragma unroll
-        for (int d = 0; d < DB; ++d)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
-        }
+        for (int rb = 0; rb < RB; ++rb)
+            softmax_tile<DHP>(s[rb][0], s[rb][1], m_run[rb], l_run[rb], oacc[rb], pf[rb], has_tail && j == n_tiles - 1,
+                              j * BN + 4 * lh, p.Tk);
 
-        bf16x8_t pf[2][2];
-        {
-            u32x4_t ww;
-            ww.x = pack_bf16x2(s0[0], s0[1]); ww.y = pack_bf16x2(s0[2], s0[3]);
-            ww.z = pack_bf16x2(s0[4], s0[5]); ww.w = pack_bf16x2(s0[6], s0[7]);
-            pf[0][0] = __builtin_bit_cast(bf16x8_t, ww);
-            ww.x = pack_bf16x2(s0[8], s0[9]); ww.y = pack_bf16x2(s0[10], s0[11]);
-            ww.z = pack_bf16x2(s0[12], s0[13]); ww.w = pack_bf16x2(s0[14], s0[15]);
-            pf[0][1] = __builtin_bit_cast(bf16x8_t, ww);
-            ww.x = pack_bf16x2(s1[0], s1[1]); ww.y = pack_bf16x2(s1[2], s1[3]);
-            ww.z = pack_bf16x2(s1[4], s1[5]); ww.w = pack_bf16x2(s1[6], s1[7]);
-            pf[1][0] = __builtin_bit_cast(bf16x8_t, ww);
-            ww.x = pack_bf16x2(s1[8], s1[9]); ww.y = pack_bf16x2(s1[10], s1[11]);
-            ww.z = pack_bf16x2(s1[12], s1[13]); ww.w = pack_bf16x2(s1[14], s1[15]);
-            pf[1][1] = __builtin_bit_cast(bf16x8_t, ww);
-        }
-
-        // ---- O^T += V'^T P^T ; A = V'^T via transpose-read of the row-major V' image ----
-        // 16-lane group g reads [4 keys][16 channels]: lane p supplies key row (p>>2), channels
-        // 4*(p&3)..+3; it receives channel (p) x 4 keys.  k-slot e of slab (kb,t) in half h is key
-        // 32kb + 16t + 8(e>>2) + 4h + (e&3): two reads (e>>2 = 0, 1).
-        if (!dbg_nopv)
-#pragma unroll
-        for (int d = 0; d < DB; ++d) {
-            if (d + 1 < DB) {                                  // next block's reads before this block's MFMAs
-                const uint32_t a0 = vbase + voff[d + 1][0], a1 = vbase + voff[d + 1][1];
-                vlo[d + 1][0] = lds_tr16_b64<0>(a0);      vhi[d + 1][0] = lds_tr16_b64<0>(a1);
-                vlo[d + 1][1] = lds_tr16_b64<SL>(a0);     vhi[d + 1][1] = lds_tr16_b64<SL>(a1);
-                vlo[d + 1][2] = lds_tr16_b64<2 * SL>(a0); vhi[d + 1][2] = lds_tr16_b64<2 * SL>(a1);
-                vlo[d + 1][3] = lds_tr16_b64<3 * SL>(a0); vhi[d + 1][3] = lds_tr16_b64<3 * SL>(a1);
-                asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // LDS returns in order: block d landed
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int sl = 0; sl < 4; ++sl) {                  // slab sl = 2*kb + t
-                const u32x4_t av = {vlo[d][sl].x, vlo[d][sl].y, vhi[d][sl].x, vhi[d][sl].y};
-                oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av), pf[sl >> 1][sl & 1],
-                                                                  oacc[d], 0, 0, 0);
-            }
-        }
+        // ---- O^T += V'^T P^T, slab-major; reads stay one slab ahead (LDS returns in order) ----
+        pv_reads_slab<DHP, 1>(vbase, voff, v1l, v1h);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * DB) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        pv_mfma_slab<DHP, RB>(v0l, v0h, pf, 0, 0, oacc);
+        pv_reads_slab<DHP, 2>(vbase, voff, v2l, v2h);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * DB) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        pv_mfma_slab<DHP, RB>(v1l, v1h, pf, 0, 1, oacc);
+        pv_reads_slab<DHP, 3>(vbase, voff, v3l, v3h);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * DB) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        pv_mfma_slab<DHP, RB>(v2l, v2h, pf, 1, 0, oacc);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        pv_mfma_slab<DHP, RB>(v3l, v3h, pf, 1, 1, oacc);
     }
 
     GTA_STAMP(3);
     if (GTA_DBG(256u)) {                                                // ablation: no epilogue at all
-        if (oacc[0][0] == 123.f) p.lse[0] = l_run;
+        if (oacc[0][0][0] == 123.f) p.lse[0] = l_run[0];
         return;
     }
-    // ---- epilogue through the O staging tile (all rows at once when it fits the ring) ----
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv_l = 1.0f / l_tot;
-    if (p.lse && lh == 0) {
-        const int t = q0 + wave * 32 + l31;
-        if (t < p.Tq) p.lse[((long)b * p.H + h) * p.Tq + t] = (m_run + __log2f(l_tot)) * LN2;
+    // ---- epilogue through the O staging tile, 128 rows per pass ----
+    float inv_l[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const float l_tot = l_run[rb] + __shfl_xor(l_run[rb], 32);
+        inv_l[rb] = 1.0f / l_tot;
+        if (p.lse && lh == 0) {
+            const int t = q0 + wave * (32 * RB) + 32 * rb + l31;
+            if (t < p.Tq) p.lse[((long)b * p.H + h) * p.Tq + t] = (m_run[rb] + __log2f(l_tot)) * LN2;
+        }
     }
     float* ost = reinterpret_cast<float*>(smem + S::OFF_RING);
     const bool xo = (p.flags & GTA_FLAG_V_TRANSFORM) != 0;
-    constexpr int NPASS = BM / S::OST_ROWS;
+    constexpr int NPASS = BM / S::OST_ROWS;                          // RB
     constexpr int WPP = NW / NPASS;                                  // waves whose rows go in one pass
-    constexpr int EITEMS = (S::OST_ROWS / 64) * CHP / NW;
-    static_assert((S::OST_ROWS / 64) * CHP % NW == 0, "epilogue items must split evenly");
+    constexpr int EITEMS = CHP / 2;                                  // epilogue map: 2 row groups x 2 parities
+    constexpr bool SAMEMAP = (RB == 1);                              // == the prologue map: reuse its (cos,sin)
+    const int rgE = wave & 1, parE = wave >> 1;
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; ++pass) {
-        // per-token (cos,sin): the prologue's registers when the item map is the same (one pass),
-        // otherwise prefetched here before the barriers
-        constexpr bool SAMEMAP = (NPASS == 1);
-        static_assert(!SAMEMAP || EITEMS == QITEMS, "epilogue must reuse the prologue item map");
+        const int rE = lane + 64 * rgE;
+        const int tE = q0 + pass * S::OST_ROWS + rE;
         f32x2_t ocs[EITEMS][4];
-        if (!SAMEMAP && xo && p.cs_q) {
+        if (!SAMEMAP && xo && p.cs_q && tE < p.Tq) {                  // prefetched before the barriers
+            auto load_ocs = [&](auto PARC) {
+                constexpr int PAR = decltype(PARC)::value;
 #pragma unroll
-            for (int it = 0; it < EITEMS; ++it) {
-                const int item = wave + NW * it;
-                const int c = item / (S::OST_ROWS / 64);
-                const int t = q0 + pass * S::OST_ROWS + lane + 64 * (item % (S::OST_ROWS / 64));
-                if (c < ch_real && t < p.Tq) load_cs(p.ctab[c], p.cs_q + ((long)b * p.Tq + t) * 2 * p.nso2, ocs[it]);
-            }
+                for (int it = 0; it < EITEMS; ++it) {
+                    const int c = 2 * it + PAR;
+                    if (c < ch_real) load_cs(GTA_DESC(c), p.cs_q + ((long)b * p.Tq + tE) * 2 * p.nso2, ocs[it]);
+                }
+            };
+            if (parE) load_ocs(std::integral_constant<int, 1>{}); else load_ocs(std::integral_constant<int, 0>{});
         }
         __syncthreads();
         if (wave / WPP == pass) {
-            const int r = (wave % WPP) * 32 + l31;
 #pragma unroll
-            for (int d = 0; d < DB; ++d)
+            for (int rb = 0; rb < RB; ++rb) {
+                const int r = (wave % WPP) * (32 * RB) + 32 * rb + l31;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4_t v = {oacc[d][4 * g] * inv_l, oacc[d][4 * g + 1] * inv_l,
-                                       oacc[d][4 * g + 2] * inv_l, oacc[d][4 * g + 3] * inv_l};
-                    *reinterpret_cast<f32x4_t*>(ost + r * S::OROW + 32 * d + 8 * g + 4 * lh) = v;
-                }
+                for (int d = 0; d < DB; ++d)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4_t v = {oacc[rb][d][4 * g] * inv_l[rb], oacc[rb][d][4 * g + 1] * inv_l[rb],
+                                           oacc[rb][d][4 * g + 2] * inv_l[rb], oacc[rb][d][4 * g + 3] * inv_l[rb]};
+                        *reinterpret_cast<f32x4_t*>(ost + r * S::OROW + 32 * d + 8 * g + 4 * lh) = v;
+                    }
+            }
         }
         __syncthreads();
         // rho_q^-1 on one (row, chunk) item and the store
-        auto out_item = [&](const uint32_t desc, const int c, const int r, const int t, const f32x2_t* cs) {
+        auto out_item = [&](const uint32_t desc, const int c, const f32x2_t* cs) {
             float x[1][8];
-            const f32x4_t a = *reinterpret_cast<const f32x4_t*>(ost + r * S::OROW + 8 * c);
-            const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(ost + r * S::OROW + 8 * c + 4);
+            const f32x4_t a = *reinterpret_cast<const f32x4_t*>(ost + rE * S::OROW + 8 * c);
+            const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(ost + rE * S::OROW + 8 * c + 4);
             x[0][0] = a.x; x[0][1] = a.y; x[0][2] = a.z; x[0][3] = a.w;
             x[0][4] = bb.x; x[0][5] = bb.y; x[0][6] = bb.z; x[0][7] = bb.w;
             if (xo && desc) {
-                const int n = view_of(t, p.Pq, p.invPq) - n_first;
+                const int n = view_of(tE, p.Pq, p.invPq) - n_first;
                 const float* rec = qrec + n * GTA_QREC;
                 chunk_apply<true, 1>(desc, rec + GTA_QREC_O, rec + GTA_QREC_D1T, rec + GTA_QREC_D2T, cs, x);
             }
-            if (!GTA_DBG(64u) || x[0][0] == 123.f) gstore_chunk2<ESZ>(og + (long)t * o_rs, c, x[0]);
+            if (!GTA_DBG(64u) || x[0][0] == 123.f) gstore_chunk2<ESZ>(og + (long)tE * o_rs, c, x[0]);
         };
-        if constexpr (SAMEMAP) {
-            // same item map as the prologue: c = 2*it + par is a constant in each code path, and the
-            // per-token (cos,sin) registers loaded there are reused
-            auto out_items = [&](auto PARC) {
-                constexpr int PAR = decltype(PARC)::value;
-                const int t = q0 + my_r;
-#pragma unroll
-                for (int it = 0; it < QITEMS; ++it) {
-                    const int c = 2 * it + PAR;
-                    if (c < ch_real && t < p.Tq) out_item(GTA_DESC(c), c, my_r, t, qcs[it]);
-                }
-            };
-            if (par) out_items(std::integral_constant<int, 1>{}); else out_items(std::integral_constant<int, 0>{});
-        } else {
+        auto out_items = [&](auto PARC) {
+            constexpr int PAR = decltype(PARC)::value;
 #pragma unroll
             for (int it = 0; it < EITEMS; ++it) {
-                const int item = wave + NW * it;
-                const int c = item / (S::OST_ROWS / 64);
-                const int r = lane + 64 * (item % (S::OST_ROWS / 64));
-                const int t = q0 + pass * S::OST_ROWS + r;
-                if (c < ch_real && t < p.Tq) out_item(p.ctab[c], c, r, t, ocs[it]);
+                const int c = 2 * it + PAR;
+                if (c < ch_real && tE < p.Tq) {
+                    if constexpr (SAMEMAP) out_item(GTA_DESC(c), c, qcs[it]);
+                    else out_item(GTA_DESC(c), c, ocs[it]);
+                }
             }
-        }
+        };
+        if (parE) out_items(std::integral_constant<int, 1>{}); else out_items(std::integral_constant<int, 0>{});
     }
     GTA_STAMP(4);
 #undef GTA_STAMP
+}
+
+// ================================================================================================
+// 3. software-pipelined flash kernel
+// ================================================================================================
+// Same tiles and images as section 2, but the tile loop is skewed so that every MFMA burst has VALU /
+// LDS work of a DIFFERENT tile to issue in its shadow (measured on gfx950, tests/probes/probe_issue.hip:
+// one 32x32x16 MFMA = 32 cycles of matrix pipe during which the wave can issue ~28 cycles of other
+// instructions for free: v_mul 5, v_max3 / v_cvt_pk 5, v_exp 9 cycles each; the un-skewed loop above runs
+// MFMA and softmax back to back and a second wave on the SIMD does not hide it):
+//
+//   step i:   R3  S'(i+1) = K'(i+1) Q'^T - m      ||  exp / sum / pack the late half of P(i), V'(i) tr-reads
+//             R1  O += V'(i) P(i)   (slabs 0,1)   ||  row max of S'(i+1), V'(i) tr-reads of slabs 2,3
+//             --  deferred-max decision for tile i+1 (wave-uniform, rare slow path)
+//             R2  O += V'(i) P(i)   (slabs 2,3)   ||  exp / sum of the early half of P(i+1), K'(i+2) fragment reads
+//
+// Deferred max (THR = 8 in log2 units): the running max m only moves when a row's tile max exceeds it by
+// more than THR, so P <= 2^8 and the O rescale is off the common path.  -m rides in as the C operand of
+// each row block's first MFMA (a 16-register splat), so S' needs no subtract.  When the slow path fires
+// for tile i+1, O still has P(i) V'(i) MFMAs in flight at the OLD scale: its rescale is applied after R2.
+//
+// LDS: K' ring of 3 images (K'(i+2) is read while K'(i+3) lands), V' ring of 2: [K0 | K1 | K2 | V1 | V0].
+// One barrier per tile; the DMA of V'(i+1) and K'(i+3) is issued right after it.
+constexpr float DEFER_THR = 8.0f;
+
+// ---- accumulator-file primitives (literal AGPR numbers; see the register map in the kernel) ----
+template <int A0>
+GTA_DEV void acc_zero() { asm volatile("v_accvgpr_write_b32 a[%c0], 0" ::"i"(A0)); }
+template <int A0>
+GTA_DEV void acc_scale(float f) {
+    float t;
+    asm volatile("v_accvgpr_read_b32 %0, a[%c2]\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a[%c2], %0" : "=&v"(t) : "v"(f), "i"(A0));
+}
+template <int A0>
+GTA_DEV f32x4_t acc_read4() {
+    f32x4_t v;
+    asm volatile("v_accvgpr_read_b32 %0, a[%c4]\n\tv_accvgpr_read_b32 %1, a[%c5]\n\tv_accvgpr_read_b32 %2, a[%c6]\n\tv_accvgpr_read_b32 %3, a[%c7]"
+                 : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w) : "i"(A0), "i"(A0 + 1), "i"(A0 + 2), "i"(A0 + 3));
+    return v;
+}
+template <int A0, int OFF>
+GTA_DEV void lds_b128_to_acc(uint32_t addr) {
+    asm volatile("ds_read_b128 a[%c1:%c2], %0 offset:%c3" ::"v"(addr), "i"(A0), "i"(A0 + 3), "i"(OFF) : "memory");
+}
+template <int A0, int OFF>
+GTA_DEV void lds_tr_to_acc(uint32_t addr) {
+    asm volatile("ds_read_b64_tr_b16 a[%c1:%c2], %0 offset:%c3" ::"v"(addr), "i"(A0), "i"(A0 + 1), "i"(OFF) : "memory");
+}
+// S'(first k step) = K' Q'^T + C ;  S' += K' Q'^T ;  O^T += V'^T P^T
+template <int K0, int Q0>
+GTA_DEV void mfma_qk_first(f32x16_t& d, const f32x16_t& c) {
+    // (s_nop: hipcc may materialise or copy the C operand right in front of the statement; a VALU write
+    //  needs two wait states before an MFMA reads it, and nothing inside an asm string is padded)
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, a[%c2:%c3], a[%c4:%c5], %1" : "=&v"(d) : "v"(c), "i"(K0), "i"(K0 + 3), "i"(Q0), "i"(Q0 + 3));
+}
+template <int K0, int Q0>
+GTA_DEV void mfma_qk(f32x16_t& d) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0" : "+v"(d) : "i"(K0), "i"(K0 + 3), "i"(Q0), "i"(Q0 + 3));
+}
+template <int O0, int V0>
+GTA_DEV void mfma_pv(const u32x4_t& pb) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 a[%c1:%c2], a[%c3:%c4], %0, a[%c1:%c2]" ::"v"(pb), "i"(O0), "i"(O0 + 15), "i"(V0), "i"(V0 + 3));
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{})
+template <class F, int... Is>
+GTA_DEV void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+GTA_DEV void static_for(F&& f) { static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
+
+template <int DHP, int RB>
+struct Smem3 {
+    static constexpr int NW = 4;
+    static constexpr int BM = 32 * NW * RB;
+    static constexpr int NT = 64 * NW;
+    static constexpr int CHP = DHP / 8;
+    static constexpr int IMG = BN * DHP * 2;
+    static constexpr int RING_BYTES = 5 * IMG;
+    static constexpr int QS_BYTES = BM * DHP * 2;
+    // RB == 1 (two workgroups per CU): Q' staging aliases K2|V1 (exactly 2 images); RB == 2: own region
+    static constexpr int OFF_QS = RB == 1 ? 2 * IMG : RING_BYTES;
+    static constexpr int TOP = RB == 1 ? RING_BYTES : RING_BYTES + QS_BYTES;
+    static constexpr int OROW = DHP + 4;
+    static constexpr int OST_ROWS = 128;
+    static constexpr int OST_BYTES = OST_ROWS * OROW * 4;
+    static_assert(RB == 1 ? QS_BYTES == 2 * IMG : true, "Q staging alias");
+    static_assert(OST_BYTES <= TOP, "O staging must fit");
+    static constexpr int OFF_QREC = TOP;
+    GTA_DEV static constexpr int off_k(int s) { return s * IMG; }
+    GTA_DEV static constexpr int off_v(int s) { return (4 - s) * IMG; }
+    static int total(int Nq) { return TOP + Nq * GTA_QREC * 4; }
+};
+
+// LDS-DMA of one tile image (IMG bytes, linear)
+template <int DHP>
+GTA_DEV void dma_image(char* dst, const char* img, int wave, int lane) {
+    constexpr int PER_WAVE = BN * DHP * 2 / 1024 / 4;
+    static_assert(PER_WAVE >= 1, "image must split over the waves");
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int piece = wave * PER_WAVE + i;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(img + piece * 1024 + lane * 16),
+            (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+    }
+}
+
+// exp2 + row-sum of one 16-value unit (in place: S' -> P)
+GTA_DEV void exp_unit(f32x16_t& s, float& l0, float& l1) {
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        s[r] = __builtin_amdgcn_exp2f(s[r]);
+        s[r + 1] = __builtin_amdgcn_exp2f(s[r + 1]);
+        l0 += s[r];
+        l1 += s[r + 1];
+    }
+}
+GTA_DEV void pack_unit(const f32x16_t& s, bf16x8_t (&pf)[2]) {
+    u32x4_t ww;
+    ww.x = pack_bf16x2(s[0], s[1]); ww.y = pack_bf16x2(s[2], s[3]);
+    ww.z = pack_bf16x2(s[4], s[5]); ww.w = pack_bf16x2(s[6], s[7]);
+    pf[0] = __builtin_bit_cast(bf16x8_t, ww);
+    ww.x = pack_bf16x2(s[8], s[9]); ww.y = pack_bf16x2(s[10], s[11]);
+    ww.z = pack_bf16x2(s[12], s[13]); ww.w = pack_bf16x2(s[14], s[15]);
+    pf[1] = __builtin_bit_cast(bf16x8_t, ww);
+}
+GTA_DEV float max_unit(const f32x16_t& s) {
+    float mx = fmaxf(s[0], s[1]);
+#pragma unroll
+    for (int r = 2; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
+    return mx;
+}
+
+template <int DHP, int ESZ, int RB, int LAYOUT>
+__global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd3_kernel(const GtaFwdParams p) {
+    using S = Smem3<DHP, RB>;
+#define GTA_DESC(c) (LAYOUT == GTA_LAYOUT_GENERIC ? p.ctab[c] : gta_layout_desc(LAYOUT, c))
+    constexpr int NW = 4, CHP = S::CHP, KS = DHP / 16, DB = DHP / 32, BM = S::BM, NT = S::NT, IMG = S::IMG;
+    constexpr int RG = BM / 64, NPAR = NW / RG, QITEMS = CHP / NPAR;
+    static_assert(NPAR * RG == NW && QITEMS * NPAR == CHP, "prologue item map");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    int w;
+    {
+        const int nwg = gridDim.x, L = blockIdx.x;
+        const int xcd = L & 7, idx = L >> 3, q8 = nwg >> 3, r8 = nwg & 7;
+        w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int bh = w / p.n_qtiles, qt = w - bh * p.n_qtiles;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int q0 = qt * BM;
+    const int n_tiles = (p.Tk + BN - 1) / BN;
+    const int ch_real = p.dh >> 3;
+
+    const char* qg = (const char*)p.q + ((long)b * p.q_sb + (long)h * p.q_sh) * ESZ;
+    char* og = (char*)p.o + ((long)b * p.o_sb + (long)h * p.o_sh) * ESZ;
+    const long q_rs = p.q_st * ESZ, o_rs = p.o_st * ESZ;
+    const char* kvimg = (const char*)p.kp + ((long)b * p.H + h) * n_tiles * (long)(2 * IMG);
+    float* qrec = reinterpret_cast<float*>(smem + S::OFF_QREC);
+#define K_IMG(j) (kvimg + (long)(j) * (2 * IMG))
+#define V_IMG(j) (kvimg + (long)(j) * (2 * IMG) + IMG)
+
+    dma_image<DHP>(smem + S::off_k(0), K_IMG(0), wave, lane);
+    dma_image<DHP>(smem + S::off_v(0), V_IMG(0), wave, lane);
+    if (n_tiles > 1) dma_image<DHP>(smem + S::off_k(1), K_IMG(1), wave, lane);
+    if (RB == 2 && n_tiles > 2) dma_image<DHP>(smem + S::off_k(2), K_IMG(2), wave, lane);
+
+    // ---- prologue: Q tile -> rho -> prescale -> bf16 LDS tile -> MFMA B fragments (as in section 2) ----
+    constexpr int RAWN = ESZ == 2 ? 1 : 2;
+    u32x4_t qraw[QITEMS][RAWN];
+    f32x2_t qcs[QITEMS][4];
+    const int rg = wave % RG, par = wave / RG;
+    const int my_r = lane + 64 * rg;
+    int my_t = q0 + my_r;
+    my_t = my_t < p.Tq ? my_t : p.Tq - 1;
+    auto load_items = [&](auto PARC) {
+        constexpr int PAR = decltype(PARC)::value;
+#pragma unroll
+        for (int it = 0; it < QITEMS; ++it) {
+            const int c = NPAR * it + PAR;
+            if (c < ch_real) {
+                const char* rp = qg + (long)my_t * q_rs + c * 8 * ESZ;
+#pragma unroll
+                for (int k2 = 0; k2 < RAWN; ++k2) qraw[it][k2] = *reinterpret_cast<const u32x4_t*>(rp + 16 * k2);
+                if (p.cs_q) load_cs(GTA_DESC(c), p.cs_q + ((long)b * p.Tq + my_t) * 2 * p.nso2, qcs[it]);
+            }
+        }
+    };
+    if (NPAR == 2 && par) load_items(std::integral_constant<int, 1>{}); else load_items(std::integral_constant<int, 0>{});
+    const int t_last = (q0 + BM - 1 < p.Tq ? q0 + BM - 1 : p.Tq - 1);
+    const int n_first = q0 / p.Pq;
+    const int n_cnt = t_last / p.Pq - n_first + 1;
+    if (p.vrep_q) stage_qrec(qrec, p.vrep_q, b, p.Nq, n_first, n_cnt, p.trans_coeff ? *p.trans_coeff : 1.0f, tid, NT);
+    __syncthreads();
+
+    const float qscale = p.scale * LOG2E / (p.tau ? *p.tau : 1.0f);
+    auto xform_items = [&](auto PARC) {
+        constexpr int PAR = decltype(PARC)::value;
+        char* qs = smem + S::OFF_QS;
+        const int r = my_r;
+#pragma unroll
+        for (int it = 0; it < QITEMS; ++it) {
+            const int c = NPAR * it + PAR;
+            float x[1][8];
+            if (c < ch_real) {
+                const uint32_t desc = GTA_DESC(c);
+                if (ESZ == 2) {
+                    unpack8(qraw[it][0], x[0]);
+                } else {
+#pragma unroll
+                    for (int k2 = 0; k2 < RAWN; ++k2) {
+                        x[0][4 * k2 + 0] = __uint_as_float(qraw[it][k2].x); x[0][4 * k2 + 1] = __uint_as_float(qraw[it][k2].y);
+                        x[0][4 * k2 + 2] = __uint_as_float(qraw[it][k2].z); x[0][4 * k2 + 3] = __uint_as_float(qraw[it][k2].w);
+                    }
+                }
+                if (desc) {
+                    const int n = view_of(my_t, p.Pq, p.invPq) - n_first;
+                    const float* rec = qrec + n * GTA_QREC;
+                    chunk_apply<false, 1>(desc, rec + GTA_QREC_A, rec + GTA_QREC_D1, rec + GTA_QREC_D2, qcs[it], x);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[0][i] *= qscale;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[0][i] = 0.f;
+            }
+            *reinterpret_cast<u32x4_t*>(qs + (r * CHP + swz<CHP>(r, c)) * 16) = pack8(x[0]);
+        }
+    };
+    if (NPAR == 2 && par) xform_items(std::integral_constant<int, 1>{}); else xform_items(std::integral_constant<int, 0>{});
+    __syncthreads();
+    // lane-constant LDS offsets (see section 2)
+    int koff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) koff[ks] = (l31 * CHP + swz<CHP>(l31, 2 * ks + lh)) * 16;
+    const int g16 = lane >> 4, p16 = lane & 15;
+    int voff[DB][2];
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+        const int u = 4 * d + 2 * (g16 & 1) + ((p16 & 3) >> 1);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int r = 4 * lh + (p16 >> 2) + 8 * hf;
+            voff[d][hf] = (r * CHP + swz<CHP>(r, u)) * 16 + (p16 & 1) * 8;
+        }
+    }
+    const bool has_tail = (p.Tk & (BN - 1)) != 0;
+
+    // ---- pipeline state ----
+    // The accumulator file is owned by the asm below, by literal register number (hipcc never sees it; the
+    // build audits the .s for compiler v_accvgpr_* / spills, tests/test_host_logic.py):
+    //   O^T  a[A_O + 16*(rb*DB + d) ..+15]        Q' fragments a[A_Q + 4*(rb*KS + ks) ..+3]
+    //   K'   a[A_K + 4*(half*KS + ks) ..+3]       V' fragments a[A_V + 4*(slab*DB + d) ..+3]
+    // S'/P, the packed P and the -m splats stay in arch VGPRs where the VALU reaches them.  (With builtin MFMAs
+    // hipcc picks one accumulator form per kernel and pays a v_accvgpr copy per S' element or per fragment.)
+    constexpr int A_O = 0, A_Q = A_O + 16 * RB * DB, A_K = A_Q + 4 * RB * KS, A_V = A_K + 8 * KS, A_END = A_V + 16 * DB;
+    static_assert(A_END <= 256, "accumulator file budget");
+    f32x16_t sA[RB][2], sB[RB][2];        // S' / P of two consecutive tiles (roles swap every step)
+    f32x16_t msplat[RB];                  // -m_run in every element: the C operand of a row block's first MFMA
+    float m_run[RB], l0[RB], l1[RB], alpha_pend[RB];
+    bool pend = false;
+    u32x4_t pf[RB][2][2];                 // P as bf16 MFMA B fragments: [row block][key half][slab in half]
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        m_run[rb] = 0.f; l0[rb] = 0.f; l1[rb] = 0.f; alpha_pend[rb] = 1.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) msplat[rb][i] = 0.f;
+    }
+    asm volatile("" ::: "a0", "a255");    // (makes the kernel descriptor allocate the whole accumulator file)
+    static_for<16 * RB * DB>([&](auto NC) { acc_zero<A_O + decltype(NC)::value>(); });
+    {   // Q' fragments: LDS -> accumulator file
+        const uint32_t qs = lds_addr(smem + S::OFF_QS);
+        static_for<RB * KS>([&](auto NC) {
+            constexpr int n = decltype(NC)::value, rb = n / KS, ks = n % KS;
+            const int r = wave * (32 * RB) + 32 * rb + l31;
+            lds_b128_to_acc<A_Q + 4 * n, 0>(qs + (r * CHP + swz<CHP>(r, 2 * ks + lh)) * 16);
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (RB == 1) {
+        __syncthreads();      // Q staging (K2 | V1) is free again
+        if (n_tiles > 2) dma_image<DHP>(smem + S::off_k(2), K_IMG(2), wave, lane);
+    }
+
+    // MFMAs and fillers per region (see the header of this section)
+    constexpr int G3 = 2 * RB * KS;       // QK^T MFMAs per tile
+    constexpr int GS = DB * RB;           // PV MFMAs per slab
+    constexpr int G1 = 2 * GS, G2 = 2 * GS;
+    constexpr int NE = 32 * RB;           // P values per lane per tile; value e -> (rb = e>>5, half = (e>>4)&1, r = e&15)
+    constexpr int NE2 = ((2 * G2 < NE / 2 ? 2 * G2 : NE / 2)) & ~1;   // exponentiated in R2, the rest in R3
+    constexpr int NV = 4 * DB;            // V' transpose-reads per pair of slabs
+    constexpr int NKR = 2 * KS;           // K' fragment reads per tile
+    // R3 item list: NV reads (cost 5), NE2/2 packs of early values (5), then (NE-NE2)/2 groups of
+    // {exp, exp, add, add, pack} (33); items are dealt to the G3 gaps by cumulative issue cost
+    constexpr int R3_NC0 = NE2 / 2, R3_NQ = (NE - NE2) / 2, R3_N = NV + R3_NC0 + R3_NQ;
+    constexpr int R3_COST = 5 * (NV + R3_NC0) + 33 * R3_NQ;
+    auto r3_first = [](int g) constexpr {      // first item of gap g
+        int c = 0;
+        for (int n = 0; n < R3_N; ++n) {
+            int gg = (int)((long)c * G3 / R3_COST);
+            if (gg > G3 - 1) gg = G3 - 1;
+            if (gg >= g) return n;
+            c += n < NV + R3_NC0 ? 5 : 33;
+        }
+        return R3_N;
+    };
+    constexpr int GH = G1 / 3 > 3 ? G1 / 3 : 3; // R1: gaps [0, GH) carry the LDS reads, [GH, G1) the row max
+    static_assert(GH < G1, "R1 needs room for the row max");
+    constexpr int NM = 8 * RB;                 // row-max chunks of 4 values
+
+    auto expadd = [&](f32x16_t (&s)[RB][2], auto EC) {
+        constexpr int e = decltype(EC)::value, rb = e >> 5, hh = (e >> 4) & 1, r = e & 15;
+        const float pv = __builtin_amdgcn_exp2f(s[rb][hh][r]);
+        s[rb][hh][r] = pv;
+        if (e & 1) l1[rb] += pv; else l0[rb] += pv;
+    };
+    auto cvt_pair = [&](f32x16_t (&s)[RB][2], auto KC) {       // values 2k, 2k+1 -> one packed word
+        constexpr int e = 2 * decltype(KC)::value, rb = e >> 5, hh = (e >> 4) & 1, r = e & 15;
+        pf[rb][hh][r >> 3][(r & 7) >> 1] = pack_bf16x2(s[rb][hh][r], s[rb][hh][r + 1]);
+    };
+    auto k_read = [&](auto NC, uint32_t kbase) {               // item n: key half n&1, k step n>>1
+        constexpr int n = decltype(NC)::value, hh = n & 1, ks = n >> 1;
+        lds_b128_to_acc<A_K + 4 * (hh * KS + ks), hh * 32 * CHP * 16>(kbase + koff[ks]);
+    };
+    auto v_read = [&](auto NC, auto SLB, uint32_t vbase) {     // item n of slabs SLB, SLB+1
+        constexpr int n = decltype(NC)::value, sl = decltype(SLB)::value + n / (2 * DB), d = (n >> 1) % DB, hf = n & 1;
+        lds_tr_to_acc<A_V + 4 * (sl * DB + d) + 2 * hf, sl * 16 * CHP * 16>(vbase + voff[d][hf]);
+    };
+    auto qk_mfma = [&](f32x16_t (&s)[RB][2], auto GC) {        // MFMA g of S' = K' Q'^T - m_run (4 chains)
+        constexpr int g = decltype(GC)::value, ks = g / (2 * RB), rb = (g % (2 * RB)) >> 1, hh = g & 1;
+        if constexpr (ks == 0) mfma_qk_first<A_K + 4 * (hh * KS + ks), A_Q + 4 * (rb * KS + ks)>(s[rb][hh], msplat[rb]);
+        else mfma_qk<A_K + 4 * (hh * KS + ks), A_Q + 4 * (rb * KS + ks)>(s[rb][hh]);
+    };
+    auto pv_mfma = [&](auto SL, auto JC) {                      // MFMA j of slab SL: O^T += V'^T P^T
+        constexpr int sl = decltype(SL)::value, j = decltype(JC)::value, d = j / RB, rb = j % RB;
+        mfma_pv<A_O + 16 * (rb * DB + d), A_V + 4 * (sl * DB + d)>(pf[rb][sl >> 1][sl & 1]);
+    };
+    // every reader of an asm MFMA's S' result sits behind this (and behind enough issue time; see callers)
+    auto s_fence = [&](f32x16_t (&s)[RB][2]) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            asm volatile("" : "+v"(s[rb][0]));
+            asm volatile("" : "+v"(s[rb][1]));
+        }
+    };
+    auto mask_tail = [&](f32x16_t (&s)[RB][2], int j) {        // keys >= Tk of the last tile
+        const int kbase = j * BN + 4 * lh;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kbase + (r & 3) + 8 * (r >> 2);
+                if (key >= p.Tk) s[rb][0][r] = -1e30f;
+                if (key + 32 >= p.Tk) s[rb][1][r] = -1e30f;
+            }
+    };
+    float mxp[RB];                                              // row max under construction
+    auto max_chunk = [&](f32x16_t (&s)[RB][2], auto CC) {       // chunk c: 4 values of row block c / 8
+        constexpr int c = decltype(CC)::value, rb = c >> 3, hh = (c >> 2) & 1, r = 4 * (c & 3);
+        if ((c & 7) == 0) mxp[rb] = fmaxf(fmaxf(s[rb][hh][r], s[rb][hh][r + 1]), fmaxf(s[rb][hh][r + 2], s[rb][hh][r + 3]));
+        else mxp[rb] = fmaxf(fmaxf(fmaxf(mxp[rb], s[rb][hh][r]), s[rb][hh][r + 1]), fmaxf(s[rb][hh][r + 2], s[rb][hh][r + 3]));
+    };
+    // deferred-max decision for the tile whose S' (relative to the current m_run) is in s
+    auto decide = [&](f32x16_t (&s)[RB][2], bool first) {
+        float mx[RB];
+        bool grow = first;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            mx[rb] = fmaxf(mxp[rb], __shfl_xor(mxp[rb], 32));
+            grow = grow || (mx[rb] > DEFER_THR);
+        }
+        if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const float delta = first ? mx[rb] : fmaxf(mx[rb], 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                m_run[rb] += delta;
+                l0[rb] *= alpha; l1[rb] *= alpha;
+                alpha_pend[rb] *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { s[rb][0][i] -= delta; s[rb][1][i] -= delta; msplat[rb][i] = -m_run[rb]; }
+            }
+            pend = true;
+        }
+    };
+
+    // one pipeline step: tile i is finished, tile i+1 is started (unless LAST)
+    auto step = [&](f32x16_t (&sc)[RB][2], f32x16_t (&sn)[RB][2], int i, auto LASTC) {
+        constexpr bool LAST = decltype(LASTC)::value;
+        // V'(i), K'(i+2) have landed (this wave's share), everyone is past R3(i-1) / R1(i-1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (i + 1 < n_tiles) dma_image<DHP>(smem + S::off_v((i + 1) & 1), V_IMG(i + 1), wave, lane);
+        if (i + 3 < n_tiles) dma_image<DHP>(smem + S::off_k(i % 3), K_IMG(i + 3), wave, lane);
+        const uint32_t vbase = lds_addr(smem + S::off_v(i & 1));
+        const uint32_t kbase = lds_addr(smem + S::off_k((i + 2) % 3));
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- R3: S'(i+1) MFMAs || V'(i) reads of slabs 0,1; packs of the early P(i); exp/sum/pack of the rest ----
+        static_for<G3>([&](auto GC) {
+            constexpr int g = decltype(GC)::value;
+            if constexpr (!LAST) qk_mfma(sn, GC);
+            constexpr int n0 = r3_first(g), n1 = r3_first(g + 1);
+            static_for<n1 - n0>([&](auto DC) {
+                constexpr int n = n0 + decltype(DC)::value;
+                if constexpr (n < NV) {
+                    v_read(std::integral_constant<int, n>{}, std::integral_constant<int, 0>{}, vbase);
+                } else if constexpr (n < NV + R3_NC0) {
+                    cvt_pair(sc, std::integral_constant<int, n - NV>{});
+                } else {
+                    constexpr int e = NE2 + 2 * (n - NV - R3_NC0);
+                    expadd(sc, std::integral_constant<int, e>{});
+                    expadd(sc, std::integral_constant<int, e + 1>{});
+                    cvt_pair(sc, std::integral_constant<int, e / 2>{});
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- R1: PV slabs 0,1 || K'(i+2) fragment reads, V'(i) reads of slabs 2,3, then the row max of S'(i+1) ----
+        asm volatile("s_nop 1" ::: "memory");       // the last packs of R3 -> first MFMA reading them
+        static_for<G1>([&](auto GC) {
+            constexpr int g = decltype(GC)::value;
+            pv_mfma(std::integral_constant<int, g / GS>{}, std::integral_constant<int, g % GS>{});
+            if constexpr (g < GH) {
+                constexpr int a0 = g * NV / GH, a1 = (g + 1) * NV / GH;
+                static_for<a1 - a0>([&](auto DC) {
+                    v_read(std::integral_constant<int, a0 + decltype(DC)::value>{}, std::integral_constant<int, 2>{}, vbase);
+                });
+                if constexpr (!LAST) {
+                    constexpr int b0 = g * NKR / GH, b1 = (g + 1) * NKR / GH;
+                    static_for<b1 - b0>([&](auto DC) { k_read(std::integral_constant<int, b0 + decltype(DC)::value>{}, kbase); });
+                }
+            } else if constexpr (!LAST) {
+                // (>= GH PV MFMAs have issued since the last QK^T MFMA: its result has landed)
+                if constexpr (g == GH) s_fence(sn);
+                constexpr int c0 = (g - GH) * NM / (G1 - GH), c1 = (g - GH + 1) * NM / (G1 - GH);
+                static_for<c1 - c0>([&](auto DC) { max_chunk(sn, std::integral_constant<int, c0 + decltype(DC)::value>{}); });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (!LAST) {
+            if (has_tail && i + 2 == n_tiles) {       // rare: redo the row max with the tail keys masked
+                mask_tail(sn, i + 1);
+                static_for<NM>([&](auto CC) { max_chunk(sn, CC); });
+            }
+            decide(sn, false);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- R2: PV slabs 2,3 || exp / sum of the first NE2 values of P(i+1) ----
+        static_for<G2>([&](auto GC) {
+            constexpr int g = decltype(GC)::value;
+            pv_mfma(std::integral_constant<int, 2 + g / GS>{}, std::integral_constant<int, g % GS>{});
+            if constexpr (!LAST) {
+                constexpr int e0 = g * NE2 / G2, e1 = (g + 1) * NE2 / G2;
+                static_for<e1 - e0>([&](auto DC) { expadd(sn, std::integral_constant<int, e0 + decltype(DC)::value>{}); });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // a slow-path decision rescales O once the MFMAs at the old scale are in
+        if (pend) {
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const float a = alpha_pend[rb];
+                if (rb == 0) static_for<16 * DB>([&](auto NC) { acc_scale<A_O + decltype(NC)::value>(a); });
+                else         static_for<16 * DB>([&](auto NC) { acc_scale<A_O + 16 * DB * (RB - 1) + decltype(NC)::value>(a); });
+                alpha_pend[rb] = 1.f;
+            }
+            asm volatile("s_nop 3" ::: "memory");
+            pend = false;
+        }
+    };
+
+    // ---- tile 0 by hand: S'(0), K'(1) fragments, decision, first exps ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    static_for<NKR>([&](auto NC) { k_read(NC, lds_addr(smem + S::off_k(0))); });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<G3>([&](auto GC) { qk_mfma(sA, GC); });
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");      // last MFMA -> first reader / K' overwrite
+    if (n_tiles > 1) static_for<NKR>([&](auto NC) { k_read(NC, lds_addr(smem + S::off_k(1))); });
+    s_fence(sA);
+    if (has_tail && n_tiles == 1) mask_tail(sA, 0);
+    static_for<NM>([&](auto CC) { max_chunk(sA, CC); });
+    decide(sA, true);
+    pend = false;                                // O is still zero
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) alpha_pend[rb] = 1.f;
+    static_for<NE2>([&](auto EC) { expadd(sA, EC); });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+        int i = 0;
+        for (; i + 2 < n_tiles; i += 2) {
+            step(sA, sB, i, std::false_type{});
+            step(sB, sA, i + 1, std::false_type{});
+        }
+        if (i + 2 == n_tiles) {
+            step(sA, sB, i, std::false_type{});
+            step(sB, sA, i + 1, std::true_type{});
+        } else {
+            step(sA, sB, i, std::true_type{});
+        }
+    }
+
+    // ---- epilogue through the O staging tile, 128 rows per pass (as in section 2) ----
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");             // last asm MFMAs -> O readers
+    float inv_l[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const float lsum = l0[rb] + l1[rb];
+        const float l_tot = lsum + __shfl_xor(lsum, 32);
+        inv_l[rb] = 1.0f / l_tot;
+        if (p.lse && lh == 0) {
+            const int t = q0 + wave * (32 * RB) + 32 * rb + l31;
+            if (t < p.Tq) p.lse[((long)b * p.H + h) * p.Tq + t] = (m_run[rb] + __log2f(l_tot)) * LN2;
+        }
+    }
+    float* ost = reinterpret_cast<float*>(smem);
+    const bool xo = (p.flags & GTA_FLAG_V_TRANSFORM) != 0;
+    constexpr int NPASS = BM / S::OST_ROWS;
+    constexpr int WPP = NW / NPASS;
+    constexpr int EITEMS = CHP / 2;
+    constexpr bool SAMEMAP = (RB == 1);
+    const int rgE = wave & 1, parE = wave >> 1;
+#pragma unroll 1
+    for (int pass = 0; pass < NPASS; ++pass) {
+        const int rE = lane + 64 * rgE;
+        const int tE = q0 + pass * S::OST_ROWS + rE;
+        f32x2_t ocs[EITEMS][4];
+        if (!SAMEMAP && xo && p.cs_q && tE < p.Tq) {
+            auto load_ocs = [&](auto PARC) {
+                constexpr int PAR = decltype(PARC)::value;
+#pragma unroll
+                for (int it = 0; it < EITEMS; ++it) {
+                    const int c = 2 * it + PAR;
+                    if (c < ch_real) load_cs(GTA_DESC(c), p.cs_q + ((long)b * p.Tq + tE) * 2 * p.nso2, ocs[it]);
+                }
+            };
+            if (parE) load_ocs(std::integral_constant<int, 1>{}); else load_ocs(std::integral_constant<int, 0>{});
+        }
+        __syncthreads();
+        if (wave / WPP == pass) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int r = (wave % WPP) * (32 * RB) + 32 * rb + l31;
+                const float il = inv_l[rb];
+                auto put = [&](auto NC) {
+                    constexpr int n = decltype(NC)::value, d = n >> 2, g = n & 3;
+                    f32x4_t v;
+                    if (rb == 0) v = acc_read4<A_O + 16 * d + 4 * g>(); else v = acc_read4<A_O + 16 * DB * (RB - 1) + 16 * d + 4 * g>();
+                    v.x *= il; v.y *= il; v.z *= il; v.w *= il;
+                    *reinterpret_cast<f32x4_t*>(ost + r * S::OROW + 32 * d + 8 * g + 4 * lh) = v;
+                };
+                static_for<4 * DB>(put);
+            }
+        }
+        __syncthreads();
+        auto out_item = [&](const uint32_t desc, const int c, const f32x2_t* cs) {
+            float x[1][8];
+            const f32x4_t a = *reinterpret_cast<const f32x4_t*>(ost + rE * S::OROW + 8 * c);
+            const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(ost + rE * S::OROW + 8 * c + 4);
+            x[0][0] = a.x; x[0][1] = a.y; x[0][2] = a.z; x[0][3] = a.w;
+            x[0][4] = bb.x; x[0][5] = bb.y; x[0][6] = bb.z; x[0][7] = bb.w;
+            if (xo && desc) {
+                const int n = view_of(tE, p.Pq, p.invPq) - n_first;
+                const float* rec = qrec + n * GTA_QREC;
+                chunk_apply<true, 1>(desc, rec + GTA_QREC_O, rec + GTA_QREC_D1T, rec + GTA_QREC_D2T, cs, x);
+            }
+            gstore_chunk2<ESZ>(og + (long)tE * o_rs, c, x[0]);
+        };
+        auto out_items = [&](auto PARC) {
+            constexpr int PAR = decltype(PARC)::value;
+#pragma unroll
+            for (int it = 0; it < EITEMS; ++it) {
+                const int c = 2 * it + PAR;
+                if (c < ch_real && tE < p.Tq) {
+                    if constexpr (SAMEMAP) out_item(GTA_DESC(c), c, qcs[it]);
+                    else out_item(GTA_DESC(c), c, ocs[it]);
+                }
+            }
+        };
+        if (parE) out_items(std::integral_constant<int, 1>{}); else out_items(std::integral_constant<int, 0>{});
+    }
+#undef K_IMG
+#undef V_IMG
+}
+
+template <int DHP, int ESZ, int RB, int LAYOUT>
+int launch_fwd3(const GtaFwdParams& p, hipStream_t stream) {
+    using S = Smem3<DHP, RB>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gta_fwd3_kernel<DHP, ESZ, RB, LAYOUT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, S::total(GTA_MAX_VIEWS)) != hipSuccess)
+            return GTA_E_LAUNCH;
+        attr_set = true;
+    }
+    const long n_wg = (long)p.B * p.H * p.n_qtiles;
+    hipLaunchKernelGGL((gta_fwd3_kernel<DHP, ESZ, RB, LAYOUT>), dim3((unsigned)n_wg), dim3(256), S::total(p.vrep_q ? p.Nq : 0),
+                       stream, p);
+    return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH;
 }
 
 template <int DHP, int ESZ>
@@ -690,18 +1323,18 @@ int launch_prep(const GtaFwdParams& p, hipStream_t stream) {
     hipLaunchKernelGGL((gta_kv_prep_kernel<DHP, ESZ>), dim3(n_tiles, p.H, p.B), dim3(256), S::TOTAL, stream, p);
     return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH;
 }
-template <int DHP, int ESZ, int NW, int LAYOUT>
+template <int DHP, int ESZ, int RB, int LAYOUT>
 int launch_fwd2(const GtaFwdParams& p, hipStream_t stream) {
-    using S = Smem2<DHP, NW>;
+    using S = Smem2<DHP, RB>;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gta_fwd2_kernel<DHP, ESZ, NW, LAYOUT>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gta_fwd2_kernel<DHP, ESZ, RB, LAYOUT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, S::total(GTA_MAX_VIEWS)) != hipSuccess)
             return GTA_E_LAUNCH;
         attr_set = true;
     }
     const long n_wg = (long)p.B * p.H * p.n_qtiles;
-    hipLaunchKernelGGL((gta_fwd2_kernel<DHP, ESZ, NW, LAYOUT>), dim3((unsigned)n_wg), dim3(64 * NW), S::total(p.vrep_q ? p.Nq : 0),
+    hipLaunchKernelGGL((gta_fwd2_kernel<DHP, ESZ, RB, LAYOUT>), dim3((unsigned)n_wg), dim3(256), S::total(p.vrep_q ? p.Nq : 0),
                        stream, p);
     return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH;
 }
@@ -714,10 +1347,10 @@ long gta_fwd2_workspace_bytes(int B, int H, int Tk, int dhp) {
 }
 int gta_fwd2_lds_bytes(int dhp, int nq) {
     switch (dhp) {
-        case 32: return Smem2<32, 4>::total(nq);
-        case 64: return Smem2<64, 4>::total(nq);
-        case 96: return Smem2<96, 4>::total(nq);
-        case 128: return Smem2<128, 4>::total(nq);
+        case 32: return Smem2<32, 1>::total(nq);
+        case 64: return Smem2<64, 1>::total(nq);
+        case 96: return Smem2<96, 1>::total(nq);
+        case 128: return Smem2<128, 1>::total(nq);
     }
     return -1;
 }
@@ -737,24 +1370,43 @@ static int layout_of(const GtaFwdParams& p, int dhp) {
     return GTA_LAYOUT_GENERIC;
 }
 
-template <int DHP, int ESZ>
-static int launch_flash(const GtaFwdParams& p, int nw, hipStream_t stream) {
-    if (nw == 8) return launch_fwd2<DHP, ESZ, 8, GTA_LAYOUT_GENERIC>(p, stream);
+// rb = 32-row query blocks per wave: 1 (128-row workgroups, two per CU) or 2 (256-row workgroups, one
+// wave per SIMD).  Compile-time layouts exist for the shipped configs; others read the chunk table.
+template <int DHP, int ESZ, int RB>
+static int launch_flash_rb(const GtaFwdParams& p, hipStream_t stream) {
     switch (layout_of(p, DHP)) {
-        case GTA_LAYOUT_MS:  if (DHP == 96) return launch_fwd2<DHP, ESZ, 4, (DHP == 96 ? GTA_LAYOUT_MS : GTA_LAYOUT_GENERIC)>(p, stream); break;
-        case GTA_LAYOUT_CL:  if (DHP == 64) return launch_fwd2<DHP, ESZ, 4, (DHP == 64 ? GTA_LAYOUT_CL : GTA_LAYOUT_GENERIC)>(p, stream); break;
-        case GTA_LAYOUT_SO2: return launch_fwd2<DHP, ESZ, 4, GTA_LAYOUT_SO2>(p, stream);
+        case GTA_LAYOUT_MS:  if (DHP == 96) return launch_fwd2<DHP, ESZ, RB, (DHP == 96 ? GTA_LAYOUT_MS : GTA_LAYOUT_GENERIC)>(p, stream); break;
+        case GTA_LAYOUT_CL:  if (DHP == 64) return launch_fwd2<DHP, ESZ, RB, (DHP == 64 ? GTA_LAYOUT_CL : GTA_LAYOUT_GENERIC)>(p, stream); break;
+        case GTA_LAYOUT_SO2: return launch_fwd2<DHP, ESZ, RB, GTA_LAYOUT_SO2>(p, stream);
     }
-    return launch_fwd2<DHP, ESZ, 4, GTA_LAYOUT_GENERIC>(p, stream);
+    return launch_fwd2<DHP, ESZ, RB, GTA_LAYOUT_GENERIC>(p, stream);
+}
+template <int DHP, int ESZ, int RB>
+static int launch_pipe_rb(const GtaFwdParams& p, hipStream_t stream) {
+    switch (layout_of(p, DHP)) {
+        case GTA_LAYOUT_MS:  if (DHP == 96) return launch_fwd3<DHP, ESZ, RB, (DHP == 96 ? GTA_LAYOUT_MS : GTA_LAYOUT_GENERIC)>(p, stream); break;
+        case GTA_LAYOUT_CL:  if (DHP == 64) return launch_fwd3<DHP, ESZ, RB, (DHP == 64 ? GTA_LAYOUT_CL : GTA_LAYOUT_GENERIC)>(p, stream); break;
+        case GTA_LAYOUT_SO2: return launch_fwd3<DHP, ESZ, RB, GTA_LAYOUT_SO2>(p, stream);
+    }
+    return launch_fwd3<DHP, ESZ, RB, GTA_LAYOUT_GENERIC>(p, stream);
+}
+template <int DHP, int ESZ>
+static int launch_flash(const GtaFwdParams& p, int rb, hipStream_t stream) {
+    if (rb == 2) {
+        if constexpr (DHP == 64 || DHP == 96) return launch_pipe_rb<DHP, ESZ, 2>(p, stream);
+        else return launch_flash_rb<DHP, ESZ, 2>(p, stream);
+    }
+    return launch_flash_rb<DHP, ESZ, 1>(p, stream);
 }
 
 int gta_fwd2_dispatch(GtaFwdParams& p, int dhp, int esz, bool run_prep, bool run_flash, int nw, hipStream_t stream) {
-    p.n_qtiles = (p.Tq + 32 * nw - 1) / (32 * nw);
+    const int rb = nw == 8 ? 2 : 1;                    // GTA_FLAG_WG8 = 256-row workgroups
+    p.n_qtiles = (p.Tq + 128 * rb - 1) / (128 * rb);
     int rc = GTA_OK;
 #define GTA_CASE2(D)                                                                    \
     case D:                                                                             \
         if (run_prep) rc = (esz == 2) ? launch_prep<D, 2>(p, stream) : launch_prep<D, 4>(p, stream); \
-        if (rc == GTA_OK && run_flash) rc = (esz == 2) ? launch_flash<D, 2>(p, nw, stream) : launch_flash<D, 4>(p, nw, stream); \
+        if (rc == GTA_OK && run_flash) rc = (esz == 2) ? launch_flash<D, 2>(p, rb, stream) : launch_flash<D, 4>(p, rb, stream); \
         return rc;
     switch (dhp) {
         GTA_CASE2(32)

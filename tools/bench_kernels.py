@@ -135,7 +135,7 @@ if __name__ == "__main__":
             seg = Pall[nwg:].reshape(nwg, 2, 8)
             print(f"== {'8-wave' if nw8 else '4-wave'} attention kernel")
             if seg.abs().sum() > 0:
-                for i, nm in enumerate(["QK^T MFMAs", "softmax", "PV (+K reads issue)", "barrier", "vmcnt wait"]):
+                for i, nm in enumerate(["QK^T MFMAs", "softmax + V reads", "PV MFMAs", "barrier", "waits (vmcnt/lgkm)", "K/Q read issue | DMA issue"]):
                     print(f"   {nm:26s} {seg[:,0,i].mean():9.0f} | {seg[:,1,i].mean():9.0f}   per tile {seg[:,0,i].mean()/20:7.0f} | {seg[:,1,i].mean()/20:7.0f}")
             xcc = P[:, 5].long(); ww = P[:, 6].long()
             nq = 5 if nw8 else 10
