@@ -17,6 +17,7 @@
 int gta_fwd_lds_bytes(int dhp, int esz);
 int gta_fwd_dispatch(const GtaFwdParams& p, int dhp, int esz, bool dma, int n_wg, hipStream_t stream);
 long gta_fwd2_workspace_bytes(int B, int H, int Tk, int dhp);
+long gta_fwd2_image_bytes(int B, int H, int Tk, int dhp);
 int gta_fwd2_lds_bytes(int dhp, int nq);
 int gta_fwd2_dispatch(GtaFwdParams& p, int dhp, int esz, bool run_prep, bool run_flash, int nw, hipStream_t stream);
 int gta_bwd_dispatch(const GtaBwdParams& p, int dhp, int esz, hipStream_t stream);
@@ -181,6 +182,7 @@ extern "C" int gta_attn_fwd(const GtaAttnDesc* d, const void* q, const void* k, 
             return fail(GTA_E_BADARG, "workspace smaller than gta_attn_fwd_workspace_bytes()");
         if (d->H > 65535 || d->B > 65535) return fail(GTA_E_UNSUPPORTED, "B or H above 65535");
         p.kp = workspace;
+        p.kn = (float*)((char*)workspace + ((gta_fwd2_image_bytes(d->B, d->H, d->Tk, padded_dh(d->dh)) + 255) & ~255L));
         rc = gta_fwd2_dispatch(p, padded_dh(d->dh), esz, !(d->flags & GTA_FLAG_KV_READY), !(d->flags & GTA_FLAG_PREP_ONLY),
                                (d->flags & GTA_FLAG_WG8) ? 8 : 4, (hipStream_t)stream);
         if (rc) return fail(rc, rc == GTA_E_LAUNCH ? hipGetErrorString(hipGetLastError()) : "no kernel instance");

@@ -5,6 +5,7 @@
 struct GtaFwdParams {
     const void* q; const void* k; const void* v; void* o; float* lse;
     void* kp;                                   // K'/V' tile-image workspace (two-stage path)
+    float* kn;                                  // per key tile: max_k |k'_k| of the bf16 image rows, [B,H,n_tiles] (or null)
     const float* vrep_q; const float* vrep_k;   // [B,N,GTA_VREP_STRIDE]
     const float* cs_q; const float* cs_k;       // [B,T,nso2,2] (cos,sin)
     const float* trans_coeff; const float* tau; // device scalars or null

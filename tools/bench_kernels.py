@@ -108,6 +108,29 @@ if __name__ == "__main__":
                 t = time_call(fn)
                 print(f"  {'8-wave' if nw8 else '4-wave'} dbg={dbg:2d} {label:36s} {t*1e3:7.1f} us", flush=True)
             os.environ["GTA_DBG"] = "0"
+    if which == "pipe":          # region cycle sums of the pipelined kernel (needs a -DGTA_ABLATE build)
+        import ctypes
+        q, k, v, packed, L = setup(B, 8, 5, 256, 5, 256, MS, 6, 2, torch.bfloat16)
+        VT = native.FLAG_V_TRANSFORM
+        out = torch.empty(B, 1280, 8, 96, device="cuda", dtype=torch.bfloat16).permute(0, 2, 1, 3)
+        desc = native.make_desc(q, k, v, out, MS, L, 5, 5, 96 ** -0.5, VT)
+        ws = torch.empty(native.attn_fwd_workspace_bytes(desc), device="cuda", dtype=torch.uint8)
+        raw_call(q, k, v, packed, MS, L, VT, ws)[0]()
+        fn, _ = raw_call(q, k, v, packed, MS, L, VT | native.FLAG_KV_READY | native.FLAG_WG8, ws)
+        nwg = B * 8 * 5
+        for _ in range(3):
+            fn()
+        print(f"pipelined kernel: {time_call(fn)*1e3:.1f} us")
+        prof = torch.zeros(nwg, 16, dtype=torch.int64, device="cuda")
+        native.lib().gta_debug_set_profile_buffer(ctypes.c_void_p(prof.data_ptr()))
+        torch.cuda.synchronize(); fn(); torch.cuda.synchronize()
+        native.lib().gta_debug_set_profile_buffer(None)
+        P = prof.cpu().double()
+        print(f"  per WG cycles: prologue {(P[:,1]-P[:,0]).mean():8.0f}  tile0+loop {(P[:,2]-P[:,1]).mean():8.0f}  epilogue {(P[:,3]-P[:,2]).mean():8.0f}  total {(P[:,3]-P[:,0]).mean():8.0f}")
+        names = ["wait+barrier", "dma issue", "R3 (QK || exp,pack,V reads)", "R1 (PV || reads, max)", "decide", "R2 (PV || exp)", "rescale"]
+        for i2, nm in enumerate(names):
+            print(f"   {nm:30s} {P[:,8+i2].mean():9.0f} cycles / WG   {P[:,8+i2].mean()/20:7.0f} per tile")
+        print(f"   slow-path decisions per WG (of 19): mean {P[:,15].mean():.2f} max {P[:,15].max():.0f}")
     if which == "timeline":
         import ctypes
         q, k, v, packed, L = setup(B, 8, 5, 256, 5, 256, MS, 6, 2, torch.bfloat16)
