@@ -300,6 +300,8 @@ __global__ __launch_bounds__(256) void gta_kv_prep_kernel(const GtaFwdParams p) 
 // as long as all the MFMAs of the tile).  RB = 2 halves the LDS bytes per MFMA and runs one wave per SIMD
 // with the whole 512-entry register file, so one block's softmax VALU can issue under the other's MFMAs.
 constexpr int NSTAGE = 3;
+constexpr float DEFER_THR = 8.0f;      // (pipelined kernel) running max moves when a row's tile max exceeds it by this
+constexpr float BOUND_THR = 96.0f;     // exp2 arguments stay below this without looking at the scores
 
 template <int DHP, int RB>
 struct Smem2 {
@@ -321,7 +323,9 @@ struct Smem2 {
     static constexpr int OFF_RING = 0;
     static constexpr int OFF_QS = STAGE;
     static constexpr int OFF_QREC = RING_BYTES;
-    static int total(int Nq) { return RING_BYTES + Nq * GTA_QREC * 4; }
+    // [ring | q-side rep records | |q'|^2 partial sums: NPAR x BM floats]
+    __host__ __device__ static int off_qsq(int Nq) { return RING_BYTES + Nq * GTA_QREC * 4; }
+    static int total(int Nq) { return off_qsq(Nq) + 2 * BM * 4; }
 };
 
 // issue the LDS-DMA of one K'/V' tile image pair (STAGE bytes, linear) into ring stage `st`
@@ -372,6 +376,59 @@ GTA_DEV void softmax_tile(f32x16_t& s0, f32x16_t& s1, float& m_run, float& l_run
     for (int d = 0; d < DHP / 32; ++d)
 #pragma unroll
         for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
+    u32x4_t ww;
+    ww.x = pack_bf16x2(s0[0], s0[1]); ww.y = pack_bf16x2(s0[2], s0[3]);
+    ww.z = pack_bf16x2(s0[4], s0[5]); ww.w = pack_bf16x2(s0[6], s0[7]);
+    pf[0][0] = __builtin_bit_cast(bf16x8_t, ww);
+    ww.x = pack_bf16x2(s0[8], s0[9]); ww.y = pack_bf16x2(s0[10], s0[11]);
+    ww.z = pack_bf16x2(s0[12], s0[13]); ww.w = pack_bf16x2(s0[14], s0[15]);
+    pf[0][1] = __builtin_bit_cast(bf16x8_t, ww);
+    ww.x = pack_bf16x2(s1[0], s1[1]); ww.y = pack_bf16x2(s1[2], s1[3]);
+    ww.z = pack_bf16x2(s1[4], s1[5]); ww.w = pack_bf16x2(s1[6], s1[7]);
+    pf[1][0] = __builtin_bit_cast(bf16x8_t, ww);
+    ww.x = pack_bf16x2(s1[8], s1[9]); ww.y = pack_bf16x2(s1[10], s1[11]);
+    ww.z = pack_bf16x2(s1[12], s1[13]); ww.w = pack_bf16x2(s1[14], s1[15]);
+    pf[1][1] = __builtin_bit_cast(bf16x8_t, ww);
+}
+
+// Full path of the lazy softmax (tile 0, masked tail, violated bound): true row max of S' (= S - m_run), move
+// m_run there, rescale l and O, re-base S' and the -m splat.  key of register r = kbase + (r&3) + 8(r>>2) (+32).
+template <int DHP>
+GTA_DEV void softmax_rebase(f32x16_t& s0, f32x16_t& s1, float& m_run, float& l_run, f32x16_t (&oacc)[DHP / 32],
+                            f32x16_t& msplat, bool first, bool tail, int kbase, int Tk) {
+    if (tail) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kbase + (r & 3) + 8 * (r >> 2);
+            if (key >= Tk) s0[r] = -1e30f;
+            if (key + 32 >= Tk) s1[r] = -1e30f;
+        }
+    }
+    float mx = s0[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s0[r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s1[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float delta = first ? mx : fmaxf(mx, 0.f);
+    const float alpha = __builtin_amdgcn_exp2f(-delta);
+    m_run += delta;
+    l_run *= alpha;
+#pragma unroll
+    for (int d = 0; d < DHP / 32; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] -= delta; s1[r] -= delta; msplat[r] = -m_run; }
+}
+// P = exp2(S'), row sum, bf16 MFMA B fragments
+GTA_DEV void softmax_exp_pack(f32x16_t& s0, f32x16_t& s1, float& l_run, bf16x8_t (&pf)[2][2]) {
+    float rs0 = 0.f, rs1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] = __builtin_amdgcn_exp2f(s0[r]); rs0 += s0[r]; }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s1[r] = __builtin_amdgcn_exp2f(s1[r]); rs1 += s1[r]; }
+    l_run += rs0 + rs1;
     u32x4_t ww;
     ww.x = pack_bf16x2(s0[0], s0[1]); ww.y = pack_bf16x2(s0[2], s0[3]);
     ww.z = pack_bf16x2(s0[4], s0[5]); ww.w = pack_bf16x2(s0[6], s0[7]);
@@ -490,6 +547,8 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
     GTA_STAMP(1);
     // ---- Q: rho, prescale, bf16 -> LDS ----
     const float qscale = p.scale * LOG2E / (p.tau ? *p.tau : 1.0f);
+    float qsq = 0.f;                                   // this thread's share of |q'_row|^2 (bf16-rounded values)
+    float* qsq_l = reinterpret_cast<float*>(smem + S::off_qsq(p.vrep_q ? p.Nq : 0));
     auto xform_items = [&](auto PARC) {
         constexpr int PAR = decltype(PARC)::value;
         char* qs = smem + S::OFF_QS;
@@ -520,11 +579,24 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
 #pragma unroll
                 for (int i = 0; i < 8; ++i) x[0][i] = 0.f;
             }
-            *reinterpret_cast<u32x4_t*>(qs + (r * CHP + swz<CHP>(r, c)) * 16) = pack8(x[0]);
+            const u32x4_t qw = pack8(x[0]);
+            *reinterpret_cast<u32x4_t*>(qs + (r * CHP + swz<CHP>(r, c)) * 16) = qw;
+            float qr[8];
+            unpack8(qw, qr);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) qsq += qr[i] * qr[i];
         }
     };
     if (NPAR == 2 && par) xform_items(std::integral_constant<int, 1>{}); else xform_items(std::integral_constant<int, 0>{});
+    qsq_l[par * BM + my_r] = qsq;
     __syncthreads();      // (also drains tile 0's DMA: harmless)
+    // |q'| of this lane's MFMA rows: with the pre-pass's per-tile max |k'| it bounds every score of a tile
+    float qn[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int r = wave * (32 * RB) + 32 * rb + l31;
+        qn[rb] = sqrtf(qsq_l[r] + (NPAR == 2 ? qsq_l[BM + r] : 0.f)) * 1.0001f;
+    }
     bf16x8_t qf[RB][KS];
     {
         const char* qs = smem + S::OFF_QS;
@@ -542,9 +614,12 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
 
     f32x16_t oacc[RB][DB];
     float m_run[RB], l_run[RB];
+    f32x16_t msplat[RB];                  // -m_run in every element: C operand of each tile's first MFMA (S' = S - m)
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
-        m_run[rb] = -1e30f; l_run[rb] = 0.f;
+        m_run[rb] = 0.f; l_run[rb] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) msplat[rb][i] = 0.f;
 #pragma unroll
         for (int d = 0; d < DB; ++d)
 #pragma unroll
@@ -578,6 +653,11 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
 
         const char* kf = ring + (j % NSTAGE) * S::STAGE;
         const char* vf = kf + S::IMG;
+        uint32_t kn_bits;                 // max_k |k'_k| of tile j (scalar load by hand: see section 3)
+        {
+            const float* kn_ptr = p.kn + __builtin_amdgcn_readfirstlane((b * p.H + h) * n_tiles + j);
+            asm volatile("s_load_dword %0, %1, 0x0" : "=s"(kn_bits) : "s"(kn_ptr) : "memory");
+        }
 
         // ---- S^T = K' Q'^T for the RB row blocks: each K' fragment is read once and used RB times ----
         f32x16_t s[RB][2];
@@ -591,10 +671,10 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
+                s[rb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[0], qf[rb][0], msplat[rb], 0, 0, 0);
+                s[rb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2[0], qf[rb][0], msplat[rb], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { s[rb][0][i] = 0.f; s[rb][1][i] = 0.f; }
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
+                for (int ks = 1; ks < KS; ++ks) {
                     s[rb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], qf[rb][ks], s[rb][0], 0, 0, 0);
                     s[rb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2[ks], qf[rb][ks], s[rb][1], 0, 0, 0);
                 }
@@ -606,11 +686,26 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
         pv_reads_slab<DHP, 0>(vbase, voff, v0l, v0h);
 
         // ---- online softmax per row block (the scheduler may run block 0's VALU under block 1's MFMAs) ----
+        // Lazy online softmax: S' already has -m_run folded in.  |q'| max_k|k'| bounds the tile's scores, so
+        // while bound - m_run stays below BOUND_THR no exponent can overflow and neither the row max nor the
+        // O rescale is needed; tile 0, the masked tail tile and a violated bound take the full path.
         bf16x8_t pf[RB][2][2];
+        {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(kn_bits));     // (K' reads have long been consumed)
+            const float kn_j = __uint_as_float(kn_bits);
+            const bool tail = has_tail && j == n_tiles - 1;
+            bool need = (j == 0) || tail;
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-            softmax_tile<DHP>(s[rb][0], s[rb][1], m_run[rb], l_run[rb], oacc[rb], pf[rb], has_tail && j == n_tiles - 1,
-                              j * BN + 4 * lh, p.Tk);
+            for (int rb = 0; rb < RB; ++rb) need = need || (qn[rb] * kn_j - m_run[rb] > BOUND_THR);
+            if (__builtin_amdgcn_ballot_w64(need) != 0) {
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+                    softmax_rebase<DHP>(s[rb][0], s[rb][1], m_run[rb], l_run[rb], oacc[rb], msplat[rb], j == 0, tail,
+                                        j * BN + 4 * lh, p.Tk);
+            }
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) softmax_exp_pack(s[rb][0], s[rb][1], l_run[rb], pf[rb]);
+        }
 
         // ---- O^T += V'^T P^T, slab-major; reads stay one slab ahead (LDS returns in order) ----
         pv_reads_slab<DHP, 1>(vbase, voff, v1l, v1h);
@@ -737,8 +832,6 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
 //
 // LDS: K' ring of 3 images (K'(i+2) is read while K'(i+3) lands), V' ring of 2: [K0 | K1 | K2 | V1 | V0].
 // One barrier per tile; the DMA of V'(i+1) and K'(i+3) is issued right after it.
-constexpr float DEFER_THR = 8.0f;
-constexpr float BOUND_THR = 96.0f;     // exp2 arguments stay below this without looking at the scores
 #ifndef GTA_PK_SUM
 #define GTA_PK_SUM 0      // (1 = packed row sums: fewer issue slots, but wrong rows on some instantiations -- not understood yet)
 #endif
