@@ -299,7 +299,29 @@ __global__ __launch_bounds__(256) void gta_kv_prep_kernel(const GtaFwdParams p) 
 // is bound by LDS fragment reads (~35 cycles per ds_read_b128 under load, 8 x 24 KB per tile per CU --
 // as long as all the MFMAs of the tile).  RB = 2 halves the LDS bytes per MFMA and runs one wave per SIMD
 // with the whole 512-entry register file, so one block's softmax VALU can issue under the other's MFMAs.
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{})
+template <class F, int... Is>
+GTA_DEV void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+GTA_DEV void static_for(F&& f) { static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
+
+// GTA_ABL: ablation mask for timing experiments only (results are WRONG with any bit set):
+//   1 no exp/sum   2 no pack   4 no row max / decision   8 no V' reads   16 no K' reads   32 no DMA in the loop
+//   64 no QK^T MFMAs   128 no PV MFMAs   256 no barrier
+#ifndef GTA_ABL
+#define GTA_ABL 0
+#endif
+constexpr int ABL = GTA_ABL;
 constexpr int NSTAGE = 3;
+// Skewed tile loop in the 128-row kernel (QK^T of tile j+1 beside the softmax of tile j).  Measured on MI355X
+// (MSN encoder, B=32): 214 us vs 212 us un-skewed at 20 key tiles, 363 vs 372 us at 40, 105 vs 96 us at 5 --
+// the softmax VALU is already hidden by the co-resident wave (ablation: removing every exp saves 2 %), what is
+// left is MFMA + LDS-DMA issue + the per-workgroup prologue/epilogue.  Off by default (it also spills ~14 VGPRs
+// outside the loop at dh = 96); build with -DGTA_PIPE1=1 to select it.
+#ifndef GTA_PIPE1
+#define GTA_PIPE1 0
+#endif
+constexpr bool PIPE1 = GTA_PIPE1 != 0;
 constexpr float DEFER_THR = 8.0f;      // (pipelined kernel) running max moves when a row's tile max exceeds it by this
 constexpr float BOUND_THR = 96.0f;     // exp2 arguments stay below this without looking at the scores
 
@@ -450,6 +472,7 @@ GTA_DEV void pv_reads_slab(uint32_t vbase, const int (&voff)[DHP / 32][2], u32x2
     constexpr int OFF = SLAB * 16 * (DHP / 8) * 16;
 #pragma unroll
     for (int d = 0; d < DHP / 32; ++d) {
+        if constexpr (ABL & 8) { vlo[d] = u32x2_t{0, 0}; vhi[d] = u32x2_t{0, 0}; continue; }
         vlo[d] = lds_tr16_b64<OFF>(vbase + voff[d][0]);
         vhi[d] = lds_tr16_b64<OFF>(vbase + voff[d][1]);
     }
@@ -463,8 +486,10 @@ GTA_DEV void pv_mfma_slab(const u32x2_t (&vlo)[DHP / 32], const u32x2_t (&vhi)[D
     for (int d = 0; d < DHP / 32; ++d) {
         const u32x4_t av = {vlo[d].x, vlo[d].y, vhi[d].x, vhi[d].y};
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
+        for (int rb = 0; rb < RB; ++rb) {
+            if constexpr (ABL & 128) { oacc[rb][d][0] += __uint_as_float(av.x); continue; }
             oacc[rb][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av), pf[rb][kb][t], oacc[rb][d], 0, 0, 0);
+        }
     }
 }
 
@@ -491,6 +516,12 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
         const int xcd = L & 7, idx = L >> 3, q8 = nwg >> 3, r8 = nwg & 7;
         w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     }
+#ifdef GTA_STAGGER
+    // experiment: de-phase the two workgroups of a CU by delaying the second slot's first workgroup
+    if (blockIdx.x >= 256 && blockIdx.x < 512) {
+        for (int k2 = 0; k2 < GTA_STAGGER; ++k2) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     const int bh = w / p.n_qtiles, qt = w - bh * p.n_qtiles;
     const int b = bh / p.H, h = bh - b * p.H;
     const int q0 = qt * BM;
@@ -644,6 +675,147 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
     }
     const bool has_tail = (p.Tk & (BN - 1)) != 0;
 
+    if constexpr (RB == 1 && PIPE1 && DHP <= 96) {
+    // ---- skewed tile loop (RB == 1): the QK^T MFMAs of tile j+1 issue beside the softmax VALU of tile j ----
+    // Two of these waves share a SIMD (two workgroups per CU).  Measured (tests/probes/probe_coissue.hip): two
+    // waves whose streams each mix MFMA and VALU reach the matrix-pipe rate together, while the unskewed loop
+    // below (all MFMAs, then all VALU, per wave) leaves the pipes idle half the time.
+    //   A(j): S'(j+1) = K'(j+1) Q'^T - m   ||  decision(j); exp / sum / pack of P(j); K' fragments 2 steps ahead
+    //   B(j): O += V'(j) P(j), slab-major  ||  V'(j) transpose-reads one slab ahead
+    f32x16_t sA[2], sB[2];
+    u32x4_t pfr[2][2];                                // P as packed bf16 words: [key half][slab in half]
+    float rs0 = 0.f, rs1 = 0.f;                       // row-sum halves (even / odd values)
+    constexpr int NEV = 32;                           // P values per lane and tile: e -> (half = e >> 4, r = e & 15)
+    constexpr int GA = 2 * KS;                        // MFMAs of A: g -> (ks = g >> 1, half = g & 1)
+#ifndef GTA_KLA
+#define GTA_KLA 2
+#endif
+    constexpr int KLA = GTA_KLA;                      // K' fragment reads run this many k steps ahead of their MFMAs
+    auto e_first = [](int g) constexpr { return g * NEV / GA; };
+    auto s_fence1 = [&](f32x16_t (&s)[2]) { asm volatile("" : "+v"(s[0])); asm volatile("" : "+v"(s[1])); };
+    auto step = [&](f32x16_t (&sc)[2], f32x16_t (&sn)[2], int j, auto LASTC) {
+        constexpr bool LAST = decltype(LASTC)::value;
+        // tile j+1 has landed, everyone is past B(j-1): its stage takes tile j+2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (!(ABL & 256)) __builtin_amdgcn_s_barrier();
+        if (!(ABL & 32) && j + 2 < n_tiles) dma_stage<DHP, RB>(ring, (j + 2) % NSTAGE, kvimg + (long)(j + 2) * S::STAGE, wave, lane);
+        const char* kf = ring + ((j + 1) % NSTAGE) * S::STAGE;          // K'(j+1)
+        const uint32_t vbase = lds_addr(ring + (j % NSTAGE) * S::STAGE + S::IMG);   // V'(j)
+        uint32_t kn_bits;
+        {
+            const float* kn_ptr = p.kn + __builtin_amdgcn_readfirstlane((b * p.H + h) * n_tiles + j);
+            asm volatile("s_load_dword %0, %1, 0x0" : "=s"(kn_bits) : "s"(kn_ptr) : "memory");
+        }
+        bf16x8_t kfr[KS][2];
+        auto k_load = [&](auto KC) {
+            constexpr int ks = decltype(KC)::value;
+            if constexpr (!LAST && ks < KS && !(ABL & 16)) {
+                kfr[ks][0] = *reinterpret_cast<const bf16x8_t*>(kf + koff[ks]);
+                kfr[ks][1] = *reinterpret_cast<const bf16x8_t*>(kf + koff[ks] + 32 * CHP * 16);
+            }
+        };
+        static_for<KLA>([&](auto KC) { k_load(KC); });
+        // decision for tile j (sc = S'(j) relative to m_run): lazy-softmax full path only when needed
+        {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(kn_bits));
+            const float kn_j = __uint_as_float(kn_bits);
+            const bool tail = has_tail && j == n_tiles - 1;
+            const bool need = (j == 0) || tail || (qn[0] * kn_j - m_run[0] > BOUND_THR);
+            if (__builtin_amdgcn_ballot_w64(need) != 0) {
+                asm volatile("" ::: "memory");
+                l_run[0] += rs0 + rs1; rs0 = 0.f; rs1 = 0.f;
+                softmax_rebase<DHP>(sc[0], sc[1], m_run[0], l_run[0], oacc[0], msplat[0], j == 0, tail, j * BN + 4 * lh, p.Tk);
+            }
+            s_fence1(sc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<GA>([&](auto GC) {
+            constexpr int g = decltype(GC)::value, ks = g >> 1, hh = g & 1;
+            if constexpr (!LAST) {
+                if constexpr (ABL & 64) { if (ks == 0) sn[hh] = msplat[0]; }
+                else if constexpr (ks == 0) sn[hh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[0][hh], qf[0][0], msplat[0], 0, 0, 0);
+                else sn[hh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ks][hh], qf[0][ks], sn[hh], 0, 0, 0);
+                if constexpr (hh == 0) k_load(std::integral_constant<int, ks + KLA>{});
+            }
+            // this gap's exps, then the sums and packs of the values finished in earlier gaps
+            constexpr int e0 = e_first(g), e1 = e_first(g + 1), ep = g > 0 ? e_first(g - 1) : 0;
+            if constexpr (!(ABL & 1))
+            static_for<e1 - e0>([&](auto DC) {
+                constexpr int e = e0 + decltype(DC)::value;
+                sc[e >> 4][e & 15] = __builtin_amdgcn_exp2f(sc[e >> 4][e & 15]);
+            });
+            static_for<e0 - ep>([&](auto DC) {
+                constexpr int e = ep + decltype(DC)::value;
+                if (e & 1) rs1 += sc[e >> 4][e & 15]; else rs0 += sc[e >> 4][e & 15];
+            });
+            static_for<e0 / 2 - ep / 2>([&](auto DC) {
+                constexpr int k = ep / 2 + decltype(DC)::value, e = 2 * k;
+                pfr[e >> 4][(e & 15) >> 3][(e & 7) >> 1] = pack_bf16x2(sc[e >> 4][e & 15], sc[e >> 4][(e & 15) + 1]);
+            });
+            if constexpr (g == GA - 1) {                      // tail of the list
+                static_for<NEV - e0>([&](auto DC) {
+                    constexpr int e = e0 + decltype(DC)::value;
+                    if (e & 1) rs1 += sc[e >> 4][e & 15]; else rs0 += sc[e >> 4][e & 15];
+                });
+                static_for<NEV / 2 - e0 / 2>([&](auto DC) {
+                    constexpr int k = e0 / 2 + decltype(DC)::value, e = 2 * k;
+                    pfr[e >> 4][(e & 15) >> 3][(e & 7) >> 1] = pack_bf16x2(sc[e >> 4][e & 15], sc[e >> 4][(e & 15) + 1]);
+                });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // ---- B(j): O^T += V'^T P^T, slab-major; reads stay one slab ahead (LDS returns in order) ----
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (no compiler-tracked LDS read is in flight past here)
+        u32x2_t v0l[DB], v0h[DB], v1l[DB], v1h[DB], v2l[DB], v2h[DB], v3l[DB], v3h[DB];
+        bf16x8_t pfb[1][2][2];
+        pfb[0][0][0] = __builtin_bit_cast(bf16x8_t, pfr[0][0]); pfb[0][0][1] = __builtin_bit_cast(bf16x8_t, pfr[0][1]);
+        pfb[0][1][0] = __builtin_bit_cast(bf16x8_t, pfr[1][0]); pfb[0][1][1] = __builtin_bit_cast(bf16x8_t, pfr[1][1]);
+        pv_reads_slab<DHP, 0>(vbase, voff, v0l, v0h);
+        pv_reads_slab<DHP, 1>(vbase, voff, v1l, v1h);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * DB) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        pv_mfma_slab<DHP, RB>(v0l, v0h, pfb, 0, 0, oacc);
+        pv_reads_slab<DHP, 2>(vbase, voff, v2l, v2h);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * DB) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        pv_mfma_slab<DHP, RB>(v1l, v1h, pfb, 0, 1, oacc);
+        pv_reads_slab<DHP, 3>(vbase, voff, v3l, v3h);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * DB) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        pv_mfma_slab<DHP, RB>(v2l, v2h, pfb, 1, 0, oacc);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        pv_mfma_slab<DHP, RB>(v3l, v3h, pfb, 1, 1, oacc);
+        if constexpr (!LAST) s_fence1(sn);
+    };
+    // tile 0: S'(0) by itself
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    {
+        const char* kf = ring;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8_t k0 = *reinterpret_cast<const bf16x8_t*>(kf + koff[ks]);
+            const bf16x8_t k1 = *reinterpret_cast<const bf16x8_t*>(kf + koff[ks] + 32 * CHP * 16);
+            sA[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[0][ks], ks == 0 ? msplat[0] : sA[0], 0, 0, 0);
+            sA[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[0][ks], ks == 0 ? msplat[0] : sA[1], 0, 0, 0);
+        }
+    }
+    {
+        int j = 0;
+        for (; j + 2 < n_tiles; j += 2) {
+            step(sA, sB, j, std::false_type{});
+            step(sB, sA, j + 1, std::false_type{});
+        }
+        if (j + 2 == n_tiles) {
+            step(sA, sB, j, std::false_type{});
+            step(sB, sA, j + 1, std::true_type{});
+        } else {
+            step(sA, sB, j, std::true_type{});
+        }
+    }
+    l_run[0] += rs0 + rs1;
+    } else
     for (int j = 0; j < n_tiles; ++j) {
         // tile j has landed (only tile j+1's pieces may still be in flight), everyone is past tile j-1
         if (j + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
@@ -746,7 +918,7 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
     constexpr int NPASS = BM / S::OST_ROWS;                          // RB
     constexpr int WPP = NW / NPASS;                                  // waves whose rows go in one pass
     constexpr int EITEMS = CHP / 2;                                  // epilogue map: 2 row groups x 2 parities
-    constexpr bool SAMEMAP = (RB == 1);                              // == the prologue map: reuse its (cos,sin)
+    constexpr bool SAMEMAP = false;   // (the prologue's (cos,sin) are NOT kept across the loop: 48 VGPRs the skewed loop needs)
     const int rgE = wave & 1, parE = wave >> 1;
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; ++pass) {
@@ -836,13 +1008,6 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
 #define GTA_PK_SUM 0      // (1 = packed row sums: fewer issue slots, but wrong rows on some instantiations -- not understood yet)
 #endif
 constexpr bool PK_SUM = GTA_PK_SUM != 0;
-// GTA_ABL: ablation mask for timing experiments only (results are WRONG with any bit set):
-//   1 no exp/sum   2 no pack   4 no row max / decision   8 no V' reads   16 no K' reads   32 no DMA in the loop
-//   64 no QK^T MFMAs   128 no PV MFMAs   256 no barrier
-#ifndef GTA_ABL
-#define GTA_ABL 0
-#endif
-constexpr int ABL = GTA_ABL;
 constexpr bool SKIP_MAX = (ABL & 4) != 0;
 
 // single VALU instructions kept single: a plain -O3 build SLP-packs adjacent f32 adds into v_pk_add_f32 (slower
@@ -893,11 +1058,7 @@ GTA_DEV void mfma_pv(const u32x4_t& pb) {
     asm volatile("v_mfma_f32_32x32x16_bf16 a[%c1:%c2], a[%c3:%c4], %0, a[%c1:%c2]" ::"v"(pb), "i"(O0), "i"(O0 + 15), "i"(V0), "i"(V0 + 3));
 }
 
-// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{})
-template <class F, int... Is>
-GTA_DEV void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
-template <int N, class F>
-GTA_DEV void static_for(F&& f) { static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
+
 
 template <int DHP, int RB>
 struct Smem3 {
