@@ -191,6 +191,18 @@ def main():
     alg_bytes = (2 * Tq + 2 * Tk) * H * dh * q.element_size() * B    # read Q,K,V once, write O once
     achieved = flops / (kern_ms * 1e-3) / 1e12
 
+    # HBM bytes per launch of the dominant kernel from the PMC counters (collected in separate rocprofv3 passes,
+    # tools/profile_r01.sh; the corrected per-launch figure is committed under profiles/): only quoted when
+    # the committed measurement is of this workload / batch / dtype
+    traffic, traffic_src = None, None
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_traffic.json")) as f:
+            t = json.load(f)
+        if (t["workload"], t["batch"], t["dtype"]) == (args.workload, B, args.dtype) and args.kv_mode == "prepass":
+            traffic, traffic_src = t["bytes_per_launch"], "profiles/r01/pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)"
+    except (OSError, KeyError, ValueError):
+        pass
+
     if rank == 0:
         n = max(world, 1)
         ms_per_step = elapsed / args.steps * 1e3
@@ -206,7 +218,8 @@ def main():
                                    f"views q/k={Nq}/{Nk}", "global_batch": n * B, "parallelism": f"dp{n}"},
             "roofline": {"bound": "mfma", "kernel": "gta_fwd2_kernel" if args.kv_mode == "prepass" else "gta_fwd_kernel", "achieved": achieved,
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
-                         "traffic": None, "kernel_ms": kern_ms, "algorithmic_flops": flops,
+                         "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                         "kernel_ms": kern_ms, "algorithmic_flops": flops,
                          "algorithmic_bytes": alg_bytes,
                          "hbm_frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
         }
