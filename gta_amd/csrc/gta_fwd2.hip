@@ -516,12 +516,6 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
         const int xcd = L & 7, idx = L >> 3, q8 = nwg >> 3, r8 = nwg & 7;
         w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     }
-#ifdef GTA_STAGGER
-    // experiment: de-phase the two workgroups of a CU by delaying the second slot's first workgroup
-    if (blockIdx.x >= 256 && blockIdx.x < 512) {
-        for (int k2 = 0; k2 < GTA_STAGGER; ++k2) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     const int bh = w / p.n_qtiles, qt = w - bh * p.n_qtiles;
     const int b = bh / p.H, h = bh - b * p.H;
     const int q0 = qt * BM;
