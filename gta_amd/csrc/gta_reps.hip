@@ -2,7 +2,7 @@
 //
 // Tiny kernels (B*N views, B*T tokens): HBM traffic is a few hundred KB per forward and they run
 // once per encoder/decoder call, shared by all layers exactly like the reference's
-// pre_compute_reps output.  One thread per view / per (token, block); nothing to tile.
+// pre_compute_reps output.  One wave per view / one thread per (token, block); nothing to tile.
 #include "gta_common.h"
 #include "../../include/gta_hip.h"
 
@@ -19,43 +19,8 @@ __constant__ float kJ2[25] = {0.f, 0.f, 0.f,  -1.f, 0.f,
                               -1.f, 0.f, 0.f,  0.f, 0.f,
                               0.f, 0.f, -S3H,  0.f, 0.5f};
 
-// Z(angle) of wigner_d.py:16-25: cos(m a) on the diagonal, sin(m a) on the anti-diagonal,
-// m = l..-l; the diagonal is written last (centre element = cos 0 = 1).
-template <int N>
-__device__ __forceinline__ void z_rot(float a, float* Z) {
-    constexpr int l = (N - 1) / 2;
-#pragma unroll
-    for (int i = 0; i < N * N; ++i) Z[i] = 0.f;
-#pragma unroll
-    for (int i = 0; i < N; ++i) Z[i * N + (N - 1 - i)] = sinf((float)(l - i) * a);
-#pragma unroll
-    for (int i = 0; i < N; ++i) Z[i * N + i] = cosf((float)(l - i) * a);
-}
-template <int N>
-__device__ __forceinline__ void matmul(const float* A, const float* B, float* C) {
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            float s = 0.f;
-#pragma unroll
-            for (int k = 0; k < N; ++k) s += A[i * N + k] * B[k * N + j];
-            C[i * N + j] = s;
-        }
-}
-// D = Z(g3) J Z(g2) J Z(g1)   (wigner_d.py:28-35)
-template <int N>
-__device__ __forceinline__ void wigner(const float* J, float g1, float g2, float g3, float* D) {
-    float Z[N * N], T0[N * N], T1[N * N];
-    z_rot<N>(g3, Z);
-    matmul<N>(Z, J, T0);
-    z_rot<N>(g2, Z);
-    matmul<N>(T0, Z, T1);
-    matmul<N>(T1, J, T0);
-    z_rot<N>(g1, Z);
-    matmul<N>(T0, Z, D);
-}
-
+// Z(angle) of wigner_d.py:16-25: cos(m a) on the diagonal, sin(m a) on the anti-diagonal, m = l..-l (the
+// diagonal is written last: centre element = cos 0 = 1);  D = Z(g3) J Z(g2) J Z(g1)  (wigner_d.py:28-35).
 // General 4x4 inverse, Gauss-Jordan with partial pivoting in fp64 (the reference calls
 // torch.linalg.inv, encoder.py:219 -- a general inverse, not the rigid closed form).
 __device__ __forceinline__ void inv4(const float* E, float* out) {
@@ -94,25 +59,74 @@ __device__ __forceinline__ void inv4(const float* E, float* out) {
         for (int j = 0; j < 4; ++j) out[i * 4 + j] = (float)a[i][4 + j];
 }
 
-// three threads per view: role 0 writes E and inverse(E), role 1 D^1, role 2 D^2 (each recomputes the
-// cheap inverse; the trig-heavy Wigner products run side by side instead of back to back)
-__global__ void build_view_reps_kernel(const float* __restrict__ E, int n_views, int L,
-                                       float* __restrict__ vrep) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = gid / 3, role = gid - 3 * i;
+// One wave per view.  Every lane runs the (latency-bound, ~300 dependent fp64 ops) inverse and the Euler angles
+// redundantly -- in SIMD that costs what one lane costs -- then lanes split the Wigner products by output
+// COLUMN: D[:, j] = Z(g3) J Z(g2) J Z(g1)[:, j] is a chain of matrix-vector products (Z has two non-zeros per
+// row), ~70 FMAs per lane instead of the 500 of the full 5x5 chain in one thread (the previous 3-threads-per-view
+// kernel took 15 us for 160 views; this one is bounded by the inverse).
+template <int N>
+__device__ __forceinline__ void wigner_column(const float* J, const float (&cs1)[3][2], const float (&cs2)[3][2],
+                                              const float (&cs3)[3][2], int j, float* col) {
+    // cs*[m] = (cos, sin)(m * angle), m = 0..2;  Z(a)[i][i] = cos((l-i)a), Z(a)[i][N-1-i] = sin((l-i)a), centre = 1
+    constexpr int l = (N - 1) / 2;
+    auto c_of = [](const float (&cs)[3][2], int m) { return cs[m < 0 ? -m : m][0]; };
+    auto s_of = [](const float (&cs)[3][2], int m) { return m < 0 ? -cs[-m][1] : cs[m][1]; };
+    float v[N], w[N];
+    // v = Z1[:, j]
+#pragma unroll
+    for (int d = 0; d < N; ++d) {
+        const float diag = c_of(cs1, l - d), anti = s_of(cs1, l - d);
+        v[d] = (d == j) ? diag : ((d == N - 1 - j) ? anti : 0.f);
+    }
+    // w = J v
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < N; ++c) acc += J[r * N + c] * v[c];
+        w[r] = acc;
+    }
+    // v = Z2 w
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+        v[r] = (r == N - 1 - r) ? w[r] : (s_of(cs2, l - r) * w[N - 1 - r] + c_of(cs2, l - r) * w[r]);
+    // w = J v
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < N; ++c) acc += J[r * N + c] * v[c];
+        w[r] = acc;
+    }
+    // col = Z3 w
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+        col[r] = (r == N - 1 - r) ? w[r] : (s_of(cs3, l - r) * w[N - 1 - r] + c_of(cs3, l - r) * w[r]);
+}
+
+__device__ __forceinline__ void view_reps_body(int block, const float* __restrict__ E, int n_views, int L,
+                                               float* __restrict__ vrep) {
+    const int lane = threadIdx.x & 63;
+    const int i = block * 4 + (threadIdx.x >> 6);
     if (i >= n_views) return;
     const float* e = E + (size_t)i * 16;
     float* o = vrep + (size_t)i * GTA_VREP_STRIDE;
-    float inv[16];
-    inv4(e, inv);
-    if (role == 0) {
-        for (int j = 0; j < 16; ++j) { o[GTA_VREP_INV + j] = e[j]; o[GTA_VREP_REP + j] = inv[j]; }
-        for (int j = GTA_VREP_D2 + 25; j < GTA_VREP_STRIDE; ++j) o[j] = 0.f;
-        if (L < 1) for (int j = GTA_VREP_D1; j < GTA_VREP_D2; ++j) o[j] = 0.f;
-        if (L < 2) for (int j = GTA_VREP_D2; j < GTA_VREP_D2 + 25; ++j) o[j] = 0.f;
-        return;
+    float ev[16], inv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) ev[j] = e[j];
+    inv4(ev, inv);
+    // records: lanes 0..15 write E and inverse(E); lanes 16.. zero the padding
+    if (lane < 16) {
+        float a = 0.f, b2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { if (j == lane) { a = ev[j]; b2 = inv[j]; } }
+        o[GTA_VREP_INV + lane] = a;
+        o[GTA_VREP_REP + lane] = b2;
     }
-    if (role > L) return;
+    for (int j = GTA_VREP_D2 + 25 + lane; j < GTA_VREP_STRIDE; j += 64) o[j] = 0.f;
+    if (L < 1 && lane < 9) o[GTA_VREP_D1 + lane] = 0.f;
+    if (L < 2 && lane < 25) o[GTA_VREP_D2 + lane] = 0.f;
+    if (L < 1) return;
     // R = inverse(E)[:3,:3]; ZYZ angles with the reference's gimbal masks (wigner_d.py:39-49)
 #define R_(r, c) inv[(r) * 4 + (c)]
     const float EPS = 1e-5f;
@@ -125,24 +139,31 @@ __global__ void build_view_reps_kernel(const float* __restrict__ E, int n_views,
     g1 = reg * g1 + up * atan2f(R_(1, 0), R_(0, 0)) + dn * atan2f(-R_(1, 0), -R_(0, 0));
     g3 = reg * g3;
 #undef R_
-    if (role == 1) {
-        float D1[9];
-        wigner<3>(kJ1, g1, g2, g3, D1);
+    float cs1[3][2], cs2[3][2], cs3[3][2];
+    auto fill = [](float a, float (&cs)[3][2]) {
+        cs[0][0] = 1.f; cs[0][1] = 0.f;
+        sincosf(a, &cs[1][1], &cs[1][0]);
+        sincosf(2.f * a, &cs[2][1], &cs[2][0]);
+    };
+    fill(g1, cs1); fill(g2, cs2); fill(g3, cs3);
+    if (lane < 3) {                       // D^1 column `lane`
+        float col[3];
+        wigner_column<3>(kJ1, cs1, cs2, cs3, lane, col);
 #pragma unroll
-        for (int j = 0; j < 9; ++j) o[GTA_VREP_D1 + j] = D1[j];
-    } else {
-        float D2[25];
-        wigner<5>(kJ2, g1, g2, g3, D2);
+        for (int r = 0; r < 3; ++r) o[GTA_VREP_D1 + r * 3 + lane] = col[r];
+    } else if (L >= 2 && lane >= 8 && lane < 13) {   // D^2 column `lane - 8`
+        float col[5];
+        wigner_column<5>(kJ2, cs1, cs2, cs3, lane - 8, col);
 #pragma unroll
-        for (int j = 0; j < 25; ++j) o[GTA_VREP_D2 + j] = D2[j];
+        for (int r = 0; r < 5; ++r) o[GTA_VREP_D2 + r * 5 + (lane - 8)] = col[r];
     }
 }
 
 // theta_{t,c=2f+d} = (float)(max_freq_d * 2 pi) * (coord_d * freq_f), freq_f = 2^(f+1-F) or 1
 // (gta.py:57-63: the double scalar is rounded to fp32 when it meets the fp32 tensor).
-__global__ void build_so2_table_kernel(const float* __restrict__ coord, int n_tokens, int F,
-                                       float k_h, float k_w, int shared, float* __restrict__ cs) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void so2_table_body(int block, const float* __restrict__ coord, int n_tokens, int F,
+                                               float k_h, float k_w, int shared, float* __restrict__ cs) {
+    const int i = block * 256 + threadIdx.x;
     const int nblk = 2 * F;
     if (i >= n_tokens * nblk) return;
     const int t = i / nblk, c = i - t * nblk;
@@ -156,14 +177,31 @@ __global__ void build_so2_table_kernel(const float* __restrict__ coord, int n_to
     cs[2 * i + 1] = s;
 }
 
+__global__ __launch_bounds__(256) void build_view_reps_kernel(const float* __restrict__ E, int n_views, int L,
+                                                              float* __restrict__ vrep) {
+    view_reps_body(blockIdx.x, E, n_views, L, vrep);
+}
+__global__ __launch_bounds__(256) void build_so2_table_kernel(const float* __restrict__ coord, int n_tokens, int F,
+                                                              float k_h, float k_w, int shared, float* __restrict__ cs) {
+    so2_table_body(blockIdx.x, coord, n_tokens, F, k_h, k_w, shared, cs);
+}
+// both builders in one launch (they are independent and each is launch-latency sized): blocks [0, n_vb) build
+// view records, the rest the SO(2) table
+__global__ __launch_bounds__(256) void build_reps_kernel(const float* __restrict__ E, int n_views, int L,
+                                                         float* __restrict__ vrep, int n_vb,
+                                                         const float* __restrict__ coord, int n_tokens, int F,
+                                                         float k_h, float k_w, int shared, float* __restrict__ cs) {
+    if ((int)blockIdx.x < n_vb) view_reps_body(blockIdx.x, E, n_views, L, vrep);
+    else so2_table_body(blockIdx.x - n_vb, coord, n_tokens, F, k_h, k_w, shared, cs);
+}
+
 }  // namespace
 
 extern "C" int gta_build_view_reps(const float* extrinsics, int32_t n_views, int32_t so3_degree,
                                    float* vrep, void* stream) {
     if (!extrinsics || !vrep || n_views <= 0) return GTA_E_BADARG;
     if (so3_degree < 0 || so3_degree > 2) return GTA_E_UNSUPPORTED;
-    const int th = 64;
-    hipLaunchKernelGGL(build_view_reps_kernel, dim3((3 * n_views + th - 1) / th), dim3(th), 0,
+    hipLaunchKernelGGL(build_view_reps_kernel, dim3((n_views + 3) / 4), dim3(256), 0,
                        (hipStream_t)stream, extrinsics, n_views, so3_degree, vrep);
     return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH;
 }
@@ -176,8 +214,24 @@ extern "C" int gta_build_so2_table(const float* coord, int32_t n_tokens, int32_t
     const float k_h = (float)((double)max_freq_h * two_pi);
     const float k_w = (float)((double)max_freq_w * two_pi);
     const long total = (long)n_tokens * 2 * nfreqs;
-    const int th = 256;
+    const int th = 256;                  // (so2_table_body assumes 256-thread blocks)
     hipLaunchKernelGGL(build_so2_table_kernel, dim3((unsigned)((total + th - 1) / th)), dim3(th), 0,
                        (hipStream_t)stream, coord, n_tokens, nfreqs, k_h, k_w, shared_freqs, cs);
+    return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH;
+}
+
+extern "C" int gta_build_reps(const float* extrinsics, int32_t n_views, int32_t so3_degree, float* vrep,
+                              const float* coord, int32_t n_tokens, int32_t nfreqs, float max_freq_h,
+                              float max_freq_w, int32_t shared_freqs, float* cs, void* stream) {
+    if (!extrinsics || !vrep || n_views <= 0 || !coord || !cs || n_tokens <= 0 || nfreqs <= 0) return GTA_E_BADARG;
+    if (so3_degree < 0 || so3_degree > 2) return GTA_E_UNSUPPORTED;
+    const double two_pi = 6.283185307179586;
+    const float k_h = (float)((double)max_freq_h * two_pi);
+    const float k_w = (float)((double)max_freq_w * two_pi);
+    const int n_vb = (n_views + 3) / 4;
+    const long total = (long)n_tokens * 2 * nfreqs;
+    const long n_tb = (total + 255) / 256;
+    hipLaunchKernelGGL(build_reps_kernel, dim3((unsigned)(n_vb + n_tb)), dim3(256), 0, (hipStream_t)stream, extrinsics,
+                       n_views, so3_degree, vrep, n_vb, coord, n_tokens, nfreqs, k_h, k_w, shared_freqs, cs);
     return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH;
 }

@@ -31,7 +31,7 @@ MAX_VIEWS = 16
 
 # every symbol include/gta_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (
-    "gta_build_view_reps", "gta_build_so2_table", "gta_attn_fwd", "gta_attn_fwd_supported",
+    "gta_build_view_reps", "gta_build_so2_table", "gta_build_reps", "gta_attn_fwd", "gta_attn_fwd_supported",
     "gta_attn_fwd_launch_info", "gta_attn_fwd_workspace_bytes", "gta_attn_bwd", "gta_attn_bwd_workspace_bytes",
     "gta_rep_apply", "gta_attn_fwd_plain",
     "gta_strerror", "gta_abi_version", "gta_sizeof_attn_desc",
@@ -76,6 +76,8 @@ def lib():
             raise GtaError("GtaAttnDesc layout mismatch between gta_hip.h and gta_amd/native.py")
         L.gta_build_view_reps.argtypes = [c_void_p, c_int32, c_int32, c_void_p, c_void_p]
         L.gta_build_so2_table.argtypes = [c_void_p, c_int32, c_int32, c_float, c_float, c_int32, c_void_p, c_void_p]
+        L.gta_build_reps.argtypes = [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_float, c_float,
+                                     c_int32, c_void_p, c_void_p]
         L.gta_attn_fwd.argtypes = [ctypes.POINTER(GtaAttnDesc)] + [c_void_p] * 12 + [c_int64, c_void_p]
         L.gta_attn_fwd_workspace_bytes.argtypes = [ctypes.POINTER(GtaAttnDesc)]
         L.gta_attn_fwd_workspace_bytes.restype = c_int64
@@ -133,6 +135,22 @@ def build_so2_table(coord: torch.Tensor, nfreqs: int, max_freq_h: float, max_fre
     check(lib().gta_build_so2_table(_ptr(c), B * T, int(nfreqs), float(max_freq_h), float(max_freq_w),
                                     int(bool(shared_freqs)), _ptr(out), _stream()), "gta_build_so2_table")
     return out
+
+
+def build_reps(transforms: torch.Tensor, so3_degree: int, coord: torch.Tensor, nfreqs: int, max_freq_h: float,
+               max_freq_w: float, shared_freqs: bool = False):
+    """build_view_reps + build_so2_table in one launch -> (vrep [B,N,72], cs [B,T,2F,2])."""
+    _require_cuda(transforms, coord)
+    B, N = transforms.shape[:2]
+    T = coord.shape[1]
+    E = transforms.detach().to(torch.float32).contiguous()
+    c = coord.detach().to(torch.float32).contiguous()
+    vrep = torch.empty(B, N, VREP_STRIDE, device=E.device, dtype=torch.float32)
+    cs = torch.empty(B, T, 2 * nfreqs, 2, device=c.device, dtype=torch.float32)
+    check(lib().gta_build_reps(_ptr(E), B * N, int(so3_degree), _ptr(vrep), _ptr(c), B * T, int(nfreqs),
+                               float(max_freq_h), float(max_freq_w), int(bool(shared_freqs)), _ptr(cs), _stream()),
+          "gta_build_reps")
+    return vrep, cs
 
 
 def make_desc(q, k, v, out, f_dims: dict, so3_degree: int, Nq: int, Nk: int, scale: float,

@@ -59,10 +59,18 @@ def _flattened(vrep, cs, T):
 def pre_compute_reps_encoder(attn_kwargs: dict, extras: dict) -> dict:
     """encoder.py:183-265: reps of the input views, q-side == k-side."""
     f = _check(attn_kwargs)
-    if f.get("so2", 0) > 0:
+    need_view = f.get("se3", 0) > 0 or f.get("so3", 0) > 0
+    L = attn_kwargs.get("so3", 0) if f.get("so3", 0) > 0 else 0
+    if f.get("so2", 0) > 0 and need_view:            # both tables in one launch
+        c = extras["input_coord"].reshape(extras["input_coord"].shape[0], -1, 2)
+        vrep, cs = native.build_reps(extras["input_transforms"], L, c, attn_kwargs["so2"], attn_kwargs["max_freq_h"],
+                                     attn_kwargs["max_freq_w"], attn_kwargs.get("shared_freqs", False))
+        extras["gta_cs_q"] = extras["gta_cs_k"] = cs
+        extras["gta_vrep_q"] = extras["gta_vrep_k"] = vrep
+        extras["gta_so3_degree"] = L
+    elif f.get("so2", 0) > 0:
         extras["gta_cs_q"] = extras["gta_cs_k"] = _so2(attn_kwargs, extras["input_coord"])
-    if f.get("se3", 0) > 0 or f.get("so3", 0) > 0:
-        L = attn_kwargs.get("so3", 0) if f.get("so3", 0) > 0 else 0
+    elif need_view:
         extras["gta_vrep_q"] = extras["gta_vrep_k"] = native.build_view_reps(extras["input_transforms"], L)
         extras["gta_so3_degree"] = L
     if attn_kwargs.get("elementwise_mul", False):

@@ -101,6 +101,13 @@ int gta_build_so2_table(const float* coord, int32_t n_tokens, int32_t nfreqs,
                         float max_freq_h, float max_freq_w, int32_t shared_freqs,
                         float* cs, void* stream);
 
+/* Both of the above in ONE launch (they are independent and launch-latency sized): what
+ * pre_compute_reps (source/encoder.py:183-265) does for a gta_so3-style config in one call.
+ * Arguments as for gta_build_view_reps followed by those of gta_build_so2_table. */
+int gta_build_reps(const float* extrinsics, int32_t n_views, int32_t so3_degree, float* vrep,
+                   const float* coord, int32_t n_tokens, int32_t nfreqs, float max_freq_h,
+                   float max_freq_w, int32_t shared_freqs, float* cs, void* stream);
+
 /* -------------------------------------------------------------------------------------------
  * Fused forward  (replaces gta.py:92-279 + AttnFn, layers.py:202-211)
  *   q [B,H,Tq,dh], k,v [B,H,Tk,dh] through the strides in desc; out like q.
