@@ -92,6 +92,10 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model-train-steps", type=int, default=0,
+                    help="also time K optimizer steps of the whole MSN gta_so3 TransformingSRT (gta_amd.srt) on synthetic "
+                         "multi-view batches, DDP over the ranks; reported as `srt_train`, not part of `value`")
+    ap.add_argument("--model-batch", type=int, default=8, help="per-GPU scenes for --model-train-steps")
     ap.add_argument("--train-steps", type=int, default=10,
                     help="extra (untimed-for-`value`) forward+backward steps reported as fwd_bwd_* fields; 0 = skip")
     ap.add_argument("--kv-mode", dest="kv_mode", default="prepass", choices=["prepass", "fused"],
@@ -187,6 +191,51 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         fwd_bwd_ms = e0.elapsed_time(e1) / args.train_steps
+    srt_train = None
+    if args.model_train_steps > 0:
+        # whole-model optimizer step (conv stem, 5 + 2 Transformer blocks on the HIP attention path,
+        # render MLP, MSE loss, AdamW; bf16 autocast; DDP's bucketed gradient all-reduce over RCCL when world > 1)
+        from gta_amd import srt, ddp
+        torch.manual_seed(1234 + rank)
+        model = srt.TransformingSRT(srt.msn_gta_so3_cfg()).to(device)
+        if dist is not None:
+            model = ddp.wrap_ddp(model, local_rank)
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+        batch = srt.synthetic_batch(args.model_batch, device=device, seed=99 + rank)
+
+        def model_step():
+            opt.zero_grad(set_to_none=True)
+            loss, _ = srt.compute_loss(model, batch, mixed_prec=(args.dtype == "bf16"))
+            loss.mean().backward()
+            opt.step()
+            return loss
+
+        for _ in range(2):
+            model_step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        tm0 = time.perf_counter()
+        for _ in range(args.model_train_steps):
+            last = model_step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dtm = time.perf_counter() - tm0
+        if dist is not None:
+            tt = torch.tensor([dtm], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dtm = float(tt.item())
+        n_ = max(world, 1)
+        ms = dtm / args.model_train_steps * 1e3
+        srt_train = {"ms_per_step": ms, "scenes_per_s": n_ * args.model_batch / (ms * 1e-3),
+                     "enc_mtokens_s": n_ * args.model_batch * 1280 / (ms * 1e-3) / 1e6,
+                     "loss": float(last.mean().item()),
+                     "config": f"MSN gta_so3 TransformingSRT (encoder 5 blocks d=768, decoder 2 blocks, 5 input + 5 target "
+                               f"views, 1280 scene tokens, 2560 query rays), {args.model_batch} scenes/GPU, "
+                               f"AdamW, {args.dtype} autocast, dp{n_}",
+                     "note": "whole-model optimizer step on synthetic batches (SURVEY 8 f2); not part of `value`"}
+        del model, opt, batch
     flops = 4.0 * B * H * Tq * Tk * dh                               # QK^T + PV, 2 flop/MAC
     alg_bytes = (2 * Tq + 2 * Tk) * H * dh * q.element_size() * B    # read Q,K,V once, write O once
     achieved = flops / (kern_ms * 1e-3) / 1e12
@@ -228,6 +277,8 @@ def main():
                                "tflops": 3.5 * flops / (fwd_bwd_ms * 1e-3) / 1e12,
                                "note": "operator forward + backward (5 GEMMs + 2 recomputed = 3.5x forward flops), "
                                        "not part of `value`"}
+        if srt_train is not None:
+            line["srt_train"] = srt_train
         if not args.no_cpu_baseline and n == 1:
             line["cpu_baseline"] = cpu_baseline(args.workload, 99)
         print(json.dumps(line), flush=True)

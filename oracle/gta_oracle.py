@@ -494,6 +494,77 @@ class OracleTransformer(nn.Module):
         return (x, attmap) if self.return_last_attmap else x
 
 
+# --------------------------------------------------------------------------------------
+# encoder / decoder wrappers, gta path (encoder.py:37-345, decoder.py:27-384, models_nvs.py:14-91)
+# --------------------------------------------------------------------------------------
+class _ConvBlock(nn.Module):
+    """encoder.py:13-34."""
+
+    def __init__(self, idim, hdim=None, odim=None):
+        super().__init__()
+        hdim = idim if hdim is None else hdim
+        odim = 2 * hdim if odim is None else odim
+        self.layers = nn.Sequential(nn.Conv2d(idim, hdim, 3, 1, 1, bias=False), nn.ReLU(),
+                                    nn.Conv2d(hdim, odim, 3, 2, 1, bias=False), nn.ReLU())
+
+    def forward(self, x):
+        return self.layers(x)
+
+
+class OracleSRT(nn.Module):
+    """CPU restatement of TransformingSRT for the GTA configs (encoder ``emb: False``, decoder ``emb: const``):
+    conv stem -> 1x1 projection -> self-attention Transformer; one learned query vector per target ray ->
+    cross-attention Transformer -> render MLP.  Parameter names follow the reference's state dict."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        ek, dk = cfg["encoder_kwargs"], cfg["decoder_kwargs"]
+        enc = nn.Module()
+        dim, attdim = ek.get("dim", 768), ek.get("attdim", 768)
+        blocks = [_ConvBlock(3, dim // 8)]
+        cur = dim // 4
+        for _ in range(1, ek.get("num_conv_blocks", 3)):
+            blocks.append(_ConvBlock(cur))
+            cur *= 2
+        enc.conv_blocks = nn.Sequential(*blocks)
+        enc.per_patch_linear = nn.Conv2d(cur, attdim, 1)
+        heads = ek.get("heads", 12)
+        enc.transformer = OracleTransformer(attdim, ek.get("num_att_blocks", 5), heads, attdim // heads, attdim * 2,
+                                            ek.get("dropout") or 0.0, True, None, False, ek["attn_args"])
+        self.encoder = enc
+        self.enc_args = ek["attn_args"]["method"]["args"]
+        dec = nn.Module()
+        ddim, z_dim, dheads = dk.get("dim", 180), dk.get("z_dim", 768), dk.get("heads", 12)
+        alloc = nn.Module()
+        alloc.initial_emb = nn.Parameter(torch.randn(ddim))
+        alloc.transformer = OracleTransformer(ddim, dk.get("num_att_blocks", 2), dheads, dk.get("dim_head") or z_dim // dheads,
+                                              dk.get("mlp_dim") or z_dim * 2, dk.get("dropout") or 0.0, False, z_dim,
+                                              False, dk["attn_args"])
+        dec.allocation_transformer = alloc
+        r = dk.get("rmlp_dim", 1536)
+        act = {"relu": nn.ReLU, "lrelu": nn.LeakyReLU, "gelu": nn.GELU}[dk.get("act", "lrelu")]
+        mlp = [nn.Linear(ddim, r), act()]
+        for _ in range(3):
+            mlp += [nn.Linear(r, r), act()]
+        mlp += [nn.Linear(r, 3), nn.Sigmoid() if dk.get("sigmoid", True) else nn.Identity()]
+        dec.render_mlp = nn.Sequential(*mlp)
+        self.decoder = dec
+        self.dec_args = dk["attn_args"]["method"]["args"]
+
+    def forward(self, input_images, input_camera_pos, input_rays, target_camera_pos, target_rays, extras):
+        B, N = input_images.shape[:2]
+        reps = encoder_reps(self.enc_args, extras)
+        x = self.encoder.per_patch_linear(self.encoder.conv_blocks(input_images.flatten(0, 1)))
+        x = x.flatten(2, 3).permute(0, 2, 1)
+        x = x.reshape(B, N * x.shape[1], x.shape[2])
+        z = self.encoder.transformer(x, None, reps)
+        reps = decoder_reps(self.dec_args, extras, reps)
+        rays = target_rays.flatten(1, 2) if target_rays.dim() == 4 else target_rays
+        q = self.decoder.allocation_transformer.initial_emb[None, None].expand(B, rays.shape[1], -1)
+        out = self.decoder.allocation_transformer.transformer(q, z, reps)
+        return self.decoder.render_mlp(out)
+
+
 def mse2psnr(mse: torch.Tensor) -> torch.Tensor:
     """common.py:14-15."""
     return -10.0 * torch.log(mse) / math.log(10.0)

@@ -54,12 +54,13 @@ def import_reference():
         import source.utils.wigner_d as ref_wig
         import source.encoder as ref_enc
         import source.decoder as ref_dec
+        import source.models_nvs as ref_nvs
     finally:
         os.chdir(cwd)
-    return ref_gta, ref_layers, ref_wig, ref_enc, ref_dec
+    return ref_gta, ref_layers, ref_wig, ref_enc, ref_dec, ref_nvs
 
 
-ref_gta, ref_layers, ref_wig, ref_enc, ref_dec = import_reference()
+ref_gta, ref_layers, ref_wig, ref_enc, ref_dec, ref_nvs = import_reference()
 
 
 def gen(seed):
@@ -220,6 +221,63 @@ def module_case(name, f_dims, so2, so3, dim, depth, H, dh, B, Nq, Pq, Nk, Pk, se
     np.savez_compressed(os.path.join(OUT, f"mod_{name}.npz"), **rec)
 
 
+def srt_case(name, seed):
+    """Reference TransformingSRT (models_nvs.py:37-91) on a tiny gta_so3-style config: forward, loss of
+    trainer.py:85-134 and every parameter gradient, with the reference's own initialisation."""
+    torch.manual_seed(seed)
+    g = gen(seed)
+    dtype = torch.float64
+    f_dims = {"triv": 0, "se3": 8, "so3": 8, "so2": 8}
+    ak = attn_kwargs(f_dims, 2, 2)
+    aa = {"method": {"name": "gta", "args": ak}}
+    cfg = {"encoder": "isrt", "decoder": "isrt",
+           "encoder_kwargs": dict(dim=48, attdim=48, num_conv_blocks=3, num_att_blocks=2, heads=2, dropout=0.0,
+                                  emb=False, attn_args=aa),
+           "decoder_kwargs": dict(dim=20, num_att_blocks=1, z_dim=48, heads=2, dropout=0.0, emb="const", rmlp_dim=32,
+                                  attn_args=aa)}
+    model = ref_nvs.TransformingSRT(cfg).double()
+    B, N, Nt, HW, P = 2, 2, 2, 32, 5
+    images = torch.rand(B, N, 3, HW, HW, generator=g, dtype=dtype)
+    h = HW // 8
+    coord_in = O.patch_coords(HW, HW, 8).to(dtype)[None, None].expand(B, N, h * h, 2).contiguous()
+    extras = {"input_transforms": O.random_extrinsics(B, N, g, dtype),
+              "target_transforms": O.random_extrinsics(B, Nt, g, dtype),
+              "input_coord": coord_in, "target_coord": rand_coords(B, Nt, P, g)}
+    cam_in = torch.randn(B, N, 3, generator=g, dtype=dtype)
+    rays_in = torch.randn(B, N, HW, HW, 3, generator=g, dtype=dtype)
+    cam_t = torch.randn(B, Nt, P, 3, generator=g, dtype=dtype)
+    rays_t = torch.randn(B, Nt, P, 3, generator=g, dtype=dtype)
+    target = torch.rand(B, Nt, P, 3, generator=g, dtype=dtype)
+    ex = dict(extras)
+    pred, _ = model(images, cam_in, rays_in, cam_t, rays_t, ex)
+    pred = pred.reshape(B, Nt * P, 3)
+    loss = ((pred - target.flatten(1, 2)) ** 2).mean((1, 2))
+    loss.sum().backward()
+
+    om = O.OracleSRT(cfg).double()
+    om.load_state_dict(model.state_dict(), strict=True)
+    pred2 = om(images, cam_in, rays_in, cam_t, rays_t, dict(extras))
+    loss2 = ((pred2 - target.flatten(1, 2)) ** 2).mean((1, 2))
+    loss2.sum().backward()
+    dev = {"pred": (pred2 - pred).abs().max().item(), "loss": (loss2 - loss).abs().max().item()}
+    ref_params, or_params = dict(model.named_parameters()), dict(om.named_parameters())
+    assert list(ref_params) == list(or_params), "state-dict order / names differ"
+    for n_, p_ in ref_params.items():
+        dev["g:" + n_] = (p_.grad - or_params[n_].grad).abs().max().item()
+    worst = max(dev.values())
+    print(f"srt_{name:24s} oracle-vs-reference max dev {worst:.2e}  ({len(ref_params)} parameters, names identical)")
+    assert worst < 5e-9, dev
+    rec = {"images": images.numpy(), "cam_in": cam_in.numpy(), "rays_in": rays_in.float().numpy(), "cam_t": cam_t.numpy(),
+           "rays_t": rays_t.numpy(), "target": target.numpy(), "pred": pred.detach().numpy(),
+           "loss": loss.detach().numpy(), "psnr": ref_nvs.__dict__.get("mse2psnr", O.mse2psnr)(loss.detach()).numpy(),
+           "meta": np.array(repr(cfg))}
+    for n_, p_ in ref_params.items():
+        rec["param." + n_] = p_.detach().numpy()
+        rec["grad." + n_] = p_.grad.numpy()
+    rec.update(flat("extras.", extras))
+    np.savez_compressed(os.path.join(OUT, f"srt_{name}.npz"), **rec)
+
+
 def wigner_case():
     """Reference rotmat_to_wigner_d_matrices on random + gimbal rotations (J unpinned)."""
     g = gen(7)
@@ -291,6 +349,7 @@ if __name__ == "__main__":
                   cross=False, shared_freqs=True)
     operator_case("recompute_so2", CL, 2, 0, H=1, B=1, Nq=2, Pq=5, Nk=2, Pk=6, seed=10, cross=True,
                   recompute_so2=True)
+    srt_case("ms_tiny", seed=30)
     module_case("enc_cl", CL, 2, 0, dim=32, depth=2, H=2, dh=16, B=2, Nq=2, Pq=6, Nk=2, Pk=6, seed=20,
                 cross=False)
     module_case("dec_ms", MS, 2, 2, dim=20, depth=2, H=2, dh=24, B=1, Nq=3, Pq=7, Nk=2, Pk=5, seed=21,

@@ -138,3 +138,20 @@ def test_pipelined_kernel_owns_its_accumulator_file():
     report, problems = mod.audit()
     assert report, "no gta_fwd3_kernel instantiation found"
     assert not problems, problems
+
+
+def test_srt_wrapper_state_dict_is_reference_compatible():
+    """gta_amd.srt.TransformingSRT takes the reference's cfg and loads the reference's own state dict
+    (fixture srt_ms_tiny: parameters of the reference TransformingSRT) with strict=True."""
+    import ast
+    from tests import _golden as G
+    from gta_amd import srt
+    d, _ = G.load("srt_ms_tiny")
+    cfg = ast.literal_eval(str(np.load(G.GOLDEN + "/srt_ms_tiny.npz")["meta"]))
+    model = srt.TransformingSRT(cfg)
+    sd = {k[len("param."):]: torch.from_numpy(v).float() for k, v in d.items() if k.startswith("param.")}
+    assert list(sd) == [n for n, _ in model.named_parameters()]
+    model.load_state_dict(sd, strict=True)
+    with pytest.raises(NotImplementedError):
+        bad = dict(cfg, encoder_kwargs=dict(cfg["encoder_kwargs"], emb="ray"))
+        srt.TransformingSRT(bad)

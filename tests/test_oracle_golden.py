@@ -118,3 +118,25 @@ def test_known_answer_properties():
     out2, attn2 = O.gta_attention(q, k, v, {"triv": 24}, {}, 1.0)
     ref = torch.softmax(q @ k.transpose(-1, -2) * 24 ** -0.5, -1) @ v
     assert (out2 - ref).abs().max() < 1e-12
+
+
+def test_srt_wrapper_matches_reference():
+    """OracleSRT (encoder / decoder wrappers, gta path) against the reference TransformingSRT fixture: its own
+    weights, rendered pixels, per-sample loss, PSNR and every parameter gradient."""
+    import ast
+    import numpy as np
+    d, _ = G.load("srt_ms_tiny")
+    cfg = ast.literal_eval(str(np.load(G.GOLDEN + "/srt_ms_tiny.npz")["meta"]))
+    om = O.OracleSRT(cfg).double()
+    sd = {k[len("param."):]: torch.from_numpy(v) for k, v in d.items() if k.startswith("param.")}
+    om.load_state_dict(sd, strict=True)
+    ex = {k[len("extras."):]: torch.from_numpy(v) for k, v in d.items() if k.startswith("extras.")}
+    t = lambda n: torch.from_numpy(d[n]).double()
+    pred = om(t("images"), t("cam_in"), t("rays_in"), t("cam_t"), t("rays_t"), ex)
+    loss = ((pred - t("target").flatten(1, 2)) ** 2).mean((1, 2))
+    loss.sum().backward()
+    assert (pred - t("pred")).abs().max() < 1e-9
+    assert (loss - t("loss")).abs().max() < 1e-10
+    assert (O.mse2psnr(loss.detach()) - t("psnr")).abs().max() < 1e-8
+    for n, p in om.named_parameters():
+        assert (p.grad - t("grad." + n)).abs().max() < 1e-9, n
