@@ -155,3 +155,28 @@ def test_srt_wrapper_state_dict_is_reference_compatible():
     with pytest.raises(NotImplementedError):
         bad = dict(cfg, encoder_kwargs=dict(cfg["encoder_kwargs"], emb="ray"))
         srt.TransformingSRT(bad)
+
+
+def test_reference_checkpoint_layout_round_trip(tmp_path):
+    """A file in the reference's checkpoint layout (checkpoint.py:21-35: one state dict per module + scalars),
+    built from the reference's own SRT weights (fixture), loads into gta_amd.TransformingSRT strictly."""
+    import ast
+    from tests import _golden as G
+    from gta_amd import srt, checkpoint
+    d, _ = G.load("srt_ms_tiny")
+    cfg = ast.literal_eval(str(np.load(G.GOLDEN + "/srt_ms_tiny.npz")["meta"]))
+    sd = {k[len("param."):]: torch.from_numpy(v).float() for k, v in d.items() if k.startswith("param.")}
+    ref_file = {"encoder": {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")},
+                "decoder": {"module." + k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")},
+                "epoch_it": 3, "it": 1234, "t": 56.0, "loss_val_best": 21.5, "run_id": "abc"}
+    path = str(tmp_path / "model.pt")
+    torch.save(ref_file, path)
+    model = srt.TransformingSRT(cfg)
+    rest = checkpoint.load_checkpoint(path, encoder=model.encoder, decoder=model.decoder)
+    assert rest == {"epoch_it": 3, "it": 1234, "t": 56.0, "loss_val_best": 21.5, "run_id": "abc"}
+    for n, p in model.named_parameters():
+        assert torch.equal(p.detach(), sd[n]), n
+    out = str(tmp_path / "again.pt")
+    checkpoint.save_checkpoint(out, {"it": 1}, encoder=model.encoder, decoder=model.decoder)
+    again = torch.load(out, weights_only=False)
+    assert sorted(again) == ["decoder", "encoder", "it"] and list(again["encoder"]) == list(ref_file["encoder"])
