@@ -846,6 +846,9 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
                 }
             }
         }
+        // the tile's key-norm bound (scalar load from the top of the iteration; the K' reads are consumed, so this
+        // wait is free -- it must sit BEFORE the V' reads below or it would drain them too)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(kn_bits));
         // V' slab 0 transpose-reads fly under the softmax
         const uint32_t vbase = lds_addr(vf);
         u32x2_t v0l[DB], v0h[DB], v1l[DB], v1h[DB], v2l[DB], v2h[DB], v3l[DB], v3h[DB];
@@ -857,7 +860,6 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
         // O rescale is needed; tile 0, the masked tail tile and a violated bound take the full path.
         bf16x8_t pf[RB][2][2];
         {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(kn_bits));     // (K' reads have long been consumed)
             const float kn_j = __uint_as_float(kn_bits);
             const bool tail = has_tail && j == n_tiles - 1;
             bool need = (j == 0) || tail;
