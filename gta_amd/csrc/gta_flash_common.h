@@ -1,0 +1,169 @@
+// gta_flash_common.h -- pieces shared by the two-stage forward kernels (gta_prep.hip, gta_fwd2.hip, gta_fwd3.hip):
+// LDS / transpose-read helpers, per-view record staging, the compile-time loop, tile constants and the
+// ablation switches.  Everything has internal linkage (anonymous namespace): each .hip is its own module.
+#pragma once
+#include <type_traits>
+#include <utility>
+#include "gta_common.h"
+#include "gta_fwd_params.h"
+#include "../../include/gta_hip.h"
+
+// Ablation hooks (tools/bench_kernels.py ablate/timeline) exist only in -DGTA_ABLATE builds.
+#ifdef GTA_ABLATE
+#define GTA_DBG(bit) ((p.dbg & (bit)) != 0)
+#else
+#define GTA_DBG(bit) false
+#endif
+
+namespace {
+
+constexpr int BN = 64;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+// ds_read_b64_tr_b16 through inline asm: the builtin makes hipcc drain vmcnt(0) (it cannot prove
+// the read does not alias the LDS-DMA in flight), which would serialise the DMA ring.  The caller
+// waits with lgkmcnt(0) + sched_barrier(0) before the first use (cdna_hip_programming.md 5.7).
+template <int IMM>
+GTA_DEV u32x2_t lds_tr16_b64(uint32_t addr) {
+    u32x2_t v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(IMM));
+    return v;
+}
+// same read into the accumulator file (MFMA A operands may live there; keeps the arch VGPRs for the softmax)
+template <int IMM>
+GTA_DEV u32x2_t lds_tr16_b64_acc(uint32_t addr) {
+    u32x2_t v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=a"(v) : "v"(addr), "i"(IMM));
+    return v;
+}
+GTA_DEV uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// shared pieces
+// ------------------------------------------------------------------------------------------------
+template <int ESZ>
+GTA_DEV void gload_chunk2(const char* rowptr, int c, float* x) {
+    if (ESZ == 2) {
+        unpack8(*reinterpret_cast<const u32x4_t*>(rowptr + c * 16), x);
+    } else {
+        const f32x4_t a = *reinterpret_cast<const f32x4_t*>(rowptr + c * 32);
+        const f32x4_t b = *reinterpret_cast<const f32x4_t*>(rowptr + c * 32 + 16);
+        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+    }
+}
+template <int ESZ>
+GTA_DEV void gstore_chunk2(char* rowptr, int c, const float* x) {
+    if (ESZ == 2) {
+        *reinterpret_cast<u32x4_t*>(rowptr + c * 16) = pack8(x);
+    } else {
+        *reinterpret_cast<f32x4_t*>(rowptr + c * 32) = f32x4_t{x[0], x[1], x[2], x[3]};
+        *reinterpret_cast<f32x4_t*>(rowptr + c * 32 + 16) = f32x4_t{x[4], x[5], x[6], x[7]};
+    }
+}
+
+// q-side / k-side per-view records -> LDS, trans_coeff mask folded in (gta.py:40-44,135-141).
+// Only views n0 .. n0+cnt-1 (the ones a query tile touches) are staged, as records 0..cnt-1; the
+// global loads are issued three at a time so the prologue pays one round trip, not one per element.
+GTA_DEV int qrec_src(int e, int* kind, int* r_, int* c_) {
+    // returns the vrep offset feeding record element e, and how to mask it
+    if (e < 32) {
+        const int ee = e & 15, r = ee >> 2, c = ee & 3;
+        const int sr = (e < 16) ? c : r, sc = (e < 16) ? r : c;        // Aq = (E.m)^T, Oq = E.m
+        *kind = 0; *r_ = sr; *c_ = sc;
+        return GTA_VREP_INV + sr * 4 + sc;
+    } else if (e < GTA_QREC_D2) {
+        const int ee = e - GTA_QREC_D1, r = ee >> 2, c = ee & 3;
+        *kind = c < 3 ? 1 : 2;
+        return GTA_VREP_D1 + r * 3 + (c < 3 ? c : 0);
+    } else if (e < GTA_QREC_D1T) {
+        const int ee = e - GTA_QREC_D2, r = ee >> 3, c = ee & 7;
+        *kind = c < 5 ? 1 : 2;
+        return GTA_VREP_D2 + r * 5 + (c < 5 ? c : 0);
+    } else if (e < GTA_QREC_D2T) {
+        const int ee = e - GTA_QREC_D1T, r = ee >> 2, c = ee & 3;
+        *kind = c < 3 ? 1 : 2;
+        return GTA_VREP_D1 + (c < 3 ? c : 0) * 3 + r;
+    } else {
+        const int ee = e - GTA_QREC_D2T, r = ee >> 3, c = ee & 7;
+        *kind = c < 5 ? 1 : 2;
+        return GTA_VREP_D2 + (c < 5 ? c : 0) * 5 + r;
+    }
+}
+GTA_DEV void stage_qrec(float* qrec, const float* vrep_q, int b, int Nq, int n0, int cnt, float tc, int tid,
+                        int nthreads) {
+    const int total = cnt * GTA_QREC;
+    const float* base = vrep_q + ((long)b * Nq + n0) * GTA_VREP_STRIDE;
+    for (int i0 = tid; i0 < total; i0 += 3 * nthreads) {
+        float val[3];
+        int kind[3], rr[3], cc[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int i = i0 + u * nthreads;
+            kind[u] = 3;
+            if (i < total) {
+                const int n = i / GTA_QREC, e = i - n * GTA_QREC;
+                val[u] = base[(long)n * GTA_VREP_STRIDE + qrec_src(e, &kind[u], &rr[u], &cc[u])];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int i = i0 + u * nthreads;
+            if (kind[u] == 3) continue;
+            float v = val[u];
+            if (kind[u] == 0) v *= (rr[u] == 3) ? (cc[u] == 3 ? 1.f : 0.f) : (cc[u] == 3 ? tc : 1.f);
+            else if (kind[u] == 2) v = 0.f;
+            qrec[i] = v;
+        }
+    }
+}
+GTA_DEV void stage_krec(float* krec, const float* vrep_k, int b, int Nk, float tc, int tid, int nthreads) {
+    for (int i = tid; i < Nk * GTA_KREC; i += nthreads) {
+        const int n = i / GTA_KREC, e = i - n * GTA_KREC;
+        const float* src = vrep_k + ((long)b * Nk + n) * GTA_VREP_STRIDE;
+        float val = 0.f;
+        if (e < 16) {
+            const int r = e >> 2, c = e & 3;
+            const float m = (r == 3) ? (c == 3 ? 1.f : 0.f) : (c == 3 ? tc : 1.f);
+            val = src[GTA_VREP_REP + e] * m;
+        } else if (e < GTA_KREC_D2) {
+            const int ee = e - GTA_KREC_D1, r = ee >> 2, c = ee & 3;
+            val = c < 3 ? src[GTA_VREP_D1 + r * 3 + c] : 0.f;
+        } else {
+            const int ee = e - GTA_KREC_D2, r = ee >> 3, c = ee & 7;
+            val = c < 5 ? src[GTA_VREP_D2 + r * 5 + c] : 0.f;
+        }
+        krec[i] = val;
+    }
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{})
+template <class F, int... Is>
+GTA_DEV void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+GTA_DEV void static_for(F&& f) { static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
+
+// GTA_ABL: ablation mask for timing experiments only (results are WRONG with any bit set):
+//   1 no exp/sum   2 no pack   4 no row max / decision   8 no V' reads   16 no K' reads   32 no DMA in the loop
+//   64 no QK^T MFMAs   128 no PV MFMAs   256 no barrier
+#ifndef GTA_ABL
+#define GTA_ABL 0
+#endif
+constexpr int ABL = GTA_ABL;
+constexpr int NSTAGE = 3;
+// Skewed tile loop in the 128-row kernel (QK^T of tile j+1 beside the softmax of tile j).  Measured on MI355X
+// (MSN encoder, B=32): 214 us vs 212 us un-skewed at 20 key tiles, 363 vs 372 us at 40, 105 vs 96 us at 5 --
+// the softmax VALU is already hidden by the co-resident wave (ablation: removing every exp saves 2 %), what is
+// left is MFMA + LDS-DMA issue + the per-workgroup prologue/epilogue.  Off by default (it also spills ~14 VGPRs
+// outside the loop at dh = 96); build with -DGTA_PIPE1=1 to select it.
+#ifndef GTA_PIPE1
+#define GTA_PIPE1 0
+#endif
+constexpr bool PIPE1 = GTA_PIPE1 != 0;
+constexpr float DEFER_THR = 8.0f;      // (pipelined kernel) running max moves when a row's tile max exceeds it by this
+constexpr float BOUND_THR = 96.0f;     // exp2 arguments stay below this without looking at the scores
+
+}  // namespace

@@ -1,7 +1,7 @@
 """Audit of the asm-owned accumulator file of the pipelined flash kernel (gta_fwd3_kernel).
 
 The kernel addresses a[16:255] by literal number inside asm statements; hipcc does not know and may park
-values of its own in AGPRs.  This script compiles gta_fwd2.hip to assembly with the Makefile's flags and
+values of its own in AGPRs.  This script compiles gta_fwd3.hip to assembly with the Makefile's flags and
 checks, for every instantiation: no scratch, no VGPR spills, and every compiler-generated AGPR access
 (outside ;;#ASMSTART/;;#ASMEND) stays below a16.  Exit code 0 = clean.  (cdna_hip_programming.md 5.7 item 4)
 """
@@ -16,9 +16,9 @@ RESERVED = 16
 
 
 def audit(extra_flags=()):
-    src = os.path.join(ROOT, "gta_amd", "csrc", "gta_fwd2.hip")
+    src = os.path.join(ROOT, "gta_amd", "csrc", "gta_fwd3.hip")
     with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "fwd2.s")
+        out = os.path.join(td, "fwd3.s")
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
                *extra_flags, src, "-o", out]
         subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
