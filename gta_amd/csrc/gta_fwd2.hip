@@ -23,6 +23,7 @@
 // prefetched) ran the MFMA-only stretches at full rate (355 cycles / 12 MFMAs) but gained nothing
 // end to end (280 us vs 243 us for two 4-wave workgroups per CU): LDS-read issue, LDS-DMA issue
 // (~100+ cycles per 1-KiB piece for the issuing wave) and two barriers per tile ate the overlap.
+#include <cstdlib>
 #include "gta_flash_common.h"
 
 int gta_prep_dispatch(const GtaFwdParams& p, int dhp, int esz, hipStream_t stream);                  // gta_prep.hip
@@ -667,8 +668,15 @@ int launch_fwd2(const GtaFwdParams& p, hipStream_t stream) {
         attr_set = true;
     }
     const long n_wg = (long)p.B * p.H * p.n_qtiles;
-    hipLaunchKernelGGL((gta_fwd2_kernel<DHP, ESZ, RB, LAYOUT>), dim3((unsigned)n_wg), dim3(256), S::total(p.vrep_q ? p.Nq : 0),
-                       stream, p);
+    int lds = S::total(p.vrep_q ? p.Nq : 0);
+#ifdef GTA_ABLATE
+    if (const char* e = getenv("GTA_LDS_PAD")) {        // occupancy experiment: inflate LDS so fewer workgroups share a CU
+        lds += atoi(e);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gta_fwd2_kernel<DHP, ESZ, RB, LAYOUT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    }
+#endif
+    hipLaunchKernelGGL((gta_fwd2_kernel<DHP, ESZ, RB, LAYOUT>), dim3((unsigned)n_wg), dim3(256), lds, stream, p);
     return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH;
 }
 

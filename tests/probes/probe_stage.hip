@@ -29,6 +29,20 @@ __global__ __launch_bounds__(256, 2) void probe(const char* __restrict__ src, ui
             for (int i = 0; i < 6; ++i)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + i * 1024),
                                                  (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+        } else if (MODE == 3) {
+            // the same 6 DMA pieces, one after every 4th MFMA
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, c1, 0, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + k * 1024),
+                                                 (__attribute__((address_space(3))) void*)(dst + k * 1024), 16, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, c2, 0, 0, 0);
+                c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, c3, 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            continue;
         } else if (MODE == 2) {
             // write last iteration's registers, then refill them
 #pragma unroll
@@ -72,5 +86,6 @@ int main() {
     run<0>("24 MFMAs + barrier", src, d, sink);
     run<1>("+ 6 x LDS-DMA (global_load_lds_dwordx4)", src, d, sink);
     run<2>("+ 6 x global_load_dwordx4 + 6 x ds_write_b128", src, d, sink);
+    run<3>("+ 6 x LDS-DMA interleaved with the MFMAs", src, d, sink);
     return 0;
 }
