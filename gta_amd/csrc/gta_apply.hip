@@ -115,6 +115,120 @@ __global__ void gta_apply_kernel(const ApplyParams p) {
     if (p.key_bias) p.key_bias[((long)b * p.H + h) * p.bias_pitch + t] = -0.5f * p.bias_scale * sq;
 }
 
+// Adjoint of the above: dx = M^T dy for the block-diagonal M of `mode`, plus (optionally) this row's contribution
+// to d loss / d trans_coeff (the entries of the masked se3 matrices that carry c, gta.py:40-44) -- one float per row,
+// summed by the caller in a fixed order.  Under euclid the key side may also carry d key_bias: the bias is
+// -0.5 s |y|^2, so dy_eff = dy - s * dbias * y with y recomputed from x.
+struct ApplyBwdParams {
+    ApplyParams f;                 // x = forward input, y unused
+    const void* dy; void* dx;
+    long dy_sb, dy_sh, dy_st, dx_sb, dx_sh, dx_st;
+    const float* dbias;            // [B,H,bias_pitch] or null
+    float* dtc_rows;               // [B,H,T] or null
+};
+
+template <int ESZ>
+__global__ void gta_apply_bwd_kernel(const ApplyBwdParams q) {
+    const ApplyParams& p = q.f;
+    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)p.B * p.H * p.T;
+    if (row >= total) return;
+    const int t = (int)(row % p.T);
+    const int h = (int)((row / p.T) % p.H);
+    const int b = (int)(row / ((long)p.T * p.H));
+    const char* x = (const char*)p.x + ((long)b * p.x_sb + (long)h * p.x_sh + (long)t * p.x_st) * ESZ;
+    const char* dy = (const char*)q.dy + ((long)b * q.dy_sb + (long)h * q.dy_sh + (long)t * q.dy_st) * ESZ;
+    char* dx = (char*)q.dx + ((long)b * q.dx_sb + (long)h * q.dx_sh + (long)t * q.dx_st) * ESZ;
+    const float tc = p.trans_coeff ? *p.trans_coeff : 1.0f;
+    const int n = t / p.P;
+    const float* vr = p.vrep ? p.vrep + ((long)b * p.N + n) * GTA_VREP_STRIDE : nullptr;
+    const float kb = q.dbias ? -p.bias_scale * q.dbias[((long)b * p.H + h) * p.bias_pitch + t] : 0.f;   // d/dy of the bias = kb * y
+    float dc = 0.f;
+    int ch = 0;
+    for (int i = 0; i < p.d_triv; ++i, ++ch) st<ESZ>(dx, ch, ld<ESZ>(dy, ch) + kb * ld<ESZ>(x, ch));
+    if (p.d_se3 > 0) {
+        float M[16];                                     // the forward's matrix, row-major (y = M x)
+        const bool use_inv_slot = (p.mode == 2) || (p.mode == 0 && !p.euclid);
+        const float* src = vr + (use_inv_slot ? GTA_VREP_INV : GTA_VREP_REP);
+        for (int r = 0; r < 4; ++r)
+            for (int c = 0; c < 4; ++c) {
+                const float m = (r == 3) ? (c == 3 ? 1.f : 0.f) : (c == 3 ? tc : 1.f);
+                const float v = src[r * 4 + c] * m;
+                if (p.mode == 0 && !p.euclid) M[c * 4 + r] = v; else M[r * 4 + c] = v;
+            }
+        if (p.euclid) {
+            for (int blk = 0; blk < p.d_se3 / 3; ++blk, ch += 3) {
+                const float a = ld<ESZ>(x, ch), bb = ld<ESZ>(x, ch + 1), c = ld<ESZ>(x, ch + 2);
+                float g[3];
+                for (int r = 0; r < 3; ++r) {
+                    const float y = M[r * 4] * a + M[r * 4 + 1] * bb + M[r * 4 + 2] * c + M[r * 4 + 3];
+                    g[r] = ld<ESZ>(dy, ch + r) + kb * y;
+                    dc += g[r] * src[r * 4 + 3];                            // y_r = ... + c * t_r
+                }
+                for (int col = 0; col < 3; ++col) st<ESZ>(dx, ch + col, M[col] * g[0] + M[4 + col] * g[1] + M[8 + col] * g[2]);
+            }
+        } else {
+            for (int blk = 0; blk < p.d_se3 / 4; ++blk, ch += 4) {
+                float xi[4], g[4];
+                for (int i = 0; i < 4; ++i) { xi[i] = ld<ESZ>(x, ch + i); g[i] = ld<ESZ>(dy, ch + i); }
+                if (kb != 0.f)
+                    for (int r = 0; r < 4; ++r)
+                        g[r] += kb * (M[r * 4] * xi[0] + M[r * 4 + 1] * xi[1] + M[r * 4 + 2] * xi[2] + M[r * 4 + 3] * xi[3]);
+                for (int col = 0; col < 4; ++col)
+                    st<ESZ>(dx, ch + col, M[col] * g[0] + M[4 + col] * g[1] + M[8 + col] * g[2] + M[12 + col] * g[3]);
+                if (p.mode == 0) dc += g[3] * (src[3] * xi[0] + src[7] * xi[1] + src[11] * xi[2]);       // y_3 = sum_c E[c][3] c x_c + x_3
+                else             dc += (g[0] * src[3] + g[1] * src[7] + g[2] * src[11]) * xi[3];           // y_r = ... + M[r][3] c x_3
+            }
+        }
+    }
+    if (p.d_so3 > 0) {
+        const int tot = p.L >= 2 ? 8 : 3;
+        for (int gI = 0; gI < p.d_so3 / tot; ++gI) {
+            for (int l = 1; l <= p.L; ++l) {
+                const int dim = 2 * l + 1;
+                const float* D = vr + (l == 1 ? GTA_VREP_D1 : GTA_VREP_D2);
+                float in[5];
+                for (int i = 0; i < dim; ++i) in[i] = ld<ESZ>(dy, ch + i);
+                for (int r = 0; r < dim; ++r) {
+                    float v = kb * ld<ESZ>(x, ch + r);                     // D orthogonal: D^T (kb D x) = kb x
+                    for (int c = 0; c < dim; ++c) v += (p.mode == 2 ? D[r * dim + c] : D[c * dim + r]) * in[c];
+                    st<ESZ>(dx, ch + r, v);
+                }
+                ch += dim;
+            }
+        }
+    }
+    if (p.d_so2 > 0) {
+        const int nblk = p.d_so2 / 2;
+        const float* cs = p.cs + ((long)b * p.T + t) * 2 * nblk;
+        for (int blk = 0; blk < nblk; ++blk, ch += 2) {
+            const float c = cs[2 * blk], s = (p.mode == 2 ? -1.f : 1.f) * cs[2 * blk + 1];
+            const float a = ld<ESZ>(dy, ch), bb = ld<ESZ>(dy, ch + 1);
+            st<ESZ>(dx, ch, c * a + s * bb + kb * ld<ESZ>(x, ch)); st<ESZ>(dx, ch + 1, -s * a + c * bb + kb * ld<ESZ>(x, ch + 1));
+        }
+    }
+    if (p.d_t2 > 0) {
+        const float cx = p.coord[((long)b * p.T + t) * 2], cy = p.coord[((long)b * p.T + t) * 2 + 1];
+        for (int blk = 0; blk < p.d_t2 / 3; ++blk, ch += 3) {
+            float a = ld<ESZ>(dy, ch), bb = ld<ESZ>(dy, ch + 1), c = ld<ESZ>(dy, ch + 2);
+            if (kb != 0.f) {                                               // y = T x recomputed for the bias term
+                const float xa = ld<ESZ>(x, ch), xb = ld<ESZ>(x, ch + 1), xc = ld<ESZ>(x, ch + 2);
+                float y0, y1, y2;
+                if (p.mode == 0)      { y0 = xa - cx * xc; y1 = xb - cy * xc; y2 = xc; }
+                else if (p.mode == 1) { y0 = xa; y1 = xb; y2 = cx * xa + cy * xb + xc; }
+                else                  { y0 = xa; y1 = xb; y2 = xc - cx * xa - cy * xb; }
+                a += kb * y0; bb += kb * y1; c += kb * y2;
+            }
+            float v0, v1, v2;
+            if (p.mode == 0)      { v0 = a; v1 = bb; v2 = c - cx * a - cy * bb; }
+            else if (p.mode == 1) { v0 = a + cx * c; v1 = bb + cy * c; v2 = c; }
+            else                  { v0 = a - cx * c; v1 = bb - cy * c; v2 = c; }
+            st<ESZ>(dx, ch, v0); st<ESZ>(dx, ch + 1, v1); st<ESZ>(dx, ch + 2, v2);
+        }
+    }
+    if (q.dtc_rows) q.dtc_rows[row] = dc;
+}
+
 }  // namespace
 
 extern "C" int gta_rep_apply(const GtaAttnDesc* d, int32_t mode, const void* x, const int64_t* x_stride,
@@ -147,5 +261,43 @@ extern "C" int gta_rep_apply(const GtaAttnDesc* d, int32_t mode, const void* x, 
     const unsigned nb = (unsigned)((total + th - 1) / th);
     if (p.esz == 2) hipLaunchKernelGGL(gta_apply_kernel<2>, dim3(nb), dim3(th), 0, (hipStream_t)stream, p);
     else            hipLaunchKernelGGL(gta_apply_kernel<4>, dim3(nb), dim3(th), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH;
+}
+
+extern "C" int gta_rep_apply_bwd(const GtaAttnDesc* d, int32_t mode, const void* x, const int64_t* x_stride,
+                                 const void* dy, const int64_t* dy_stride, const float* vrep, const float* cs,
+                                 const float* coord, const float* trans_coeff, const float* dkey_bias, float bias_scale,
+                                 int64_t bias_pitch, void* dx, const int64_t* dx_stride, float* dtc_rows, void* stream) {
+    if (!d || !x || !dy || !dx || !x_stride || !dy_stride || !dx_stride || mode < 0 || mode > 2) return GTA_E_BADARG;
+    if (d->abi_version != GTA_ABI_VERSION) return GTA_E_BADARG;
+    if (d->d_triv + d->d_se3 + d->d_so3 + d->d_so2 + d->d_t2 != d->dh) return GTA_E_LAYOUT;
+    const bool euclid = (d->flags & GTA_FLAG_EUCLID) != 0;
+    if (d->d_se3 % (euclid ? 3 : 4) || d->d_so2 % 2 || d->d_t2 % 3) return GTA_E_LAYOUT;
+    if (d->d_so3 > 0 && (d->so3_degree < 1 || d->so3_degree > 2 || d->d_so3 % (d->so3_degree == 2 ? 8 : 3))) return GTA_E_UNSUPPORTED;
+    if ((d->d_se3 > 0 || d->d_so3 > 0) && !vrep) return GTA_E_BADARG;
+    if (d->d_so2 > 0 && !cs) return GTA_E_BADARG;
+    if (d->d_t2 > 0 && !coord) return GTA_E_BADARG;
+    ApplyBwdParams q;
+    ApplyParams& p = q.f;
+    p.x = x; p.y = nullptr;
+    p.x_sb = x_stride[0]; p.x_sh = x_stride[1]; p.x_st = x_stride[2];
+    p.y_sb = p.y_sh = p.y_st = 0;
+    p.vrep = vrep; p.cs = cs; p.coord = coord; p.trans_coeff = trans_coeff;
+    p.key_bias = nullptr; p.bias_scale = bias_scale; p.bias_pitch = bias_pitch;
+    p.B = d->B; p.H = d->H;
+    p.T = mode == 1 ? d->Tk : d->Tq;
+    p.N = mode == 1 ? d->Nk : d->Nq;
+    p.P = p.T / p.N;
+    p.d_triv = d->d_triv; p.d_se3 = d->d_se3; p.d_so3 = d->d_so3; p.d_so2 = d->d_so2; p.d_t2 = d->d_t2; p.L = d->so3_degree;
+    p.mode = mode; p.euclid = euclid ? 1 : 0; p.esz = d->dtype == GTA_DTYPE_BF16 ? 2 : 4;
+    q.dy = dy; q.dx = dx;
+    q.dy_sb = dy_stride[0]; q.dy_sh = dy_stride[1]; q.dy_st = dy_stride[2];
+    q.dx_sb = dx_stride[0]; q.dx_sh = dx_stride[1]; q.dx_st = dx_stride[2];
+    q.dbias = dkey_bias; q.dtc_rows = dtc_rows;
+    const long total = (long)p.B * p.H * p.T;
+    const int th = 256;
+    const unsigned nb = (unsigned)((total + th - 1) / th);
+    if (p.esz == 2) hipLaunchKernelGGL(gta_apply_bwd_kernel<2>, dim3(nb), dim3(th), 0, (hipStream_t)stream, q);
+    else            hipLaunchKernelGGL(gta_apply_bwd_kernel<4>, dim3(nb), dim3(th), 0, (hipStream_t)stream, q);
     return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH;
 }

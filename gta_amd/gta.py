@@ -184,44 +184,126 @@ class _GtaAttn(torch.autograd.Function):
         return dq, dk, dv, dtc, None, None, None, None, None, None, None
 
 
+class _GenericAttn(torch.autograd.Function):
+    """Ablation layouts the fused kernels refuse (t2 slab, so3 degree 1, unaligned slabs, euclid similarity):
+    generic rho-apply kernels (gta_rep_apply) around the plain attention kernel, and for the backward their
+    adjoints (gta_rep_apply_bwd) around the fused backward on an identity layout."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, trans_coeff, tau, cfg, packed):
+        f_dims, so3_degree, scale, v_transform, euclid = cfg
+        dt = q.dtype
+        if dt not in (torch.float32, torch.bfloat16):
+            raise native.GtaError(f"unsupported dtype {dt}")
+        k, v = k.to(dt), v.to(dt)
+        B, H, Tq, dh = q.shape
+        Tk = k.shape[2]
+        Nq, Nk = _views(f_dims, packed, q, k)
+        flags = (native.FLAG_V_TRANSFORM if v_transform else 0) | (native.FLAG_EUCLID if euclid else 0)
+        dhp = (dh + 7) // 8 * 8                                    # the attention kernel works on 8-channel chunks
+        mk = lambda T: torch.zeros(B, T, H, dhp, device=q.device, dtype=dt).permute(0, 2, 1, 3)
+        qp, kp, vp, op = mk(Tq), mk(Tk), mk(Tk), mk(Tq)
+        out = torch.empty(B, Tq, H, dh, device=q.device, dtype=dt).permute(0, 2, 1, 3)
+        desc = native.make_desc(q, k, v, out, f_dims, so3_degree, Nq, Nk, scale, flags)
+        tc = trans_coeff.detach().float().reshape(-1) if torch.is_tensor(trans_coeff) else None
+        ta = tau.detach().float().reshape(-1) if torch.is_tensor(tau) else None
+        pitch = (Tk + 63) // 64 * 64
+        kbias = torch.zeros(B, H, pitch, device=q.device, dtype=torch.float32) if euclid else None
+        vq, vk = packed.get("vrep_q"), packed.get("vrep_k")
+        native.rep_apply(desc, 0, q, vq, packed.get("cs_q"), packed.get("coord_q"), tc, qp[..., :dh])
+        native.rep_apply(desc, 1, k, vk, packed.get("cs_k"), packed.get("coord_k"), tc, kp[..., :dh], kbias, scale)
+        if v_transform:
+            native.rep_apply(desc, 1, v, vk, packed.get("cs_k"), packed.get("coord_k"), tc, vp[..., :dh])
+        else:
+            vp[..., :dh] = v
+        pdesc = native.make_desc(qp, kp, vp, op, {"triv": dhp}, 0, 1, 1, scale, 0)
+        lse = torch.empty(B, H, Tq, device=q.device, dtype=torch.float32)
+        native.attn_fwd_plain(pdesc, qp, kp, vp, kbias, ta, op, lse)
+        if v_transform:
+            native.rep_apply(desc, 2, op[..., :dh], vq, packed.get("cs_q"), packed.get("coord_q"), tc, out)
+        else:
+            out.copy_(op[..., :dh])
+        ctx.cfg, ctx.packed, ctx.flags = cfg, packed, flags
+        ctx.tc_meta = None if not torch.is_tensor(trans_coeff) else (trans_coeff.shape, trans_coeff.dtype)
+        ctx.save_for_backward(q, k, v, qp, kp, vp, op, lse, tc, ta)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import backward as _bw
+        q, k, v, qp, kp, vp, op, lse, tc, ta = ctx.saved_tensors
+        f_dims, so3_degree, scale, v_transform, euclid = ctx.cfg
+        packed = ctx.packed
+        if ta is not None and ctx.needs_input_grad[4]:
+            raise native.GtaError("gradient w.r.t. the adjustable softmax temperature is not implemented")
+        dt = q.dtype
+        B, H, Tq, dh = q.shape
+        Tk = k.shape[2]
+        dhp = qp.shape[-1]
+        Nq, Nk = _views(f_dims, packed, q, k)
+        desc = native.make_desc(q, k, v, q, f_dims, so3_degree, Nq, Nk, scale, ctx.flags)
+        vq, vk = packed.get("vrep_q"), packed.get("vrep_k")
+        mk = lambda T, d=dhp: torch.zeros(B, T, H, d, device=q.device, dtype=dt).permute(0, 2, 1, 3)
+        rows = lambda T: torch.zeros(B, H, T, device=q.device, dtype=torch.float32)
+        need_tc = f_dims.get("se3", 0) > 0 and ctx.tc_meta is not None
+        dout = dout.to(dt)
+        # o = rho2(o~)  ->  do~ = rho2^T do
+        dop = mk(Tq)
+        r_o = rows(Tq) if need_tc else None
+        if v_transform:
+            native.rep_apply_bwd(desc, 2, op[..., :dh], dout, vq, packed.get("cs_q"), packed.get("coord_q"), tc,
+                                 dop[..., :dh], r_o)
+        else:
+            dop[..., :dh] = dout
+        # plain attention backward on the padded identity layout.  euclid_sim: the key bias -s|k'|^2/2 of the forward
+        # is carried by two spare channels, q' = (.., 1, 1), k' = (.., hi, lo) with hi + lo = -|k'|^2/2 split so that
+        # bf16 keeps it to 2^-16 -- the same logits, no bias operand in the backward kernels; the gradient of the
+        # bias comes back as dk'[hi channel] and is folded in by the adjoint below.
+        dbias = None
+        if euclid:
+            dhp2 = (dh + 2 + 31) // 32 * 32
+            grow = lambda x_, T: torch.cat([x_[..., :dh], torch.zeros(B, H, T, dhp2 - dh, device=q.device, dtype=dt)], -1)
+            qp, kp, vp, op, dop = grow(qp, Tq), grow(kp, Tk), grow(vp, Tk), grow(op, Tq), grow(dop, Tq)
+            bias = -0.5 * kp[..., :dh].float().pow(2).sum(-1)                         # [B,H,Tk]
+            hi = bias.to(dt)
+            qp[..., dh:dh + 2] = 1.0
+            kp[..., dh] = hi
+            kp[..., dh + 1] = (bias - hi.float()).to(dt)
+            as_rows = lambda x_: x_.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)   # [B,T,H,d] memory like the kernels' outputs
+            qp, kp, vp, op, dop = as_rows(qp), as_rows(kp), as_rows(vp), as_rows(op), as_rows(dop)
+            dhp = dhp2
+        pcfg = ({"triv": dhp}, 0, 1, 1, scale, 0)
+        dqp, dkp, dvp, _ = _bw.attn_bwd(pcfg, qp, kp, vp, op, dop, lse, None, ta, None, None, None, None)
+        if euclid:
+            pitch = (Tk + 63) // 64 * 64
+            dbias = torch.zeros(B, H, pitch, device=q.device, dtype=torch.float32)
+            dbias[..., :Tk] = dkp[..., dh].float()
+        dq, dk, dv = mk(Tq, dh), mk(Tk, dh), mk(Tk, dh)
+        r_q, r_k, r_v = (rows(Tq), rows(Tk), rows(Tk)) if need_tc else (None, None, None)
+        native.rep_apply_bwd(desc, 0, q, dqp[..., :dh], vq, packed.get("cs_q"), packed.get("coord_q"), tc, dq, r_q)
+        native.rep_apply_bwd(desc, 1, k, dkp[..., :dh], vk, packed.get("cs_k"), packed.get("coord_k"), tc, dk, r_k,
+                             dkey_bias=dbias, bias_scale=1.0)
+        if v_transform:
+            native.rep_apply_bwd(desc, 1, v, dvp[..., :dh], vk, packed.get("cs_k"), packed.get("coord_k"), tc, dv, r_v)
+        else:
+            dv.copy_(dvp[..., :dh])
+            r_v = None
+        dtc = None
+        if need_tc:
+            tot = r_q.sum(dtype=torch.float64) + r_k.sum(dtype=torch.float64)
+            if r_v is not None:
+                tot = tot + r_v.sum(dtype=torch.float64)
+            if r_o is not None and v_transform:
+                tot = tot + r_o.sum(dtype=torch.float64)
+            dtc = tot.to(ctx.tc_meta[1]).reshape(ctx.tc_meta[0])
+        return dq, dk, dv, dtc, None, None, None
+
+
 def _generic_forward(q, k, v, f_dims, packed, so3_degree, trans_coeff, tau, scale, v_transform, euclid):
-    """Ablation layouts the fused kernels refuse (t2 slab, euclid similarity, so3 degree 1, unaligned
-    slabs): generic rho-apply kernels around the plain attention kernel.  Forward only."""
-    if any(t is not None and torch.is_tensor(t) and t.requires_grad and torch.is_grad_enabled()
-           for t in (q, k, v, trans_coeff)):
-        raise native.GtaError("backward is not built for this f_dims layout / euclid_sim (forward-only generic path)")
-    dt = q.dtype
-    if dt not in (torch.float32, torch.bfloat16):
-        raise native.GtaError(f"unsupported dtype {dt}")
-    k, v = k.to(dt), v.to(dt)
-    B, H, Tq, dh = q.shape
-    Tk = k.shape[2]
-    Nq, Nk = _views(f_dims, packed, q, k)
-    flags = (native.FLAG_V_TRANSFORM if v_transform else 0) | (native.FLAG_EUCLID if euclid else 0)
-    dhp = (dh + 7) // 8 * 8                                    # the attention kernel works on 8-channel chunks
-    mk = lambda T: torch.zeros(B, T, H, dhp, device=q.device, dtype=dt).permute(0, 2, 1, 3)
-    qp, kp, vp, op = mk(Tq), mk(Tk), mk(Tk), mk(Tq)
-    out = torch.empty(B, Tq, H, dh, device=q.device, dtype=dt).permute(0, 2, 1, 3)
-    desc = native.make_desc(q, k, v, out, f_dims, so3_degree, Nq, Nk, scale, flags)
-    tc = trans_coeff.detach().float().reshape(-1) if torch.is_tensor(trans_coeff) else None
-    ta = tau.detach().float().reshape(-1) if torch.is_tensor(tau) else None
-    pitch = (Tk + 63) // 64 * 64
-    kbias = torch.zeros(B, H, pitch, device=q.device, dtype=torch.float32) if euclid else None
-    vq, vk = packed.get("vrep_q"), packed.get("vrep_k")
-    native.rep_apply(desc, 0, q, vq, packed.get("cs_q"), packed.get("coord_q"), tc, qp[..., :dh])
-    native.rep_apply(desc, 1, k, vk, packed.get("cs_k"), packed.get("coord_k"), tc, kp[..., :dh], kbias, scale)
-    if v_transform:
-        native.rep_apply(desc, 1, v, vk, packed.get("cs_k"), packed.get("coord_k"), tc, vp[..., :dh])
-    else:
-        vp[..., :dh] = v
-    pdesc = native.make_desc(qp, kp, vp, op, {"triv": dhp}, 0, 1, 1, scale, 0)
-    lse = torch.empty(B, H, Tq, device=q.device, dtype=torch.float32)
-    native.attn_fwd_plain(pdesc, qp, kp, vp, kbias, ta, op, lse)
-    if v_transform:
-        native.rep_apply(desc, 2, op[..., :dh], vq, packed.get("cs_q"), packed.get("coord_q"), tc, out)
-    else:
-        out.copy_(op[..., :dh])
-    return out
+    """Generic path entry (forward + backward through _GenericAttn)."""
+    tc = trans_coeff if torch.is_tensor(trans_coeff) else None
+    ta = tau if torch.is_tensor(tau) else None
+    return _GenericAttn.apply(q, k, v, tc, ta, (f_dims, so3_degree, scale, v_transform, euclid), packed)
 
 
 def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: int = 0,
@@ -254,15 +336,15 @@ def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: 
     if kv_mode == "fused" or not use_dma:
         flags |= native.FLAG_FUSED_KV
     Nq, Nk = _views(f_dims, packed, q, k)
+    if isinstance(trans_coeff, (int, float)):
+        trans_coeff = torch.tensor([float(trans_coeff)], device=q.device, dtype=torch.float32)
+    if isinstance(tau, (int, float)):
+        tau = None if float(tau) == 1.0 else torch.tensor([float(tau)], device=q.device, dtype=torch.float32)
     if q.is_cuda and not pretransformed:
         probe = native.make_desc(q, k, v, q, f_dims, so3_degree, Nq, Nk, scale, flags)
         if native.attn_fwd_supported(probe) == -3:       # GTA_E_UNSUPPORTED: valid request, no fused kernel
             return _generic_forward(q, k, v, f_dims, packed, so3_degree, trans_coeff, tau, scale, v_transform, euclid)
     cfg = ({k_: int(v_) for k_, v_ in f_dims.items()}, int(so3_degree), Nq, Nk, float(scale), flags)
-    if isinstance(trans_coeff, (int, float)):
-        trans_coeff = torch.tensor([float(trans_coeff)], device=q.device, dtype=torch.float32)
-    if isinstance(tau, (int, float)):
-        tau = None if float(tau) == 1.0 else torch.tensor([float(tau)], device=q.device, dtype=torch.float32)
     return _GtaAttn.apply(q, k, v, trans_coeff, tau, None, cfg, packed.get("vrep_q"), packed.get("vrep_k"),
                           packed.get("cs_q"), packed.get("cs_k"))
 

@@ -31,7 +31,7 @@ MAX_VIEWS = 16
 
 # every symbol include/gta_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (
-    "gta_build_view_reps", "gta_build_so2_table", "gta_build_reps", "gta_attn_fwd", "gta_attn_fwd_supported",
+    "gta_build_view_reps", "gta_build_so2_table", "gta_build_reps", "gta_rep_apply_bwd", "gta_attn_fwd", "gta_attn_fwd_supported",
     "gta_attn_fwd_launch_info", "gta_attn_fwd_workspace_bytes", "gta_attn_bwd", "gta_attn_bwd_workspace_bytes",
     "gta_rep_apply", "gta_attn_fwd_plain",
     "gta_strerror", "gta_abi_version", "gta_sizeof_attn_desc",
@@ -76,6 +76,9 @@ def lib():
             raise GtaError("GtaAttnDesc layout mismatch between gta_hip.h and gta_amd/native.py")
         L.gta_build_view_reps.argtypes = [c_void_p, c_int32, c_int32, c_void_p, c_void_p]
         L.gta_build_so2_table.argtypes = [c_void_p, c_int32, c_int32, c_float, c_float, c_int32, c_void_p, c_void_p]
+        L.gta_rep_apply_bwd.argtypes = [ctypes.POINTER(GtaAttnDesc), c_int32, c_void_p, ctypes.POINTER(c_int64), c_void_p,
+                                        ctypes.POINTER(c_int64), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                        c_int64, c_void_p, ctypes.POINTER(c_int64), c_void_p, c_void_p]
         L.gta_build_reps.argtypes = [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_float, c_float,
                                      c_int32, c_void_p, c_void_p]
         L.gta_attn_fwd.argtypes = [ctypes.POINTER(GtaAttnDesc)] + [c_void_p] * 12 + [c_int64, c_void_p]
@@ -224,6 +227,19 @@ def rep_apply(desc: GtaAttnDesc, mode: int, x, vrep, cs, coord, trans_coeff, y, 
     check(lib().gta_rep_apply(ctypes.byref(desc), int(mode), _ptr(x), xs, _ptr(vrep), _ptr(cs), _ptr(coord),
                               _ptr(trans_coeff), _ptr(y), ys, _ptr(key_bias), float(bias_scale),
                               0 if key_bias is None else key_bias.shape[-1], _stream()), "gta_rep_apply")
+
+
+def rep_apply_bwd(desc: GtaAttnDesc, mode: int, x, dy, vrep, cs, coord, trans_coeff, dx, dtc_rows=None, dkey_bias=None,
+                  bias_scale=0.0):
+    """Adjoint of rep_apply(mode): dx = M^T dy; dtc_rows [B,H,T] receives per-row d trans_coeff terms."""
+    _require_cuda(x, dy, dx)
+    xs = (c_int64 * 3)(*x.stride()[:3])
+    ys = (c_int64 * 3)(*dy.stride()[:3])
+    ds = (c_int64 * 3)(*dx.stride()[:3])
+    check(lib().gta_rep_apply_bwd(ctypes.byref(desc), int(mode), _ptr(x), xs, _ptr(dy), ys, _ptr(vrep), _ptr(cs),
+                                  _ptr(coord), _ptr(trans_coeff), _ptr(dkey_bias), float(bias_scale),
+                                  0 if dkey_bias is None else dkey_bias.shape[-1], _ptr(dx), ds, _ptr(dtc_rows),
+                                  _stream()), "gta_rep_apply_bwd")
 
 
 def attn_fwd_plain(desc: GtaAttnDesc, q, k, v, key_bias, tau, out, lse):

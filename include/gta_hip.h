@@ -158,7 +158,7 @@ int gta_attn_bwd(const GtaAttnDesc* desc,
 /* -------------------------------------------------------------------------------------------
  * Generic path for the reference's ablations (any f_dims layout): t2 slab (gta.py:221-238,272-274),
  * euclid similarity (GTA_FLAG_EUCLID; gta.py:146-156,251-253 + EuclidAttnFn layers.py:213-224),
- * so3 of degree 1, unaligned slabs.  Forward only.  Usage: q' = apply(mode 0), k' = apply(mode 1)
+ * so3 of degree 1, unaligned slabs.  Usage: q' = apply(mode 0), k' = apply(mode 1)
  * (+ key_bias under euclid), v' = apply(mode 1), o~ = gta_attn_fwd_plain(q',k',v',key_bias),
  * o = apply(mode 2).
  *   x, y: [B,H,T,dh] through x_stride/y_stride (b,h,t), dtype from desc; T,N = Tq,Nq (modes 0,2) or Tk,Nk.
@@ -169,6 +169,16 @@ int gta_rep_apply(const GtaAttnDesc* desc, int32_t mode, const void* x, const in
                   const float* vrep, const float* cs, const float* coord, const float* trans_coeff,
                   void* y, const int64_t* y_stride, float* key_bias, float bias_scale, int64_t bias_pitch,
                   void* stream);
+
+/* Adjoint of gta_rep_apply(mode): dx = M^T dy (what autograd produces for gta.py:134-238 on the generic path).
+ *   x: the tensor gta_rep_apply(mode) was given; dy, dx: [B,H,T,dh] through their strides.
+ *   dtc_rows [B,H,T] fp32 or NULL: this row's contribution to d loss / d trans_coeff (sum them in a fixed order).
+ *   dkey_bias [B,H,bias_pitch] or NULL (mode 1 under euclid): gradient w.r.t. the key bias the forward call wrote;
+ *   folded in as dy - bias_scale * dkey_bias * y.  Rows whose slabs carry no bias term (so3/so2/t2) ignore it. */
+int gta_rep_apply_bwd(const GtaAttnDesc* desc, int32_t mode, const void* x, const int64_t* x_stride,
+                      const void* dy, const int64_t* dy_stride, const float* vrep, const float* cs,
+                      const float* coord, const float* trans_coeff, const float* dkey_bias, float bias_scale,
+                      int64_t bias_pitch, void* dx, const int64_t* dx_stride, float* dtc_rows, void* stream);
 
 /* softmax((scale * q k^T + key_bias) / tau) v with no rep at all (the fused kernel on an identity layout).
  * key_bias: [B,H,bias_pitch] fp32, added to scale*q.k BEFORE the division by tau; bias_pitch a multiple of 64 >= Tk; or NULL.

@@ -46,13 +46,66 @@ def test_generic_path_matches_fused_on_a_fused_layout():
     assert st["finite"] and st["rel_rms"] < 8e-3, st
 
 
-def test_generic_path_is_forward_only():
+def test_generic_path_backward_matches_reference_t2():
+    """t2 ablation (runs/*/GTA/gta_t2): dq, dk, dv through gta_rep_apply_bwd + the plain backward against the
+    reference's autograd gradients (fixture op_t2)."""
     d, meta = G.load("op_t2")
     ex = G.extras_of(d, torch.float32, "cuda")
     q, k, v = (torch.from_numpy(d[n]).float().cuda().requires_grad_() for n in "qkv")
-    with pytest.raises(native.GtaError):
-        gta_amd.multihead_geometric_transform_attention(q, k, v, attn_fn=SimpleNamespace(scale=float(d["scale"])),
-                                                        f_dims=meta["f_dims"], reps=ex, trans_coeff=None)
+    out, _ = gta_amd.multihead_geometric_transform_attention(
+        q, k, v, attn_fn=SimpleNamespace(scale=float(d["scale"])), f_dims=meta["f_dims"], reps=ex, trans_coeff=None)
+    (out * torch.from_numpy(d["w"]).float().cuda()).sum().backward()
+    torch.cuda.synchronize()
+    for name, t in (("dq", q), ("dk", k), ("dv", v)):
+        st = C.err_stats(t.grad.cpu(), torch.from_numpy(d[name]).float())
+        assert st["finite"] and st["max_abs"] <= 4e-2 * st["ref_max"] and st["rel_rms"] <= 2e-2, (name, st)
+
+
+def test_generic_path_backward_matches_fused_backward():
+    """On a layout both paths support, the generic path's gradients (incl. d trans_coeff) equal the fused backward's."""
+    from gta_amd import gta as G2
+    f_dims, so2, so3 = {"triv": 0, "se3": 48, "so3": 24, "so2": 24}, 6, 2
+    q, k, v, ex, ak, cross = C.synth_inputs(1, 2, 2, 96, 2, 80, f_dims, so2, so3, torch.float32, seed=5)
+    exd = {kk: vv.cuda() for kk, vv in ex.items()}
+    gta_amd.pre_compute_reps_encoder(ak, exd)
+    gta_amd.pre_compute_reps_decoder(ak, exd)
+    packed = gta_amd.pack_reps(exd, f_dims)
+    w = torch.randn(1, 2, 192, 96, device="cuda")
+    grads = {}
+    for name in ("fused", "generic"):
+        qq, kk, vv = (t.clone().cuda().requires_grad_() for t in (q, k, v))
+        tc = torch.tensor([0.3], device="cuda", requires_grad=True)
+        if name == "fused":
+            o = gta_amd.gta_attention(qq, kk, vv, f_dims, packed, so3_degree=2, trans_coeff=tc)
+        else:
+            o = G2._generic_forward(qq, kk, vv, f_dims, packed, 2, tc, None, 96 ** -0.5, True, False)
+        (o.float() * w).sum().backward()
+        grads[name] = (qq.grad, kk.grad, vv.grad, tc.grad)
+    torch.cuda.synchronize()
+    for a, b_, nm in zip(grads["generic"][:3], grads["fused"][:3], ("dq", "dk", "dv")):
+        st = C.err_stats(a.cpu(), b_.cpu())
+        assert st["finite"] and st["rel_rms"] < 2e-2, (nm, st)
+    ga, gb = grads["generic"][3].item(), grads["fused"][3].item()
+    assert abs(ga - gb) <= 2e-2 * max(1.0, abs(gb)), (ga, gb)
+
+
+def test_generic_path_backward_matches_reference_euclid():
+    """euclid_sim ablation (runs/*/GTA/gta_euclid, gta_so3_euclid): affine SE(3) action on 3-vectors + the
+    -|q'-k'|^2/2 similarity; dq, dk, dv, d trans_coeff against the reference's autograd (fixture op_euclid)."""
+    d, meta = G.load("op_euclid")
+    ex = G.extras_of(d, torch.float32, "cuda")
+    q, k, v = (torch.from_numpy(d[n]).float().cuda().requires_grad_() for n in "qkv")
+    tc = torch.tensor([float(d["trans_coeff"].reshape(-1)[0])], device="cuda", requires_grad=True)
+    out, _ = gta_amd.multihead_geometric_transform_attention(
+        q, k, v, attn_fn=SimpleNamespace(scale=float(d["scale"])), f_dims=meta["f_dims"], reps=ex, trans_coeff=tc,
+        euclid=True)
+    (out * torch.from_numpy(d["w"]).float().cuda()).sum().backward()
+    torch.cuda.synchronize()
+    for name, t in (("dq", q), ("dk", k), ("dv", v)):
+        st = C.err_stats(t.grad.cpu(), torch.from_numpy(d[name]).float())
+        assert st["finite"] and st["max_abs"] <= 5e-2 * st["ref_max"] and st["rel_rms"] <= 2.5e-2, (name, st)
+    ref_tc = float(d["dtrans_coeff"].reshape(-1)[0])
+    assert abs(tc.grad.item() - ref_tc) <= 5e-2 * max(1.0, abs(ref_tc)), (tc.grad.item(), ref_tc)
 
 
 @pytest.mark.parametrize("case", ["cl_cross", "ms_self", "euclid", "t2"])
