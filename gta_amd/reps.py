@@ -8,6 +8,7 @@ kernels read are stored:
 
     extras['gta_vrep_q'], extras['gta_vrep_k']   [B, N, 72]      per-view E, inv(E), D^1, D^2
     extras['gta_cs_q'],   extras['gta_cs_k']     [B, T, 2F, 2]   per-token (cos, sin)
+    extras['gta_coord_q'], extras['gta_coord_k'] [B, T, 2]       token coordinates of the t2 slab (make_T2mats, gta.py:72-89)
     extras['gta_so3_degree']
 
 The encoder call sets q-side == k-side (self-attention); the decoder call overwrites only the
@@ -31,8 +32,6 @@ def _check(attn_kwargs):
     f = attn_kwargs["f_dims"]
     if attn_kwargs.get("ray_to_se3", False):
         raise NotImplementedError("ray_to_se3 is dead code in the reference (ray2rotation is undefined)")
-    if f.get("t2", 0) > 0:
-        raise NotImplementedError("t2 reps: use the reference-style dict + the unfused path")
     for key in ("zeroout_so3", "id_so3"):
         if attn_kwargs.get(key, False):
             raise NotImplementedError(f"{key} ablation is not built")
@@ -73,6 +72,9 @@ def pre_compute_reps_encoder(attn_kwargs: dict, extras: dict) -> dict:
     elif need_view:
         extras["gta_vrep_q"] = extras["gta_vrep_k"] = native.build_view_reps(extras["input_transforms"], L)
         extras["gta_so3_degree"] = L
+    if f.get("t2", 0) > 0:                            # encoder.py:208-215: T2 reps are the raw token coordinates
+        c = extras["input_coord"]
+        extras["gta_coord_q"] = extras["gta_coord_k"] = c.reshape(c.shape[0], -1, 2).detach().float().contiguous()
     if attn_kwargs.get("elementwise_mul", False):
         T = extras["input_coord"].reshape(extras["input_coord"].shape[0], -1, 2).shape[1]
         fr, fi = _flattened(extras.get("gta_vrep_q") if f.get("se3", 0) > 0 else None, extras.get("gta_cs_q"), T)
@@ -94,6 +96,12 @@ def pre_compute_reps_decoder(attn_kwargs: dict, extras: dict) -> dict:
         if "gta_vrep_k" not in extras:
             extras["gta_vrep_k"] = native.build_view_reps(extras["input_transforms"], L)
         extras["gta_so3_degree"] = L
+    if f.get("t2", 0) > 0:                            # decoder.py:283-290: q side only
+        c = extras["target_coord"]
+        extras["gta_coord_q"] = c.reshape(c.shape[0], -1, 2).detach().float().contiguous()
+        if "gta_coord_k" not in extras:
+            ci = extras["input_coord"]
+            extras["gta_coord_k"] = ci.reshape(ci.shape[0], -1, 2).detach().float().contiguous()
     if attn_kwargs.get("elementwise_mul", False):
         T = extras["target_coord"].reshape(extras["target_coord"].shape[0], -1, 2).shape[1]
         fr, fi = _flattened(extras.get("gta_vrep_q") if f.get("se3", 0) > 0 else None, extras.get("gta_cs_q"), T)

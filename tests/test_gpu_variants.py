@@ -7,6 +7,7 @@ import torch
 
 import gta_amd
 from gta_amd import native
+from oracle import gta_oracle as O
 from tests import _golden as G
 from tests import _hip_cases as C
 
@@ -156,3 +157,45 @@ def test_elementwise_mul_module_runs_and_trains():
     y, attn = att(x, extras=exd, return_attmap=True)
     y.sum().backward()
     assert torch.isfinite(y).all() and torch.isfinite(x.grad).all() and attn.shape == (2, 2, 40, 40)
+
+
+@pytest.mark.parametrize("variant", ["t2", "euclid"])
+def test_ablation_transformer_trains_and_matches_oracle(variant):
+    """A Transformer block with the gta_t2 / gta_euclid attention settings (runs/*/GTA/gta_t2, gta_euclid): device
+    rep builders + generic path forward and backward against the CPU oracle module under the same weights."""
+    if variant == "t2":
+        f_dims, extra = {"so2": 8, "t2": 6}, {}
+        dim, H, dh = 28, 2, 14
+    else:
+        f_dims, extra = {"se3": 6, "so2": 8}, {"euclid_sim": True}
+        dim, H, dh = 28, 2, 14
+    ak = {"f_dims": f_dims, "so2": 2, "so3": 0, "max_freq_h": 1, "max_freq_w": 1, **extra}
+    aa = {"method": {"name": "gta", "args": ak}}
+    torch.manual_seed(3)
+    tr = gta_amd.Transformer(dim, 2, H, dh, 2 * dim, 0.0, True, None, False, aa)
+    ot = O.OracleTransformer(dim, 2, H, dh, 2 * dim, 0.0, True, None, False, aa)
+    ot.load_state_dict(tr.state_dict(), strict=True)
+    g = torch.Generator().manual_seed(9)
+    N, P = 2, 24
+    ex = {"input_transforms": O.random_extrinsics(2, N, g), "input_coord": torch.rand(2, N, P, 2, generator=g)}
+    x = torch.randn(2, N * P, dim, generator=g)
+    w = torch.randn(2, N * P, dim, generator=g)
+    xo = x.clone().requires_grad_()
+    yo = ot(xo, None, O.encoder_reps(ak, ex))
+    (yo * w).sum().backward()
+    tr = tr.cuda()
+    exd = {k: v.cuda() for k, v in ex.items()}
+    gta_amd.pre_compute_reps_encoder(ak, exd)
+    xd = x.clone().cuda().requires_grad_()
+    yd = tr(xd, None, exd)
+    (yd * w.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    st = C.err_stats(yd.detach().cpu(), yo.detach())
+    assert st["finite"] and st["rel_rms"] < 1.5e-2, st
+    st = C.err_stats(xd.grad.cpu(), xo.grad)
+    assert st["finite"] and st["rel_rms"] < 4e-2, st
+    for (n, p), (_, po) in zip(tr.named_parameters(), ot.named_parameters()):
+        if n.endswith("trans_coeff"):
+            continue
+        st = C.err_stats(p.grad.cpu(), po.grad)
+        assert st["finite"] and st["max_abs"] <= 6e-2 * max(st["ref_max"], 1e-3) + 1e-5, (n, st)
