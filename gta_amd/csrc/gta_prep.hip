@@ -15,16 +15,17 @@ struct PrepSmem {
     static constexpr int CHP = DHP / 8;
     static constexpr int RAW_UNITS = DHP * ESZ / 16;
     static constexpr int RAW_BYTES = BN * DHP * ESZ;
-    static constexpr int OFF_KREC = 0;
-    static constexpr int KREC_BYTES = GTA_MAX_VIEWS * GTA_KREC * 4;
-    static constexpr int OFF_RAWK = KREC_BYTES;
+    static constexpr int OFF_RAWK = 0;
     static constexpr int OFF_RAWV = OFF_RAWK + RAW_BYTES;
     // bf16 input: a raw unit and its image unit have the same (row, position) -> transform in place;
     // fp32 input: the image (half the bytes) gets its own region
     static constexpr int IMG = BN * DHP * 2;
     static constexpr int OFF_IMGK = (ESZ == 2) ? OFF_RAWK : OFF_RAWV + RAW_BYTES;
     static constexpr int OFF_IMGV = (ESZ == 2) ? OFF_RAWV : OFF_IMGK + IMG;
-    static constexpr int TOTAL = (ESZ == 2) ? OFF_RAWV + RAW_BYTES : OFF_IMGV + IMG;
+    // the k-side view records (and later the 4 x 64 row-norm partials) sit behind the data, sized by the actual
+    // number of views: 5 workgroups per CU with 16 views' worth reserved, 6 with the 5 views of the MSN config
+    static constexpr int OFF_KREC = (ESZ == 2) ? OFF_RAWV + RAW_BYTES : OFF_IMGV + IMG;
+    static int total(int Nk) { const int rec = Nk * GTA_KREC * 4; return OFF_KREC + (rec > 1024 ? rec : 1024); }
 };
 
 template <int DHP, int ESZ>
@@ -145,11 +146,11 @@ int launch_prep(const GtaFwdParams& p, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gta_kv_prep_kernel<DHP, ESZ>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, S::TOTAL) != hipSuccess) return GTA_E_LAUNCH;
+                                hipFuncAttributeMaxDynamicSharedMemorySize, S::total(GTA_MAX_VIEWS)) != hipSuccess) return GTA_E_LAUNCH;
         attr_set = true;
     }
     const int n_tiles = (p.Tk + BN - 1) / BN;
-    hipLaunchKernelGGL((gta_kv_prep_kernel<DHP, ESZ>), dim3(n_tiles, p.H, p.B), dim3(256), S::TOTAL, stream, p);
+    hipLaunchKernelGGL((gta_kv_prep_kernel<DHP, ESZ>), dim3(n_tiles, p.H, p.B), dim3(256), S::total(p.vrep_k ? p.Nk : 0), stream, p);
     return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH;
 }
 }  // namespace
