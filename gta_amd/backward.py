@@ -13,7 +13,8 @@ def _rows_ok(t: torch.Tensor) -> bool:
     return t.stride(3) == 1 and t.data_ptr() % 16 == 0 and all((s * esz) % 16 == 0 for s in t.stride()[:3])
 
 
-def attn_bwd(cfg, q, k, v, out, dout, lse, tc, ta, vrep_q, vrep_k, cs_q, cs_k, kv_images=None):
+def attn_bwd(cfg, q, k, v, out, dout, lse, tc, ta, vrep_q, vrep_k, cs_q, cs_k, kv_images=None, want_dtau=False):
+    """Returns (dq, dk, dv, dtrans_coeff or None, dtau or None); dtau ([1] fp32) only with ``want_dtau``."""
     f_dims, so3_degree, Nq, Nk, scale, flags = cfg
     flags = flags & ~(native.FLAG_FUSED_KV | native.FLAG_KV_READY | native.FLAG_PREP_ONLY | native.FLAG_WG8)
     dt = q.dtype
@@ -29,5 +30,6 @@ def attn_bwd(cfg, q, k, v, out, dout, lse, tc, ta, vrep_q, vrep_k, cs_q, cs_k, k
     dtc = torch.zeros(1, device=q.device, dtype=torch.float32) if f_dims.get("se3", 0) > 0 else None
     desc = native.make_desc(q, k, v, out, f_dims, so3_degree, Nq, Nk, scale, flags)
     ws = torch.empty(native.attn_bwd_workspace_bytes(desc), device=q.device, dtype=torch.uint8)
-    native.attn_bwd(desc, q, k, v, out, dout, lse, vrep_q, vrep_k, cs_q, cs_k, tc, ta, kv_images, dq, dk, dv, dtc, ws)
-    return dq, dk, dv, dtc
+    dta = torch.zeros(1, device=q.device, dtype=torch.float32) if (want_dtau and ta is not None) else None
+    native.attn_bwd(desc, q, k, v, out, dout, lse, vrep_q, vrep_k, cs_q, cs_k, tc, ta, kv_images, dq, dk, dv, dtc, ws, dta)
+    return dq, dk, dv, dtc, dta

@@ -198,7 +198,7 @@ extern "C" int gta_attn_fwd(const GtaAttnDesc* d, const void* q, const void* k, 
 // backward
 // ---------------------------------------------------------------------------------------------
 namespace {
-struct BwdLayout { int64_t off_qimg, off_stats, off_dc, off_kv, total; int n_prep, n_dq, n_dkv; };
+struct BwdLayout { int64_t off_qimg, off_stats, off_dc, off_dt, off_kv, total; int n_prep, n_dq, n_dkv; };
 BwdLayout bwd_layout(const GtaAttnDesc* d) {
     BwdLayout L;
     const int dhp = padded_dh(d->dh);
@@ -211,7 +211,8 @@ BwdLayout bwd_layout(const GtaAttnDesc* d) {
     L.off_qimg = 0;
     L.off_stats = al(L.off_qimg + (int64_t)d->B * d->H * n_qt * stage);
     L.off_dc = al(L.off_stats + (int64_t)d->B * d->H * n_qt * 128 * 4);
-    L.off_kv = al(L.off_dc + (int64_t)(L.n_prep + L.n_dq + L.n_dkv) * 4);
+    L.off_dt = al(L.off_dc + (int64_t)(L.n_prep + L.n_dq + L.n_dkv) * 4);
+    L.off_kv = al(L.off_dt + (int64_t)L.n_dq * 4);
     L.total = al(L.off_kv + (int64_t)d->B * d->H * n_kt * stage);
     return L;
 }
@@ -226,7 +227,8 @@ extern "C" int gta_attn_bwd(const GtaAttnDesc* d, const void* q, const void* k, 
                             const void* dout, const float* lse, const float* vrep_q, const float* vrep_k,
                             const float* cs_q, const float* cs_k, const float* trans_coeff, const float* tau,
                             const void* kv_images, void* dq, void* dk, void* dv, const int64_t* dqkv_stride,
-                            const int64_t* dout_stride, float* dtrans_coeff, void* workspace, int64_t workspace_bytes,
+                            const int64_t* dout_stride, float* dtrans_coeff, float* dtau, void* workspace,
+                            int64_t workspace_bytes,
                             void* stream) {
     int rc = check_common(d);
     if (rc) return rc;
@@ -267,6 +269,7 @@ extern "C" int gta_attn_bwd(const GtaAttnDesc* d, const void* q, const void* k, 
     p.trans_coeff = trans_coeff; p.tau = tau;
     p.kvimg = kv_images; p.qimg = ws + L.off_qimg; p.stats = (float*)(ws + L.off_stats);
     p.dc_partial = (float*)(ws + L.off_dc); p.dtrans_coeff = (d->d_se3 > 0) ? dtrans_coeff : nullptr;
+    p.dt_partial = (tau && dtau) ? (float*)(ws + L.off_dt) : nullptr; p.dtau = (tau && dtau) ? dtau : nullptr;
     p.q_sb = d->q_stride[0]; p.q_sh = d->q_stride[1]; p.q_st = d->q_stride[2];
     p.k_sb = d->k_stride[0]; p.k_sh = d->k_stride[1]; p.k_st = d->k_stride[2];
     p.v_sb = d->v_stride[0]; p.v_sh = d->v_stride[1]; p.v_st = d->v_stride[2];

@@ -474,7 +474,8 @@ __global__ __launch_bounds__(256, 2) void gta_bwd_dq_kernel(const GtaBwdParams p
     __syncthreads();
     const char* qg = (const char*)p.q + ((long)b * p.q_sb + (long)h * p.q_sh) * ESZ;
     char* dqg = (char*)p.dq + ((long)b * p.dq_sb + (long)h * p.dq_sh) * ESZ;
-    float dcpart = 0.f;
+    float dcpart = 0.f, dtpart = 0.f;
+    const bool want_dtau = p.dt_partial != nullptr;
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
         const int item = wave + 4 * it;
@@ -504,10 +505,21 @@ __global__ __launch_bounds__(256, 2) void gta_bwd_dq_kernel(const GtaBwdParams p
                 chunk_apply<true, 1>(desc, rc + BREC_MT, rc + BREC_D1T, rc + BREC_D2T, cs, x);
             }
             g_store_chunk<ESZ>(dqg + (long)t * p.dq_st * ESZ, c, x[0]);
+            if (want_dtau) {                  // d tau = -(1/tau) sum <q, dq>  (gta_hip.h)
+                float q8[8];
+                g_load_chunk<ESZ>(qg + (long)t * p.q_st * ESZ, c, q8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) dtpart += x[0][i] * q8[i];
+            }
         }
     }
     const float dc_wg = wg_sum256(dcpart, reinterpret_cast<float*>(smem + S::OFF_SCR), tid);
     if (tid == 0) p.dc_partial[p.dc_off_dq + w] = dc_wg;
+    if (want_dtau) {
+        __syncthreads();
+        const float dt_wg = wg_sum256(dtpart, reinterpret_cast<float*>(smem + S::OFF_SCR), tid);
+        if (tid == 0) p.dt_partial[w] = dt_wg;
+    }
 }
 
 // ================================================================================================
@@ -755,7 +767,8 @@ __global__ __launch_bounds__(256, 2) void gta_bwd_dkv_kernel(const GtaBwdParams 
 }
 
 // deterministic two-level sum: 1024 threads each take a fixed strided subset, then a fixed tree
-__global__ __launch_bounds__(1024) void gta_reduce_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+__global__ __launch_bounds__(1024) void gta_reduce_kernel(const float* __restrict__ part, int n, float* __restrict__ out,
+                                                          const float* __restrict__ neg_div) {
     __shared__ float sm[1024];
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;                 // 4 independent loads in flight per thread
     int i = threadIdx.x;
@@ -767,7 +780,7 @@ __global__ __launch_bounds__(1024) void gta_reduce_kernel(const float* __restric
         if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *out = sm[0];
+    if (threadIdx.x == 0) *out = neg_div ? -sm[0] / *neg_div : sm[0];
 }
 
 template <typename K>
@@ -794,7 +807,10 @@ int run_bwd(const GtaBwdParams& p, hipStream_t stream) {
     const int n_dkv = p.B * p.H * ((p.Tk + 127) / 128);
     hipLaunchKernelGGL((gta_bwd_dkv_kernel<DHP, ESZ>), dim3(n_dkv), dim3(256), DkvSmem<DHP>::total(p.vrep_k ? p.Nk : 0), stream, p);
     if (p.dtrans_coeff)
-        hipLaunchKernelGGL(gta_reduce_kernel, dim3(1), dim3(1024), 0, stream, p.dc_partial, p.dc_total, p.dtrans_coeff);
+        hipLaunchKernelGGL(gta_reduce_kernel, dim3(1), dim3(1024), 0, stream, p.dc_partial, p.dc_total, p.dtrans_coeff,
+                           (const float*)nullptr);
+    if (p.dtau)
+        hipLaunchKernelGGL(gta_reduce_kernel, dim3(1), dim3(1024), 0, stream, p.dt_partial, n_dq, p.dtau, p.tau);
     return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH;
 }
 

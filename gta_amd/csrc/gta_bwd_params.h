@@ -12,6 +12,8 @@ struct GtaBwdParams {
     float* stats;             // [B,H,n_qt64][128] = lse*log2e | D
     float* dc_partial;        // per-workgroup d trans_coeff partial sums
     float* dtrans_coeff;      // [1] or null
+    float* dt_partial;        // per-dQ-workgroup sum of <q, dq> (d tau), or null
+    float* dtau;              // [1] or null
     long q_sb, q_sh, q_st, k_sb, k_sh, k_st, v_sb, v_sh, v_st, o_sb, o_sh, o_st, do_sb, do_sh, do_st;
     long dq_sb, dq_sh, dq_st, dk_sb, dk_sh, dk_st, dv_sb, dv_sh, dv_st;
     int dc_off_prep, dc_off_dq, dc_off_dkv, dc_total;

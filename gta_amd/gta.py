@@ -167,21 +167,23 @@ class _GtaAttn(torch.autograd.Function):
         ctx.save_for_backward(q, k, v, out, lse, tc, ta, vrep_q, vrep_k, cs_q, cs_k)
         ctx.tc_shape = None if trans_coeff is None else trans_coeff.shape
         ctx.tc_dtype = None if trans_coeff is None else trans_coeff.dtype
+        ctx.tau_meta = None if tau is None else (tau.shape, tau.dtype)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         from . import backward as _bw
         q, k, v, out, lse, tc, ta, vrep_q, vrep_k, cs_q, cs_k = ctx.saved_tensors
-        if ta is not None and ctx.needs_input_grad[4]:
-            raise native.GtaError("gradient w.r.t. the adjustable softmax temperature is not implemented")
-        dq, dk, dv, dtc = _bw.attn_bwd(ctx.cfg, q, k, v, out, dout, lse, tc, ta, vrep_q, vrep_k, cs_q, cs_k,
-                                       kv_images=ctx.kv_images)
+        want_dtau = ta is not None and ctx.needs_input_grad[4]
+        dq, dk, dv, dtc, dta = _bw.attn_bwd(ctx.cfg, q, k, v, out, dout, lse, tc, ta, vrep_q, vrep_k, cs_q, cs_k,
+                                            kv_images=ctx.kv_images, want_dtau=want_dtau)
         if ctx.tc_shape is not None and dtc is not None:
             dtc = dtc.reshape(ctx.tc_shape).to(ctx.tc_dtype)
         else:
             dtc = None
-        return dq, dk, dv, dtc, None, None, None, None, None, None, None
+        if dta is not None:
+            dta = dta.reshape(ctx.tau_meta[0]).to(ctx.tau_meta[1])
+        return dq, dk, dv, dtc, dta, None, None, None, None, None, None
 
 
 class _GenericAttn(torch.autograd.Function):
@@ -225,6 +227,7 @@ class _GenericAttn(torch.autograd.Function):
             out.copy_(op[..., :dh])
         ctx.cfg, ctx.packed, ctx.flags = cfg, packed, flags
         ctx.tc_meta = None if not torch.is_tensor(trans_coeff) else (trans_coeff.shape, trans_coeff.dtype)
+        ctx.tau_meta = None if not torch.is_tensor(tau) else (tau.shape, tau.dtype)
         ctx.save_for_backward(q, k, v, qp, kp, vp, op, lse, tc, ta)
         return out
 
@@ -234,8 +237,7 @@ class _GenericAttn(torch.autograd.Function):
         q, k, v, qp, kp, vp, op, lse, tc, ta = ctx.saved_tensors
         f_dims, so3_degree, scale, v_transform, euclid = ctx.cfg
         packed = ctx.packed
-        if ta is not None and ctx.needs_input_grad[4]:
-            raise native.GtaError("gradient w.r.t. the adjustable softmax temperature is not implemented")
+        want_dtau = ta is not None and ctx.needs_input_grad[4]
         dt = q.dtype
         B, H, Tq, dh = q.shape
         Tk = k.shape[2]
@@ -273,7 +275,11 @@ class _GenericAttn(torch.autograd.Function):
             qp, kp, vp, op, dop = as_rows(qp), as_rows(kp), as_rows(vp), as_rows(op), as_rows(dop)
             dhp = dhp2
         pcfg = ({"triv": dhp}, 0, 1, 1, scale, 0)
-        dqp, dkp, dvp, _ = _bw.attn_bwd(pcfg, qp, kp, vp, op, dop, lse, None, ta, None, None, None, None)
+        # (with the bias in the augmented channels, <q', dq'> also carries the bias part of d tau)
+        dqp, dkp, dvp, _, dta = _bw.attn_bwd(pcfg, qp, kp, vp, op, dop, lse, None, ta, None, None, None, None,
+                                             want_dtau=want_dtau)
+        if dta is not None:
+            dta = dta.reshape(ctx.tau_meta[0]).to(ctx.tau_meta[1])
         if euclid:
             pitch = (Tk + 63) // 64 * 64
             dbias = torch.zeros(B, H, pitch, device=q.device, dtype=torch.float32)
@@ -296,7 +302,7 @@ class _GenericAttn(torch.autograd.Function):
             if r_o is not None and v_transform:
                 tot = tot + r_o.sum(dtype=torch.float64)
             dtc = tot.to(ctx.tc_meta[1]).reshape(ctx.tc_meta[0])
-        return dq, dk, dv, dtc, None, None, None
+        return dq, dk, dv, dtc, dta, None, None
 
 
 def _generic_forward(q, k, v, f_dims, packed, so3_degree, trans_coeff, tau, scale, v_transform, euclid):

@@ -87,7 +87,7 @@ def lib():
         L.gta_attn_fwd_supported.argtypes = [ctypes.POINTER(GtaAttnDesc)]
         L.gta_attn_fwd_launch_info.argtypes = [ctypes.POINTER(GtaAttnDesc)] + [ctypes.POINTER(c_int32)] * 3
         L.gta_attn_bwd.argtypes = ([ctypes.POINTER(GtaAttnDesc)] + [c_void_p] * 16
-                                   + [ctypes.POINTER(c_int64), ctypes.POINTER(c_int64), c_void_p, c_void_p, c_int64, c_void_p])
+                                   + [ctypes.POINTER(c_int64), ctypes.POINTER(c_int64), c_void_p, c_void_p, c_void_p, c_int64, c_void_p])
         L.gta_attn_bwd_workspace_bytes.argtypes = [ctypes.POINTER(GtaAttnDesc)]
         L.gta_attn_bwd_workspace_bytes.restype = c_int64
         L.gta_rep_apply.argtypes = [ctypes.POINTER(GtaAttnDesc), c_int32, c_void_p, ctypes.POINTER(c_int64), c_void_p, c_void_p,
@@ -208,14 +208,14 @@ def attn_bwd_workspace_bytes(desc: GtaAttnDesc) -> int:
 
 
 def attn_bwd(desc: GtaAttnDesc, q, k, v, out, dout, lse, vrep_q, vrep_k, cs_q, cs_k, trans_coeff, tau, kv_images,
-             dq, dk, dv, dtrans_coeff, workspace):
+             dq, dk, dv, dtrans_coeff, workspace, dtau=None):
     """All tensors [B,H,T,dh] views (unit channel stride); dq/dk/dv/dout strides are passed explicitly."""
     _require_cuda(q, k, v, out, dout, dq, dk, dv, workspace)
     gs = (c_int64 * 9)(*(list(dq.stride()[:3]) + list(dk.stride()[:3]) + list(dv.stride()[:3])))
     ds = (c_int64 * 3)(*dout.stride()[:3])
     check(lib().gta_attn_bwd(ctypes.byref(desc), _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(dout), _ptr(lse),
                              _ptr(vrep_q), _ptr(vrep_k), _ptr(cs_q), _ptr(cs_k), _ptr(trans_coeff), _ptr(tau),
-                             _ptr(kv_images), _ptr(dq), _ptr(dk), _ptr(dv), gs, ds, _ptr(dtrans_coeff),
+                             _ptr(kv_images), _ptr(dq), _ptr(dk), _ptr(dv), gs, ds, _ptr(dtrans_coeff), _ptr(dtau),
                              _ptr(workspace), workspace.numel(), _stream()), "gta_attn_bwd")
 
 

@@ -140,9 +140,12 @@ int64_t gta_attn_fwd_workspace_bytes(const GtaAttnDesc* desc);
  *            dout [B,H,Tq,dh] with element strides dout_stride[3] (b,h,t), reps as in the forward.
  *   kv_images: the forward's workspace (K'/V' tile images) or NULL -> recomputed here.
  *   outputs: dq, dk, dv with element strides dqkv_stride[9] = dq(b,h,t), dk(b,h,t), dv(b,h,t);
- *            dtrans_coeff [1] fp32 (d loss / d trans_coeff, layers.py:191) or NULL.
- *   No gradient is produced for the reps/poses (gta.py:194-198 detaches them; poses are data) nor
- *   for tau (GTA_E_UNSUPPORTED when desc asks for it is the caller's concern).
+ *            dtrans_coeff [1] fp32 (d loss / d trans_coeff, layers.py:191) or NULL;
+ *            dtau [1] fp32 (d loss / d tau of TemperatureAdjsutableSoftmax, layers.py:135-143,195-200) or
+ *            NULL.  The logits are z = scale q'.k' / tau, so dL/dtau = -(1/tau) sum_ij dz_ij z_ij
+ *            = -(1/tau) sum_i <q'_i, dq'_i> = -(1/tau) sum_i <q_i, dq_i>  (rho_q is linear): it falls out of
+ *            the dQ kernel's epilogue, no extra pass over the tiles.
+ *   No gradient is produced for the reps/poses (gta.py:194-198 detaches them; poses are data).
  * ------------------------------------------------------------------------------------------- */
 int64_t gta_attn_bwd_workspace_bytes(const GtaAttnDesc* desc);
 int gta_attn_bwd(const GtaAttnDesc* desc,
@@ -152,7 +155,7 @@ int gta_attn_bwd(const GtaAttnDesc* desc,
                  const float* trans_coeff, const float* tau,
                  const void* kv_images,
                  void* dq, void* dk, void* dv, const int64_t* dqkv_stride, const int64_t* dout_stride,
-                 float* dtrans_coeff,
+                 float* dtrans_coeff, float* dtau,
                  void* workspace, int64_t workspace_bytes, void* stream);
 
 /* -------------------------------------------------------------------------------------------

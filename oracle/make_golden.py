@@ -119,9 +119,16 @@ def operator_case(name, f_dims, so2, so3, H, B, Nq, Pq, Nk, Pk, seed, cross, dty
     scale = dh ** -0.5
 
     # the reference's AttnFn closes over `tau`; build it through the real Attention ctor
-    att = ref_layers.Attention(dim=H * dh, heads=H, dim_head=dh,
-                               attn_args={"method": {"name": "gta", "args": dict(ak, euclid_sim=euclid)}})
-    assert abs(att.attn_fn.scale - scale) < 1e-12 and tau == 1.0
+    # (softmax: adjustable -> TemperatureAdjsutableSoftmax's parameter, layers.py:135-143,195-200)
+    aa = {"method": {"name": "gta", "args": dict(ak, euclid_sim=euclid)}}
+    if tau != 1.0:
+        aa["softmax"] = "adjustable"
+    att = ref_layers.Attention(dim=H * dh, heads=H, dim_head=dh, attn_args=aa)
+    assert abs(att.attn_fn.scale - scale) < 1e-12
+    tau_p = None
+    if tau != 1.0:
+        tau_p = att.attend.tau
+        tau_p.data = torch.tensor([tau], dtype=dtype)
     out, attn = ref_gta.multihead_geometric_transform_attention(
         q, k, v, attn_fn=att.attn_fn, f_dims=f_dims, reps=extras,
         trans_coeff=tc if f_dims.get("se3", 0) > 0 else None,
@@ -134,7 +141,8 @@ def operator_case(name, f_dims, so2, so3, H, B, Nq, Pq, Nk, Pk, seed, cross, dty
         reps_o = O.decoder_reps(ak, extras, reps_o)
     q2, k2, v2 = (t.detach().clone().requires_grad_() for t in (q, k, v))
     tc2 = tc.detach().clone().requires_grad_()
-    out_o, attn_o = O.gta_attention(q2, k2, v2, f_dims, reps_o, tc2, v_transform, euclid, scale, tau)
+    tau2 = torch.tensor([tau], dtype=dtype, requires_grad=True) if tau_p is not None else tau
+    out_o, attn_o = O.gta_attention(q2, k2, v2, f_dims, reps_o, tc2, v_transform, euclid, scale, tau2)
     (out_o * w).sum().backward()
     dev = {
         "out": (out_o - out).abs().max().item(), "attn": (attn_o - attn).abs().max().item(),
@@ -143,6 +151,8 @@ def operator_case(name, f_dims, so2, so3, H, B, Nq, Pq, Nk, Pk, seed, cross, dty
     }
     if tc.grad is not None:
         dev["dtc"] = (tc2.grad - tc.grad).abs().max().item()
+    if tau_p is not None:
+        dev["dtau"] = (tau2.grad - tau_p.grad).abs().max().item()
     for key in ("se3rep_q", "se3rep_k", "inv_se3rep_q", "so2rep_q", "so2rep_k"):
         if key in extras:
             dev["rep:" + key] = (reps_o[key] - extras[key]).abs().max().item()
@@ -162,6 +172,7 @@ def operator_case(name, f_dims, so2, so3, H, B, Nq, Pq, Nk, Pk, seed, cross, dty
            "out": out.detach().numpy(), "attn": attn.detach().numpy(),
            "dq": q.grad.numpy(), "dk": k.grad.numpy(), "dv": v.grad.numpy(),
            "dtrans_coeff": (tc.grad.numpy() if tc.grad is not None else np.zeros(1)),
+           "tau": np.float64(tau), "dtau": (tau_p.grad.numpy() if tau_p is not None else np.zeros(1)),
            "meta": np.array(repr(dict(f_dims=f_dims, so2=so2, so3=so3, H=H, B=B, Nq=Nq, Pq=Pq,
                                       Nk=Nk, Pk=Pk, cross=cross, euclid=euclid,
                                       v_transform=v_transform, extra=kw)))}
@@ -331,6 +342,12 @@ if __name__ == "__main__":
     torch.set_num_threads(4)
     CL = {"se3": 8, "so2": 8}
     MS = {"triv": 0, "se3": 8, "so3": 8, "so2": 8}
+    if sys.argv[1:] == ["--tau-only"]:       # the adjustable-softmax cases alone (added after the first batch)
+        operator_case("ms_tau", MS, 2, 2, H=2, B=2, Nq=3, Pq=5, Nk=3, Pk=5, seed=11, cross=False, tau=1.6)
+        operator_case("cl_cross_tau", CL, 2, 0, H=2, B=1, Nq=3, Pq=7, Nk=2, Pk=6, seed=12, cross=True, tau=0.6)
+        operator_case("euclid_tau", {"se3": 6, "so2": 8}, 2, 0, H=2, B=2, Nq=2, Pq=5, Nk=2, Pk=5, seed=13,
+                      cross=False, euclid=True, tau=1.3)
+        sys.exit(0)
     operator_case("cl_self", CL, 2, 0, H=2, B=2, Nq=2, Pq=6, Nk=2, Pk=6, seed=0, cross=False)
     operator_case("cl_cross", CL, 2, 0, H=2, B=2, Nq=3, Pq=7, Nk=2, Pk=6, seed=1, cross=True)
     operator_case("ms_self", MS, 2, 2, H=2, B=2, Nq=3, Pq=5, Nk=3, Pk=5, seed=2, cross=False)
@@ -349,6 +366,10 @@ if __name__ == "__main__":
                   cross=False, shared_freqs=True)
     operator_case("recompute_so2", CL, 2, 0, H=1, B=1, Nq=2, Pq=5, Nk=2, Pk=6, seed=10, cross=True,
                   recompute_so2=True)
+    operator_case("ms_tau", MS, 2, 2, H=2, B=2, Nq=3, Pq=5, Nk=3, Pk=5, seed=11, cross=False, tau=1.6)
+    operator_case("cl_cross_tau", CL, 2, 0, H=2, B=1, Nq=3, Pq=7, Nk=2, Pk=6, seed=12, cross=True, tau=0.6)
+    operator_case("euclid_tau", {"se3": 6, "so2": 8}, 2, 0, H=2, B=2, Nq=2, Pq=5, Nk=2, Pk=5, seed=13,
+                  cross=False, euclid=True, tau=1.3)
     srt_case("ms_tiny", seed=30)
     module_case("enc_cl", CL, 2, 0, dim=32, depth=2, H=2, dh=16, B=2, Nq=2, Pq=6, Nk=2, Pk=6, seed=20,
                 cross=False)

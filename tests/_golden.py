@@ -43,3 +43,10 @@ def attn_kwargs_of(meta):
           "max_freq_h": 1, "max_freq_w": 1}
     ak.update(meta.get("extra", {}))
     return ak
+
+
+def tau_of(d, dtype=torch.float32, device="cpu", grad=True):
+    """The softmax temperature of a `softmax: adjustable` fixture as a 1-element leaf tensor, else None."""
+    if "tau" not in d or float(d["tau"]) == 1.0:
+        return None
+    return torch.tensor([float(d["tau"])], dtype=dtype, device=device, requires_grad=grad)

@@ -40,7 +40,8 @@ def golden_forward(case, dtype, use_dma=True, builder="packed", device="cuda", k
     q, k, v = (torch.from_numpy(d[n]).to(dtype).to(device) for n in "qkv")
     tc = torch.tensor([float(d["trans_coeff"])], device=device)
     out, _ = gta_amd.multihead_geometric_transform_attention(
-        q, k, v, attn_fn=SimpleNamespace(scale=float(d["scale"])), f_dims=f_dims, reps=ex, trans_coeff=tc,
+        q, k, v, attn_fn=SimpleNamespace(scale=float(d["scale"]), tau=G.tau_of(d, torch.float32, device, grad=False)),
+        f_dims=f_dims, reps=ex, trans_coeff=tc,
         v_transform=meta["v_transform"], euclid=meta["euclid"], use_dma=use_dma, kv_mode=kv_mode)
     torch.cuda.synchronize()
     return out.float().cpu(), torch.from_numpy(d["out"]).float(), meta

@@ -32,9 +32,10 @@ def test_golden_gradients(case, dtype, kv_mode):
     ex = G.extras_of(d, torch.float32, "cuda")
     q, k, v = (torch.from_numpy(d[n]).to(dtype).cuda().requires_grad_() for n in "qkv")
     tc = torch.tensor([float(d["trans_coeff"])], device="cuda", requires_grad=True)
+    tau = G.tau_of(d, torch.float32, "cuda")
     out, _ = gta_amd.multihead_geometric_transform_attention(
-        q, k, v, attn_fn=SimpleNamespace(scale=float(d["scale"])), f_dims=meta["f_dims"], reps=ex, trans_coeff=tc,
-        v_transform=meta["v_transform"], kv_mode=kv_mode)
+        q, k, v, attn_fn=SimpleNamespace(scale=float(d["scale"]), tau=tau), f_dims=meta["f_dims"], reps=ex,
+        trans_coeff=tc, v_transform=meta["v_transform"], kv_mode=kv_mode)
     (out.float() * torch.from_numpy(d["w"]).float().cuda()).sum().backward()
     torch.cuda.synchronize()
     for name, t in (("dq", q), ("dk", k), ("dv", v)):
@@ -42,6 +43,9 @@ def test_golden_gradients(case, dtype, kv_mode):
     if meta["f_dims"].get("se3", 0) > 0:
         ref = float(d["dtrans_coeff"][0])
         got = float(tc.grad.item())
+        assert abs(got - ref) <= 2e-2 * max(1.0, abs(ref)), (got, ref)
+    if tau is not None:                                   # softmax: adjustable (layers.py:195-200)
+        ref, got = float(d["dtau"][0]), float(tau.grad.item())
         assert abs(got - ref) <= 2e-2 * max(1.0, abs(ref)), (got, ref)
 
 
@@ -91,3 +95,38 @@ def test_gradients_vs_oracle_autograd(shape, dtype):
     if f_dims.get("se3", 0) > 0:
         ref, got = float(tco.grad.item()), float(tcd.grad.item())
         assert abs(got - ref) <= 3e-2 * max(1.0, abs(ref)), (got, ref)
+
+
+@pytest.mark.parametrize("shape,dtype", [("MS-dec", torch.bfloat16), ("CL-enc", torch.float32), ("ragged", torch.float32)])
+def test_tau_gradient_vs_oracle_autograd(shape, dtype):
+    """`softmax: adjustable` at the BASELINE shapes: forward with tau != 1 and d loss / d tau from the dQ kernel's
+    epilogue against autograd through the oracle."""
+    from oracle import gta_oracle as O
+    B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3 = SHAPES[shape]
+    q, k, v, ex, ak, cross = C.synth_inputs(B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, dtype, seed=17)
+    if dtype == torch.bfloat16:
+        q, k, v = q.bfloat16().float(), k.bfloat16().float(), v.bfloat16().float()
+    w = torch.randn(q.shape, generator=torch.Generator().manual_seed(19))
+    qo, ko, vo = (t.clone().requires_grad_() for t in (q, k, v))
+    tauo = torch.tensor([0.8], requires_grad=True)
+    reps = O.encoder_reps(ak, ex)
+    if cross:
+        reps = O.decoder_reps(ak, ex, reps)
+    out_o, _ = O.gta_attention(qo, ko, vo, f_dims, reps, 0.37, tau=tauo)
+    (out_o * w).sum().backward()
+    exd = {kk: vv.cuda() for kk, vv in ex.items()}
+    gta_amd.pre_compute_reps_encoder(ak, exd)
+    if cross:
+        gta_amd.pre_compute_reps_decoder(ak, exd)
+    packed = gta_amd.pack_reps(exd, f_dims)
+    qd, kd, vd = (t.to(dtype).cuda().requires_grad_() for t in (q, k, v))
+    taud = torch.tensor([0.8], device="cuda", requires_grad=True)
+    out = gta_amd.gta_attention(qd, kd, vd, f_dims, packed, so3_degree=exd.get("gta_so3_degree", 0),
+                                trans_coeff=0.37 if f_dims.get("se3", 0) > 0 else None, tau=taud)
+    (out.float() * w.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    _check(out.float().cpu(), out_o.detach(), "out", 2.5e-2, 1.2e-2)
+    for name, a, b in (("dq", qd, qo), ("dk", kd, ko), ("dv", vd, vo)):
+        _check(a.grad.float().cpu(), b.grad, name)
+    ref, got = float(tauo.grad.item()), float(taud.grad.item())
+    assert abs(got - ref) <= 3e-2 * max(1.0, abs(ref)), (got, ref)

@@ -29,6 +29,30 @@ def test_ablation_fixture_forward(case, dtype):
     assert st["finite"] and st["max_abs"] <= 3e-2 * st["ref_max"] and st["rel_rms"] <= 1.5e-2, st
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_euclid_adjustable_softmax_fixture(dtype):
+    """euclid similarity + `softmax: adjustable` (layers.py:195-224): out, dq, dk, dv, d trans_coeff and d tau of the
+    generic path against the reference's autograd (fixture op_euclid_tau)."""
+    d, meta = G.load("op_euclid_tau")
+    ex = G.extras_of(d, torch.float32, "cuda")
+    q, k, v = (torch.from_numpy(d[n]).to(dtype).cuda().requires_grad_() for n in "qkv")
+    tc = torch.tensor([float(d["trans_coeff"])], device="cuda", requires_grad=True)
+    tau = G.tau_of(d, torch.float32, "cuda")
+    out, _ = gta_amd.multihead_geometric_transform_attention(
+        q, k, v, attn_fn=SimpleNamespace(scale=float(d["scale"]), tau=tau), f_dims=meta["f_dims"], reps=ex,
+        trans_coeff=tc, v_transform=meta["v_transform"], euclid=True)
+    (out.float() * torch.from_numpy(d["w"]).float().cuda()).sum().backward()
+    torch.cuda.synchronize()
+    st = C.err_stats(out.float().cpu(), torch.from_numpy(d["out"]).float())
+    assert st["finite"] and st["max_abs"] <= 3e-2 * st["ref_max"] and st["rel_rms"] <= 1.5e-2, st
+    for name, t in (("dq", q), ("dk", k), ("dv", v)):
+        st = C.err_stats(t.grad.float().cpu(), torch.from_numpy(d[name]).float())
+        assert st["finite"] and st["max_abs"] <= 5e-2 * st["ref_max"] + 1e-6 and st["rel_rms"] <= 2.5e-2, (name, st)
+    for name, t in (("dtrans_coeff", tc), ("dtau", tau)):
+        ref, got = float(d[name].reshape(-1)[0]), float(t.grad.item())
+        assert abs(got - ref) <= 5e-2 * max(1.0, abs(ref)), (name, got, ref)
+
+
 def test_generic_path_matches_fused_on_a_fused_layout():
     """Same inputs through gta_rep_apply + plain attention and through the fused kernel."""
     from tests.test_gpu_forward import SHAPES

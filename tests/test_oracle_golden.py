@@ -28,8 +28,9 @@ def test_operator_matches_reference(case):
             assert (a - b).abs().max() < TOL
     q, k, v = (torch.from_numpy(d[n]).requires_grad_() for n in "qkv")
     tc = torch.tensor([float(d["trans_coeff"])], dtype=torch.float64, requires_grad=True)
+    tau = G.tau_of(d, torch.float64)            # softmax: adjustable fixtures carry tau and d tau
     out, attn = O.gta_attention(q, k, v, meta["f_dims"], reps, tc, meta["v_transform"], meta["euclid"],
-                                float(d["scale"]))
+                                float(d["scale"]), 1.0 if tau is None else tau)
     (out * torch.from_numpy(d["w"])).sum().backward()
     assert np.abs(out.detach().numpy() - d["out"]).max() < TOL
     assert np.abs(attn.detach().numpy() - d["attn"]).max() < TOL
@@ -37,6 +38,8 @@ def test_operator_matches_reference(case):
         assert np.abs(t.grad.numpy() - d[n]).max() < TOL, n
     if meta["f_dims"].get("se3", 0) > 0:
         assert np.abs(tc.grad.numpy() - d["dtrans_coeff"]).max() < TOL
+    if tau is not None:
+        assert np.abs(tau.grad.numpy() - d["dtau"]).max() < TOL
 
 
 @pytest.mark.parametrize("case", G.list_cases("mod_"))
