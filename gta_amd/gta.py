@@ -130,7 +130,7 @@ class _GtaAttn(torch.autograd.Function):
     flash_events = None     # (start, end) torch.cuda.Event pair set by bench.py, else None
 
     @staticmethod
-    def forward(ctx, q, k, v, trans_coeff, tau, f_dims_t, cfg, vrep_q, vrep_k, cs_q, cs_k):
+    def forward(ctx, q, k, v, trans_coeff, tau, kv_cache, cfg, vrep_q, vrep_k, cs_q, cs_k):
         f_dims, so3_degree, Nq, Nk, scale, flags = cfg
         dt = q.dtype
         if dt not in (torch.float32, torch.bfloat16):
@@ -147,8 +147,17 @@ class _GtaAttn(torch.autograd.Function):
         desc = native.make_desc(q, k, v, out, f_dims, so3_degree, Nq, Nk, scale, flags)
         ws = None
         if not (flags & (native.FLAG_FUSED_KV | native.FLAG_PRETRANSFORMED)):
-            ws = torch.empty(native.attn_fwd_workspace_bytes(desc), device=q.device, dtype=torch.uint8)
-        if ws is not None and _GtaAttn.flash_events is not None:
+            if kv_cache is not None and kv_cache.get("images") is not None:
+                # K'/V' tile images of an earlier call against the same keys (chunked decode): skip the pre-pass
+                ws = kv_cache["images"]
+                if ws.numel() < native.attn_fwd_workspace_bytes(desc) or ws.device != q.device:
+                    raise native.GtaError("kv_cache holds images of a different key set")
+                desc.flags = flags | native.FLAG_KV_READY
+            else:
+                ws = torch.empty(native.attn_fwd_workspace_bytes(desc), device=q.device, dtype=torch.uint8)
+                if kv_cache is not None:
+                    kv_cache["images"] = ws
+        if ws is not None and _GtaAttn.flash_events is not None and not (desc.flags & native.FLAG_KV_READY):
             # instrumentation (bench.py): bracket the attention kernel alone with stream events
             desc.flags = flags | native.FLAG_PREP_ONLY
             native.attn_fwd(desc, q, k, v, vrep_q, vrep_k, cs_q, cs_k, tc, ta, out, lse, ws)
@@ -315,12 +324,15 @@ def _generic_forward(q, k, v, f_dims, packed, so3_degree, trans_coeff, tau, scal
 def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: int = 0,
                   trans_coeff=None, tau=None, scale: Optional[float] = None, v_transform: bool = True,
                   euclid: bool = False, pretransformed: bool = False, use_dma: bool = True,
-                  kv_mode: str = "auto") -> torch.Tensor:
+                  kv_mode: str = "auto", kv_cache: Optional[dict] = None) -> torch.Tensor:
     """Fused GTA attention on packed reps.  q [B,H,Tq,dh], k/v [B,H,Tk,dh] -> out [B,H,Tq,dh].
 
     kv_mode: 'prepass' = K/V rep pre-pass + lean attention kernel (two launches);
              'fused'   = one kernel, rho_k applied inside the attention loop;
-             'auto'    = 'prepass' when several query tiles share each key tile, else 'fused'."""
+             'auto'    = 'prepass' when several query tiles share each key tile, else 'fused'.
+    kv_cache: a dict owned by the caller (inference only).  The first call stores the K'/V' tile images of the
+             pre-pass in it; later calls with the same keys, reps and trans_coeff (e.g. the next query chunk of a
+             full-image decode, trainer.py:137-181) stream them again without re-running the pre-pass."""
     if scale is None:
         scale = q.shape[-1] ** -0.5
     flags = 0
@@ -337,6 +349,10 @@ def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: 
         kv_mode = "prepass"
     if kv_mode not in ("auto", "prepass", "fused"):
         raise ValueError(f"kv_mode {kv_mode!r}")
+    if kv_cache is not None:
+        if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in (q, k, v, trans_coeff)):
+            raise native.GtaError("kv_cache is an inference feature: call under torch.no_grad()")
+        kv_mode = "prepass"
     if kv_mode == "auto":
         kv_mode = "prepass" if q.shape[2] > 256 else "fused"
     if kv_mode == "fused" or not use_dma:
@@ -351,7 +367,7 @@ def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: 
         if native.attn_fwd_supported(probe) == -3:       # GTA_E_UNSUPPORTED: valid request, no fused kernel
             return _generic_forward(q, k, v, f_dims, packed, so3_degree, trans_coeff, tau, scale, v_transform, euclid)
     cfg = ({k_: int(v_) for k_, v_ in f_dims.items()}, int(so3_degree), Nq, Nk, float(scale), flags)
-    return _GtaAttn.apply(q, k, v, trans_coeff, tau, None, cfg, packed.get("vrep_q"), packed.get("vrep_k"),
+    return _GtaAttn.apply(q, k, v, trans_coeff, tau, kv_cache, cfg, packed.get("vrep_q"), packed.get("vrep_k"),
                           packed.get("cs_q"), packed.get("cs_k"))
 
 

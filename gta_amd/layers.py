@@ -121,13 +121,23 @@ class Attention(nn.Module):
             raise ValueError("GTA attention needs `extras` (the reps dict)")
         B, Tq, _ = x.shape
         H, dh = self.heads, self.dim_head
+        kv_cache = None
         if z is None:
             qkv = self.to_qkv(x).view(B, Tq, 3, H, dh)                    # layers.py:389
             q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))   # strided views, no copy
         else:
             q = self.to_q(x).view(B, Tq, H, dh).permute(0, 2, 1, 3)      # layers.py:391-392
-            kv = self.to_kv(z).view(B, z.shape[1], 2, H, dh)
-            k, v = (kv[:, :, i].permute(0, 2, 1, 3) for i in range(2))
+            # chunked decode (srt.render_image): the key side of a cross-attention layer does not change between
+            # query chunks, so its projection and its K'/V' images are kept in the caller's cache
+            if "gta_kv_cache" in extras and not torch.is_grad_enabled():
+                kv_cache = extras["gta_kv_cache"].setdefault(id(self), {})
+            if kv_cache is not None and "kv" in kv_cache:
+                k, v = kv_cache["kv"]
+            else:
+                kv = self.to_kv(z).view(B, z.shape[1], 2, H, dh)
+                k, v = (kv[:, :, i].permute(0, 2, 1, 3) for i in range(2))
+                if kv_cache is not None:
+                    kv_cache["kv"] = (k, v)
         tau = self.attend.tau if self.attend is not None else None
         if self.elementwise_mul:                                          # layers.py:410-419
             ex = dict(vecrep_q=self.rep_to_vec(extras["flattened_rep_q"]), vecrep_k=self.rep_to_vec(extras["flattened_rep_k"]),
@@ -144,7 +154,8 @@ class Attention(nn.Module):
             q, k, v, self.f_dims, packed,
             so3_degree=_gta._so3_degree(self.f_dims, packed, extras),
             trans_coeff=self.trans_coeff, tau=self.attend.tau if self.attend is not None else None,
-            scale=self.scale, v_transform=self.method_args.get("v_transform", True), euclid=self.euclid)
+            scale=self.scale, v_transform=self.method_args.get("v_transform", True), euclid=self.euclid,
+            kv_cache=kv_cache)
         out = out.permute(0, 2, 1, 3).reshape(B, Tq, H * dh)              # free: out is [B,Tq,H,dh] in memory
         out = self.to_out(out)
         if return_attmap:                                                  # layers.py:441-442

@@ -177,6 +177,33 @@ class TransformingSRT(nn.Module):
         return self.decode(z, target_camera_pos, target_rays, extras=extras)
 
 
+@torch.no_grad()
+def render_image(model: "TransformingSRT", z, camera_pos, rays, extras, max_num_rays: int = 8192, reuse_kv: bool = True):
+    """Full-image decode of one target view per scene, in query chunks (trainer.py:137-181).
+
+    z [B,K,C] scene tokens from ``model.encoder`` (whose call also left the key-side reps in ``extras``);
+    camera_pos [B,3]; rays [B,h,w,3]; ``extras['target_transforms']`` [B,1,4,4] is the pose of the rendered view.
+    Returns ``(img [B,h,w,3], {})``.  The reference re-projects K/V and re-applies rho_k for every chunk of every
+    layer; here (``reuse_kv``) each cross-attention layer keeps its K/V projection and its K'/V' tile images across
+    the chunks (GTA_FLAG_KV_READY), so a chunk costs the query side plus the attention kernel only."""
+    from .gta import make_2dcoord
+    B, h, w = rays.shape[:3]
+    coord = torch.from_numpy(make_2dcoord(h, w)).to(z.device).flatten(0, 1)[None].expand(B, -1, -1)   # [B,h*w,2]
+    rays = rays.flatten(1, 2)
+    cam = camera_pos[:, None].expand(-1, rays.shape[1], -1)
+    img = torch.zeros(B, h * w, 3, dtype=camera_pos.dtype, device=camera_pos.device)
+    ex = dict(extras)                                  # the caller's dict keeps its own target_* entries
+    if reuse_kv:
+        ex["gta_kv_cache"] = {}
+    for i in range(0, h * w, max_num_rays):
+        sl = slice(i, i + max_num_rays)
+        ex["target_rays"] = rays[:, None, sl]
+        ex["target_coord"] = coord[:, None, sl]
+        pix, _ = model.decode(z=z, x=cam[:, None, sl], rays=rays[:, None, sl], extras=ex)
+        img[:, sl] = pix.to(img.dtype)
+    return img.view(B, h, w, 3), {}
+
+
 def mse2psnr(mse: torch.Tensor) -> torch.Tensor:
     """common.py:14-15."""
     return -10.0 * torch.log(mse) / math.log(10.0)

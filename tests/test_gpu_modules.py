@@ -119,3 +119,45 @@ def test_srt_model_matches_reference(mixed):
         assert st["max_abs"] <= tol, (n, st)
         worst = max(worst, st["rel_rms"])
     assert worst < (0.3 if mixed else 0.1)
+
+
+def test_render_image_chunked_decode():
+    """Full-image decode (trainer.py:137-181) under the reference's weights: chunked queries with the per-layer K/V
+    cache == the same without the cache (bit for bit) == the oracle decoding every pixel in one call."""
+    from gta_amd import srt
+    from oracle import gta_oracle as O
+    import ast
+    import numpy as np
+    d, model, data = _srt()
+    model.eval()
+    h, w = 9, 14
+    B = data["input_images"].shape[0]
+    g = torch.Generator().manual_seed(3)
+    rays = torch.randn(B, h, w, 3, generator=g).cuda()
+    cam = torch.randn(B, 3, generator=g).cuda()
+    extras = {"input_transforms": data["input_transforms"], "input_coord": data["input_coord"],
+              "target_transforms": data["target_transforms"][:, 1:2]}
+    with torch.no_grad():
+        z, extras = model.encoder(data["input_images"], data["input_camera_pos"], data["input_rays"], extras)
+        img_c, _ = srt.render_image(model, z, cam, rays, extras, max_num_rays=50, reuse_kv=True)
+        img_n, _ = srt.render_image(model, z, cam, rays, extras, max_num_rays=50, reuse_kv=False)
+        img_1, _ = srt.render_image(model, z, cam, rays, extras, max_num_rays=h * w, reuse_kv=True)
+    torch.cuda.synchronize()
+    assert img_c.shape == (B, h, w, 3)
+    assert torch.equal(img_c, img_n)
+    assert (img_c - img_1).abs().max() < 2e-3          # another chunking = other query tiles per workgroup, same pixels
+    # oracle: every pixel of the view as one query set
+    cfg = ast.literal_eval(str(np.load(G.GOLDEN + "/srt_ms_tiny.npz")["meta"]))
+    om = O.OracleSRT(cfg)
+    om.load_state_dict({k[len("param."):]: torch.from_numpy(v).float() for k, v in d.items() if k.startswith("param.")},
+                       strict=True)
+    om.eval()
+    coord = torch.from_numpy(gta_amd.gta.make_2dcoord(h, w)).flatten(0, 1)[None, None].expand(B, 1, -1, -1)
+    ex_o = {"input_transforms": data["input_transforms"].cpu(), "input_coord": data["input_coord"].cpu(),
+            "target_transforms": data["target_transforms"][:, 1:2].cpu(), "target_coord": coord}
+    with torch.no_grad():
+        ref = om(data["input_images"].cpu(), None, None, None, rays.cpu().flatten(1, 2), ex_o).view(B, h, w, 3)
+    st = C.err_stats(img_c.cpu(), ref)
+    assert st["finite"] and st["max_abs"] < 1e-2, st
+    mse = ((img_c.cpu() - ref) ** 2).mean()
+    assert mse < 1e-5, mse
