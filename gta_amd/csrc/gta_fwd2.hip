@@ -203,6 +203,9 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
 #define GTA_STAMP(k) do { } while (0)
 #endif
     GTA_STAMP(0);
+#ifdef GTA_ABLATE
+    if (p.prof && tid == 0) p.prof[(long)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();   // 100 MHz reference
+#endif
     dma_stage<DHP, RB>(ring, 0, kvimg, wave, lane);                   // tile 0 on its way
 
     // ---- prologue: every global load is issued up front (one latency exposure, not one per item).
@@ -229,6 +232,7 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
         }
     };
     if (NPAR == 2 && par) load_items(std::integral_constant<int, 1>{}); else load_items(std::integral_constant<int, 0>{});
+    GTA_STAMP(7);                                                        // (all prologue loads issued)
     // views touched by this query tile: records are staged relative to n_first
     const int t_last = (q0 + BM - 1 < p.Tq ? q0 + BM - 1 : p.Tq - 1);
     const int n_first = q0 / p.Pq;
@@ -654,6 +658,9 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
         if (parE) out_items(std::integral_constant<int, 1>{}); else out_items(std::integral_constant<int, 0>{});
     }
     GTA_STAMP(4);
+#ifdef GTA_ABLATE
+    if (p.prof && tid == 0) p.prof[(long)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+#endif
 #undef GTA_STAMP
 }
 

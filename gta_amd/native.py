@@ -13,7 +13,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgta_hip.so")
+# GTA_HIP_LIB: developer override (instrumented -DGTA_ABLATE builds of the same library)
+LIB_PATH = os.environ.get("GTA_HIP_LIB") or os.path.join(_HERE, "csrc", "libgta_hip.so")
 
 GTA_ABI_VERSION = 1
 DTYPE_F32, DTYPE_BF16 = 0, 1
