@@ -208,10 +208,80 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
 #endif
     dma_stage<DHP, RB>(ring, 0, kvimg, wave, lane);                   // tile 0 on its way
 
+    // views touched by this query tile: records are staged relative to n_first
+    const int t_last = (q0 + BM - 1 < p.Tq ? q0 + BM - 1 : p.Tq - 1);
+    const int n_first = q0 / p.Pq;
+    const int n_cnt = t_last / p.Pq - n_first + 1;
+    const float qscale = p.scale * LOG2E / (p.tau ? *p.tau : 1.0f);
+    constexpr int RAWN = ESZ == 2 ? 1 : 2;
+    bf16x8_t qf[RB][KS];
+    float qn[RB];                  // |q'| of this lane's MFMA rows: with the pre-pass's per-tile max |k'| it bounds every score of a tile
+    if constexpr (RB == 1) {
+    // ---- prologue, fragment-direct: lane (l31, lh) of a wave IS the owner of MFMA B fragment (row 32*wave + l31,
+    // chunks 2ks + lh), and rho_q acts inside a chunk -- so the lane loads exactly those 6 raw chunks, applies rho_q,
+    // scales, rounds, and the result is qf[ks].  No Q staging tile, no LDS round trip, no barrier besides the one
+    // behind the view records; ring stage 1 is free from the start, so tile 1 is requested together with tile 0.
+    // The chunk kind of lanes 0-31 (even chunk) and 32-63 (odd chunk) is the same constant for every se3/se3,
+    // so3/so3, so2/so2 pair of the shipped layouts (the select folds); a mixed pair runs both kinds under exec masks.
+    if (n_tiles > 1) dma_stage<DHP, RB>(ring, 1, kvimg + (long)S::STAGE, wave, lane);
+    const int my_r = wave * 32 + l31;
+    int my_t = q0 + my_r;
+    my_t = my_t < p.Tq ? my_t : p.Tq - 1;
+    u32x4_t qraw[KS][RAWN];
+    f32x2_t qcs[KS][4];
+    uint32_t dl[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int c = 2 * ks + lh;
+        dl[ks] = lh ? GTA_DESC(2 * ks + 1) : GTA_DESC(2 * ks);
+        if (c < ch_real && !GTA_DBG(32u)) {
+            const char* rp = qg + (long)my_t * q_rs + c * 8 * ESZ;
+#pragma unroll
+            for (int k2 = 0; k2 < RAWN; ++k2) qraw[ks][k2] = *reinterpret_cast<const u32x4_t*>(rp + 16 * k2);
+            if (p.cs_q) load_cs(dl[ks], p.cs_q + ((long)b * p.Tq + my_t) * 2 * p.nso2, qcs[ks]);
+        }
+    }
+    GTA_STAMP(7);                                                        // (all prologue loads issued)
+    if (p.vrep_q && !GTA_DBG(128u)) stage_qrec(qrec, p.vrep_q, b, p.Nq, n_first, n_cnt, p.trans_coeff ? *p.trans_coeff : 1.0f, tid, NT);
+    __syncthreads();
+    GTA_STAMP(1);
+    float qsq = 0.f;                                   // this lane's share of |q'_row|^2 (bf16-rounded values)
+    const float* rec_q = qrec + (view_of(my_t, p.Pq, p.invPq) - n_first) * GTA_QREC;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int c = 2 * ks + lh;
+        float x[1][8];
+        if (c < ch_real) {
+            if (ESZ == 2) {
+                unpack8(qraw[ks][0], x[0]);
+            } else {
+#pragma unroll
+                for (int k2 = 0; k2 < RAWN; ++k2) {
+                    x[0][4 * k2 + 0] = __uint_as_float(qraw[ks][k2].x); x[0][4 * k2 + 1] = __uint_as_float(qraw[ks][k2].y);
+                    x[0][4 * k2 + 2] = __uint_as_float(qraw[ks][k2].z); x[0][4 * k2 + 3] = __uint_as_float(qraw[ks][k2].w);
+                }
+            }
+            if (dl[ks]) chunk_apply<false, 1>(dl[ks], rec_q + GTA_QREC_A, rec_q + GTA_QREC_D1, rec_q + GTA_QREC_D2, qcs[ks], x);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[0][i] *= qscale;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[0][i] = 0.f;
+        }
+        const u32x4_t qw = pack8(x[0]);
+        qf[0][ks] = __builtin_bit_cast(bf16x8_t, qw);
+        float qr[8];
+        unpack8(qw, qr);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qsq += qr[i] * qr[i];
+    }
+    qsq += __shfl_xor(qsq, 32);                                          // the row's other chunk parity
+    qn[0] = sqrtf(qsq) * 1.0001f;
+    GTA_STAMP(2);
+    } else {
     // ---- prologue: every global load is issued up front (one latency exposure, not one per item).
     // item map: wave -> (row group rg = wave % RG, chunk parity par = wave / RG); item it -> chunk
     // NPAR*it + par: a constant in each of the NPAR straight-line code paths.
-    constexpr int RAWN = ESZ == 2 ? 1 : 2;
     u32x4_t qraw[QITEMS][RAWN];
     f32x2_t qcs[QITEMS][4];
     const int rg = wave % RG, par = wave / RG;
@@ -233,16 +303,11 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
     };
     if (NPAR == 2 && par) load_items(std::integral_constant<int, 1>{}); else load_items(std::integral_constant<int, 0>{});
     GTA_STAMP(7);                                                        // (all prologue loads issued)
-    // views touched by this query tile: records are staged relative to n_first
-    const int t_last = (q0 + BM - 1 < p.Tq ? q0 + BM - 1 : p.Tq - 1);
-    const int n_first = q0 / p.Pq;
-    const int n_cnt = t_last / p.Pq - n_first + 1;
     if (p.vrep_q && !GTA_DBG(128u)) stage_qrec(qrec, p.vrep_q, b, p.Nq, n_first, n_cnt, p.trans_coeff ? *p.trans_coeff : 1.0f, tid, NT);
     __syncthreads();
 
     GTA_STAMP(1);
     // ---- Q: rho, prescale, bf16 -> LDS ----
-    const float qscale = p.scale * LOG2E / (p.tau ? *p.tau : 1.0f);
     float qsq = 0.f;                                   // this thread's share of |q'_row|^2 (bf16-rounded values)
     float* qsq_l = reinterpret_cast<float*>(smem + S::off_qsq(p.vrep_q ? p.Nq : 0));
     auto xform_items = [&](auto PARC) {
@@ -287,13 +352,11 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
     qsq_l[par * BM + my_r] = qsq;
     __syncthreads();      // (also drains tile 0's DMA: harmless)
     // |q'| of this lane's MFMA rows: with the pre-pass's per-tile max |k'| it bounds every score of a tile
-    float qn[RB];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
         const int r = wave * (32 * RB) + 32 * rb + l31;
         qn[rb] = sqrtf(qsq_l[r] + (NPAR == 2 ? qsq_l[BM + r] : 0.f)) * 1.0001f;
     }
-    bf16x8_t qf[RB][KS];
     {
         const char* qs = smem + S::OFF_QS;
 #pragma unroll
@@ -307,6 +370,8 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
     __syncthreads();      // Q staging (ring stages 1..2) is free again
     if (n_tiles > 1) dma_stage<DHP, RB>(ring, 1, kvimg + (long)S::STAGE, wave, lane);
     GTA_STAMP(2);
+
+    }
 
     f32x16_t oacc[RB][DB];
     float m_run[RB], l_run[RB];
@@ -597,6 +662,42 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
     constexpr int WPP = NW / NPASS;                                  // waves whose rows go in one pass
     constexpr int EITEMS = CHP / 2;                                  // epilogue map: 2 row groups x 2 parities
     constexpr bool SAMEMAP = false;   // (the prologue's (cos,sin) are NOT kept across the loop: 48 VGPRs the skewed loop needs)
+    if constexpr (RB == 1) {
+        // ---- epilogue in registers: the accumulators hold, per lane (row l31), the 4-channel HALF lh of every chunk;
+        // one v_permlane32_swap per value hands lanes 0-31 the whole even chunk of a pair and lanes 32-63 the whole odd
+        // one (the same ownership as the prologue), rho_q^-1 acts inside the chunk, and the chunk is stored.  No O
+        // staging tile, no barrier.
+        const int tE = q0 + wave * 32 + l31;
+        const bool rowok = tE < p.Tq;
+        const int tC = rowok ? tE : p.Tq - 1;
+        constexpr int NP = CHP / 2;
+        f32x2_t ocs[NP][4];
+        uint32_t dle[NP];
+#pragma unroll
+        for (int kp = 0; kp < NP; ++kp) {
+            dle[kp] = lh ? GTA_DESC(2 * kp + 1) : GTA_DESC(2 * kp);
+            if (xo && p.cs_q && 2 * kp + lh < ch_real) load_cs(dle[kp], p.cs_q + ((long)b * p.Tq + tC) * 2 * p.nso2, ocs[kp]);
+        }
+        const float* rec_o = qrec + (view_of(tC, p.Pq, p.invPq) - n_first) * GTA_QREC;
+#pragma unroll
+        for (int kp = 0; kp < NP; ++kp) {
+            const int d = (2 * kp) >> 2, ge = (2 * kp) & 3;
+            float x[1][8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t ua = __float_as_uint(oacc[0][d][4 * ge + i] * inv_l[0]);         // half lh of the even chunk
+                const uint32_t ub = __float_as_uint(oacc[0][d][4 * (ge + 1) + i] * inv_l[0]);   // half lh of the odd chunk
+                const auto sw = __builtin_amdgcn_permlane32_swap(ua, ub, false, false);         // ua[32..63] <-> ub[0..31]
+                x[0][i] = __uint_as_float(sw[0]);
+                x[0][4 + i] = __uint_as_float(sw[1]);
+            }
+            const int c = 2 * kp + lh;
+            if (rowok && c < ch_real) {
+                if (xo && dle[kp]) chunk_apply<true, 1>(dle[kp], rec_o + GTA_QREC_O, rec_o + GTA_QREC_D1T, rec_o + GTA_QREC_D2T, ocs[kp], x);
+                if (!GTA_DBG(64u) || x[0][0] == 123.f) gstore_chunk2<ESZ>(og + (long)tE * o_rs, c, x[0]);
+            }
+        }
+    } else {
     const int rgE = wave & 1, parE = wave >> 1;
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; ++pass) {
@@ -650,12 +751,12 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
             for (int it = 0; it < EITEMS; ++it) {
                 const int c = 2 * it + PAR;
                 if (c < ch_real && tE < p.Tq) {
-                    if constexpr (SAMEMAP) out_item(GTA_DESC(c), c, qcs[it]);
-                    else out_item(GTA_DESC(c), c, ocs[it]);
+                    out_item(GTA_DESC(c), c, ocs[it]);
                 }
             }
         };
         if (parE) out_items(std::integral_constant<int, 1>{}); else out_items(std::integral_constant<int, 0>{});
+    }
     }
     GTA_STAMP(4);
 #ifdef GTA_ABLATE
