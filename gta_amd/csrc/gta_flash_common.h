@@ -93,31 +93,81 @@ GTA_DEV int qrec_src(int e, int* kind, int* r_, int* c_) {
         return GTA_VREP_D2 + (c < 5 ? c : 0) * 5 + r;
     }
 }
-GTA_DEV void stage_qrec(float* qrec, const float* vrep_q, int b, int Nq, int n0, int cnt, float tc, int tid,
-                        int nthreads) {
+// One batch = three record elements per thread; split into its load and its store half so a caller can put other
+// memory requests between them (the attention kernel issues its tile DMA there: off the prologue's critical path).
+struct QrecBatch { float val[3]; int kind[3], rr[3], cc[3]; };
+GTA_DEV void qrec_batch_load(QrecBatch& q, const float* vrep_q, int b, int Nq, int n0, int cnt, int i0, int nthreads) {
     const int total = cnt * GTA_QREC;
     const float* base = vrep_q + ((long)b * Nq + n0) * GTA_VREP_STRIDE;
-    for (int i0 = tid; i0 < total; i0 += 3 * nthreads) {
-        float val[3];
-        int kind[3], rr[3], cc[3];
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int i = i0 + u * nthreads;
-            kind[u] = 3;
-            if (i < total) {
-                const int n = i / GTA_QREC, e = i - n * GTA_QREC;
-                val[u] = base[(long)n * GTA_VREP_STRIDE + qrec_src(e, &kind[u], &rr[u], &cc[u])];
-            }
+    for (int u = 0; u < 3; ++u) {
+        const int i = i0 + u * nthreads;
+        q.kind[u] = 3; q.val[u] = 0.f; q.rr[u] = 0; q.cc[u] = 0;
+        if (i < total) {
+            const int n = i / GTA_QREC, e = i - n * GTA_QREC;
+            q.val[u] = base[(long)n * GTA_VREP_STRIDE + qrec_src(e, &q.kind[u], &q.rr[u], &q.cc[u])];
         }
+    }
+}
+GTA_DEV void qrec_batch_store(const QrecBatch& q, float* qrec, float tc, int i0, int nthreads) {
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int i = i0 + u * nthreads;
-            if (kind[u] == 3) continue;
-            float v = val[u];
-            if (kind[u] == 0) v *= (rr[u] == 3) ? (cc[u] == 3 ? 1.f : 0.f) : (cc[u] == 3 ? tc : 1.f);
-            else if (kind[u] == 2) v = 0.f;
-            qrec[i] = v;
-        }
+    for (int u = 0; u < 3; ++u) {
+        const int i = i0 + u * nthreads;
+        if (q.kind[u] == 3) continue;
+        float v = q.val[u];
+        if (q.kind[u] == 0) v *= (q.rr[u] == 3) ? (q.cc[u] == 3 ? 1.f : 0.f) : (q.cc[u] == 3 ? tc : 1.f);
+        else if (q.kind[u] == 2) v = 0.f;
+        qrec[i] = v;
+    }
+}
+// The same staging with the record cut into four segments, one per wave of a 256-thread workgroup, so that the kind
+// of element a lane handles is WAVE-uniform (qrec_src above is a five-way per-lane branch: every path runs, masked):
+//   wave 0: Aq, Oq (32 / view)   wave 1: D1, D1^T (24 / view)   wave 2: D2 (40 / view)   wave 3: D2^T (40 / view)
+// idx = position in the wave's segment list (lane, lane + 64, ...).  dst < 0: nothing to do.
+struct QrecItem { float val; int kind, rr, cc, dst; };
+GTA_DEV void qrec_seg_load(QrecItem& q, const float* vrep_q, int b, int Nq, int n0, int cnt, int seg, int idx) {
+    q.val = 0.f; q.kind = 1; q.rr = 0; q.cc = 0; q.dst = -1;
+    const float* base = vrep_q + ((long)b * Nq + n0) * GTA_VREP_STRIDE;
+    int n, e, src;
+    if (seg == 0) {
+        if (idx >= cnt * 32) return;
+        n = idx >> 5;
+        const int k = idx & 31, ee = k & 15, r = ee >> 2, c = ee & 3;
+        const int sr = (k < 16) ? c : r, sc = (k < 16) ? r : c;          // Aq = (E.m)^T, Oq = E.m
+        q.kind = 0; q.rr = sr; q.cc = sc;
+        src = GTA_VREP_INV + sr * 4 + sc; e = k;
+    } else if (seg == 1) {
+        if (idx >= cnt * 24) return;
+        n = idx / 24;
+        const int k = idx - 24 * n, t = k >= 12, kk = t ? k - 12 : k, r = kk >> 2, c = kk & 3, cz = c < 3 ? c : 0;
+        q.kind = c < 3 ? 1 : 2;
+        src = GTA_VREP_D1 + (t ? cz * 3 + r : r * 3 + cz); e = (t ? GTA_QREC_D1T : GTA_QREC_D1) + kk;
+    } else {
+        if (idx >= cnt * 40) return;
+        n = idx / 40;
+        const int k = idx - 40 * n, r = k >> 3, c = k & 7, cz = c < 5 ? c : 0;
+        q.kind = c < 5 ? 1 : 2;
+        src = GTA_VREP_D2 + (seg == 3 ? cz * 5 + r : r * 5 + cz); e = (seg == 3 ? GTA_QREC_D2T : GTA_QREC_D2) + k;
+    }
+    q.dst = n * GTA_QREC + e;
+    q.val = base[(long)n * GTA_VREP_STRIDE + src];
+}
+GTA_DEV void qrec_seg_store(const QrecItem& q, float* qrec, float tc) {
+    if (q.dst < 0) return;
+    float v = q.val;
+    if (q.kind == 0) v *= (q.rr == 3) ? (q.cc == 3 ? 1.f : 0.f) : (q.cc == 3 ? tc : 1.f);
+    else if (q.kind == 2) v = 0.f;
+    qrec[q.dst] = v;
+}
+// items a wave's segment list holds for cnt views
+GTA_DEV int qrec_seg_count(int seg, int cnt) { return cnt * (seg == 0 ? 32 : seg == 1 ? 24 : 40); }
+GTA_DEV void stage_qrec(float* qrec, const float* vrep_q, int b, int Nq, int n0, int cnt, float tc, int tid,
+                        int nthreads, int first = 0) {
+    const int total = cnt * GTA_QREC;
+    for (int i0 = tid + first; i0 < total; i0 += 3 * nthreads) {
+        QrecBatch q;
+        qrec_batch_load(q, vrep_q, b, Nq, n0, cnt, i0, nthreads);
+        qrec_batch_store(q, qrec, tc, i0, nthreads);
     }
 }
 GTA_DEV void stage_krec(float* krec, const float* vrep_k, int b, int Nk, float tc, int tid, int nthreads) {

@@ -199,14 +199,16 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
     if (GTA_DBG(512u)) return;                                          // ablation: bare launch
 #ifdef GTA_ABLATE
 #define GTA_STAMP(k) do { if (p.prof && tid == 0) p.prof[(long)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define GTA_STAMP2(k) do { if (p.prof && tid == 0) p.prof[((long)gridDim.x + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define GTA_STAMP(k) do { } while (0)
+#define GTA_STAMP2(k) do { } while (0)
 #endif
     GTA_STAMP(0);
 #ifdef GTA_ABLATE
     if (p.prof && tid == 0) p.prof[(long)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();   // 100 MHz reference
 #endif
-    dma_stage<DHP, RB>(ring, 0, kvimg, wave, lane);                   // tile 0 on its way
+    if constexpr (RB != 1) dma_stage<DHP, RB>(ring, 0, kvimg, wave, lane);      // tile 0 on its way
 
     // views touched by this query tile: records are staged relative to n_first
     const int t_last = (q0 + BM - 1 < p.Tq ? q0 + BM - 1 : p.Tq - 1);
@@ -223,58 +225,86 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
     // behind the view records; ring stage 1 is free from the start, so tile 1 is requested together with tile 0.
     // The chunk kind of lanes 0-31 (even chunk) and 32-63 (odd chunk) is the same constant for every se3/se3,
     // so3/so3, so2/so2 pair of the shipped layouts (the select folds); a mixed pair runs both kinds under exec masks.
-    if (n_tiles > 1) dma_stage<DHP, RB>(ring, 1, kvimg + (long)S::STAGE, wave, lane);
+    // Request order = need order (loads return in order): the Q chunks gate the transform, the view records gate the
+    // barrier in front of it, the tiles are not read before the loop -- so the 12 tile-DMA instructions go out last.
     const int my_r = wave * 32 + l31;
     int my_t = q0 + my_r;
     my_t = my_t < p.Tq ? my_t : p.Tq - 1;
     u32x4_t qraw[KS][RAWN];
     f32x2_t qcs[KS][4];
-    uint32_t dl[KS];
+    const float tc = p.trans_coeff ? *p.trans_coeff : 1.0f;            // (asked for first: the record stores below need it)
+    // chunk descriptor of this lane's chunk 2ks + lh
+#define GTA_DL(ks) (lh ? GTA_DESC(2 * (ks) + 1) : GTA_DESC(2 * (ks)))
+    // `full`: dh fills the padded head, so every chunk of every lane exists and no per-lane guard (exec save/restore per
+    // load) is needed: the specialised path is straight-line code with immediate offsets off one row pointer.
+    const bool full = ch_real == CHP;
+    const char* qrow = qg + (long)my_t * q_rs + lh * 8 * ESZ;           // chunk 2ks + lh sits at + ks * 16 * ESZ
+    const float* csrow = p.cs_q ? p.cs_q + ((long)b * p.Tq + my_t) * 2 * p.nso2 : nullptr;
+    GTA_STAMP2(0);
+    auto q_loads = [&](auto FULLC) {
+        constexpr bool FULL = decltype(FULLC)::value;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const int c = 2 * ks + lh;
-        dl[ks] = lh ? GTA_DESC(2 * ks + 1) : GTA_DESC(2 * ks);
-        if (c < ch_real && !GTA_DBG(32u)) {
-            const char* rp = qg + (long)my_t * q_rs + c * 8 * ESZ;
+        for (int ks = 0; ks < KS; ++ks) {
+            if ((FULL || 2 * ks + lh < ch_real) && !GTA_DBG(32u)) {
 #pragma unroll
-            for (int k2 = 0; k2 < RAWN; ++k2) qraw[ks][k2] = *reinterpret_cast<const u32x4_t*>(rp + 16 * k2);
-            if (p.cs_q) load_cs(dl[ks], p.cs_q + ((long)b * p.Tq + my_t) * 2 * p.nso2, qcs[ks]);
+                for (int k2 = 0; k2 < RAWN; ++k2) qraw[ks][k2] = *reinterpret_cast<const u32x4_t*>(qrow + ks * 16 * ESZ + 16 * k2);
+                if (csrow) load_cs(GTA_DL(ks), csrow, qcs[ks]);
+            }
+        }
+    };
+    if (full) q_loads(std::true_type{}); else q_loads(std::false_type{});
+    GTA_STAMP2(1);
+    const bool want_rec = p.vrep_q && !GTA_DBG(128u);
+    QrecItem rb0;
+    if (want_rec) qrec_seg_load(rb0, p.vrep_q, b, p.Nq, n_first, n_cnt, wave, lane);
+    GTA_STAMP2(2);
+    dma_stage<DHP, RB>(ring, 0, kvimg, wave, lane);
+    if (n_tiles > 1) dma_stage<DHP, RB>(ring, 1, kvimg + (long)S::STAGE, wave, lane);
+    GTA_STAMP(7);                                                        // (all prologue loads issued)
+    if (want_rec) {
+        qrec_seg_store(rb0, qrec, tc);
+        for (int idx = lane + 64; idx < qrec_seg_count(wave, n_cnt); idx += 64) {       // (more than one view per tile only)
+            QrecItem it;
+            qrec_seg_load(it, p.vrep_q, b, p.Nq, n_first, n_cnt, wave, idx);
+            qrec_seg_store(it, qrec, tc);
         }
     }
-    GTA_STAMP(7);                                                        // (all prologue loads issued)
-    if (p.vrep_q && !GTA_DBG(128u)) stage_qrec(qrec, p.vrep_q, b, p.Nq, n_first, n_cnt, p.trans_coeff ? *p.trans_coeff : 1.0f, tid, NT);
+    GTA_STAMP2(3);
     __syncthreads();
     GTA_STAMP(1);
     float qsq = 0.f;                                   // this lane's share of |q'_row|^2 (bf16-rounded values)
     const float* rec_q = qrec + (view_of(my_t, p.Pq, p.invPq) - n_first) * GTA_QREC;
+    auto q_xform = [&](auto FULLC) {
+        constexpr bool FULL = decltype(FULLC)::value;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const int c = 2 * ks + lh;
-        float x[1][8];
-        if (c < ch_real) {
-            if (ESZ == 2) {
-                unpack8(qraw[ks][0], x[0]);
+        for (int ks = 0; ks < KS; ++ks) {
+            float x[1][8];
+            if (FULL || 2 * ks + lh < ch_real) {
+                if (ESZ == 2) {
+                    unpack8(qraw[ks][0], x[0]);
+                } else {
+#pragma unroll
+                    for (int k2 = 0; k2 < RAWN; ++k2) {
+                        x[0][4 * k2 + 0] = __uint_as_float(qraw[ks][k2].x); x[0][4 * k2 + 1] = __uint_as_float(qraw[ks][k2].y);
+                        x[0][4 * k2 + 2] = __uint_as_float(qraw[ks][k2].z); x[0][4 * k2 + 3] = __uint_as_float(qraw[ks][k2].w);
+                    }
+                }
+                if (GTA_DL(ks)) chunk_apply<false, 1>(GTA_DL(ks), rec_q + GTA_QREC_A, rec_q + GTA_QREC_D1, rec_q + GTA_QREC_D2, qcs[ks], x);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[0][i] *= qscale;
             } else {
 #pragma unroll
-                for (int k2 = 0; k2 < RAWN; ++k2) {
-                    x[0][4 * k2 + 0] = __uint_as_float(qraw[ks][k2].x); x[0][4 * k2 + 1] = __uint_as_float(qraw[ks][k2].y);
-                    x[0][4 * k2 + 2] = __uint_as_float(qraw[ks][k2].z); x[0][4 * k2 + 3] = __uint_as_float(qraw[ks][k2].w);
-                }
+                for (int i = 0; i < 8; ++i) x[0][i] = 0.f;
             }
-            if (dl[ks]) chunk_apply<false, 1>(dl[ks], rec_q + GTA_QREC_A, rec_q + GTA_QREC_D1, rec_q + GTA_QREC_D2, qcs[ks], x);
+            const u32x4_t qw = pack8(x[0]);
+            qf[0][ks] = __builtin_bit_cast(bf16x8_t, qw);
+            float qr[8];
+            unpack8(qw, qr);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) x[0][i] *= qscale;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) x[0][i] = 0.f;
+            for (int i = 0; i < 8; ++i) qsq += qr[i] * qr[i];
         }
-        const u32x4_t qw = pack8(x[0]);
-        qf[0][ks] = __builtin_bit_cast(bf16x8_t, qw);
-        float qr[8];
-        unpack8(qw, qr);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) qsq += qr[i] * qr[i];
-    }
+    };
+    if (full) q_xform(std::true_type{}); else q_xform(std::false_type{});
     qsq += __shfl_xor(qsq, 32);                                          // the row's other chunk parity
     qn[0] = sqrtf(qsq) * 1.0001f;
     GTA_STAMP(2);
@@ -672,31 +702,36 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
         const int tC = rowok ? tE : p.Tq - 1;
         constexpr int NP = CHP / 2;
         f32x2_t ocs[NP][4];
-        uint32_t dle[NP];
-#pragma unroll
-        for (int kp = 0; kp < NP; ++kp) {
-            dle[kp] = lh ? GTA_DESC(2 * kp + 1) : GTA_DESC(2 * kp);
-            if (xo && p.cs_q && 2 * kp + lh < ch_real) load_cs(dle[kp], p.cs_q + ((long)b * p.Tq + tC) * 2 * p.nso2, ocs[kp]);
-        }
+        const bool fast = ch_real == CHP && q0 + BM <= p.Tq;          // no ragged channel, no ragged row: no per-lane guards
+        const float* csrow_o = (xo && p.cs_q) ? p.cs_q + ((long)b * p.Tq + tC) * 2 * p.nso2 : nullptr;
         const float* rec_o = qrec + (view_of(tC, p.Pq, p.invPq) - n_first) * GTA_QREC;
+        char* orow = og + (long)tC * o_rs + lh * 8 * ESZ;                // chunk 2kp + lh goes to + kp * 16 * ESZ
+        auto o_items = [&](auto FASTC) {
+            constexpr bool FAST = decltype(FASTC)::value;
+            if (csrow_o) {
 #pragma unroll
-        for (int kp = 0; kp < NP; ++kp) {
-            const int d = (2 * kp) >> 2, ge = (2 * kp) & 3;
-            float x[1][8];
+                for (int kp = 0; kp < NP; ++kp)
+                    if (FAST || 2 * kp + lh < ch_real) load_cs(GTA_DL(kp), csrow_o, ocs[kp]);
+            }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t ua = __float_as_uint(oacc[0][d][4 * ge + i] * inv_l[0]);         // half lh of the even chunk
-                const uint32_t ub = __float_as_uint(oacc[0][d][4 * (ge + 1) + i] * inv_l[0]);   // half lh of the odd chunk
-                const auto sw = __builtin_amdgcn_permlane32_swap(ua, ub, false, false);         // ua[32..63] <-> ub[0..31]
-                x[0][i] = __uint_as_float(sw[0]);
-                x[0][4 + i] = __uint_as_float(sw[1]);
+            for (int kp = 0; kp < NP; ++kp) {
+                const int d = (2 * kp) >> 2, ge = (2 * kp) & 3;
+                float x[1][8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t ua = __float_as_uint(oacc[0][d][4 * ge + i] * inv_l[0]);         // half lh of the even chunk
+                    const uint32_t ub = __float_as_uint(oacc[0][d][4 * (ge + 1) + i] * inv_l[0]);   // half lh of the odd chunk
+                    const auto sw = __builtin_amdgcn_permlane32_swap(ua, ub, false, false);         // ua[32..63] <-> ub[0..31]
+                    x[0][i] = __uint_as_float(sw[0]);
+                    x[0][4 + i] = __uint_as_float(sw[1]);
+                }
+                if (FAST || (rowok && 2 * kp + lh < ch_real)) {
+                    if (xo && GTA_DL(kp)) chunk_apply<true, 1>(GTA_DL(kp), rec_o + GTA_QREC_O, rec_o + GTA_QREC_D1T, rec_o + GTA_QREC_D2T, ocs[kp], x);
+                    if (!GTA_DBG(64u) || x[0][0] == 123.f) gstore_chunk2<ESZ>(orow + kp * 16 * ESZ, 0, x[0]);
+                }
             }
-            const int c = 2 * kp + lh;
-            if (rowok && c < ch_real) {
-                if (xo && dle[kp]) chunk_apply<true, 1>(dle[kp], rec_o + GTA_QREC_O, rec_o + GTA_QREC_D1T, rec_o + GTA_QREC_D2T, ocs[kp], x);
-                if (!GTA_DBG(64u) || x[0][0] == 123.f) gstore_chunk2<ESZ>(og + (long)tE * o_rs, c, x[0]);
-            }
-        }
+        };
+        if (fast) o_items(std::true_type{}); else o_items(std::false_type{});
     } else {
     const int rgE = wave & 1, parE = wave >> 1;
 #pragma unroll 1
@@ -763,6 +798,8 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
     if (p.prof && tid == 0) p.prof[(long)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
 #endif
 #undef GTA_STAMP
+#undef GTA_STAMP2
+#undef GTA_DL
 }
 
 template <int DHP, int ESZ, int RB, int LAYOUT>

@@ -43,6 +43,15 @@ __global__ __launch_bounds__(256, 2) void probe(const char* __restrict__ src, ui
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             continue;
+        } else if (MODE == 4) {
+            // the DMA alone: how many bytes per clock does a CU's LDS-DMA path move (L2-resident source)?
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + i * 1024),
+                                                 (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            continue;
         } else if (MODE == 2) {
             // write last iteration's registers, then refill them
 #pragma unroll
@@ -87,5 +96,6 @@ int main() {
     run<1>("+ 6 x LDS-DMA (global_load_lds_dwordx4)", src, d, sink);
     run<2>("+ 6 x global_load_dwordx4 + 6 x ds_write_b128", src, d, sink);
     run<3>("+ 6 x LDS-DMA interleaved with the MFMAs", src, d, sink);
+    run<4>("6 x LDS-DMA per wave alone (24 KiB / workgroup)", src, d, sink);
     return 0;
 }

@@ -172,6 +172,13 @@ if __name__ == "__main__":
                 print(f"dbg={dbg}: kernel span {span_us:.1f} us by s_memrealtime; shader clock during the kernel {ghz:.3f} GHz")
             d = P[:, 7] - P[:, 0]
             print(f"   {'(start -> Q/cs loads issued)':28s} mean {d.mean():9.0f} ticks  min {d.min():9.0f} max {d.max():9.0f}")
+            if not nw8:
+                X = Pall[nwg:2 * nwg]
+                for nm, a_, b_ in (("start -> before Q loads", P[:, 0], X[:, 0]), ("Q/cs loads issue", X[:, 0], X[:, 1]),
+                                   ("record load issue", X[:, 1], X[:, 2]), ("tile DMA issue", X[:, 2], P[:, 7]),
+                                   ("wait + record stores", P[:, 7], X[:, 3]), ("barrier", X[:, 3], P[:, 1])):
+                    d = b_ - a_
+                    print(f"     {nm:26s} mean {d.mean():9.0f}  min {d.min():9.0f} max {d.max():9.0f}")
             for i, nm in enumerate(names):
                 d = P[:, i + 1] - P[:, i]
                 print(f"   {nm:28s} mean {d.mean():9.0f} ticks  min {d.min():9.0f} max {d.max():9.0f}")
