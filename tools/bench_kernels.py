@@ -187,6 +187,9 @@ if __name__ == "__main__":
             pass
             pass
         os.environ["GTA_DBG"] = "0"
+    if which == "dt":            # dh = 64 shapes: these run three workgroups per CU (151 VGPRs, 51 KB LDS)
+        report("DT", B, 16, 1, 1024, 1, 1024, {"so2": 64}, 16, 0)
+        report("CL-dec", B, 6, 3, 853, 2, 300, CL, 8, 0)
     if which in ("all", "others"):
         report("MS-dec", B, 8, 5, 512, 5, 256, MS, 6, 2)
         report("CL-enc", B, 6, 2, 300, 2, 300, CL, 8, 0)
