@@ -56,6 +56,7 @@ SHAPES = {
     "MS-enc": (1, 8, 5, 256, 5, 256, {"triv": 0, "se3": 48, "so3": 24, "so2": 24}, 6, 2),
     "MS-dec": (1, 8, 5, 512, 5, 256, {"triv": 0, "se3": 48, "so3": 24, "so2": 24}, 6, 2),
     "ragged": (1, 3, 3, 37, 2, 45, {"triv": 8, "se3": 16, "so2": 8}, 2, 0),
+    "many-views": (2, 2, 12, 20, 9, 28, {"triv": 0, "se3": 48, "so3": 24, "so2": 24}, 6, 2),
     "wide": (1, 2, 2, 160, 2, 96, {"se3": 64, "so2": 64}, 16, 0),                # dh = 128
     "wide-ragged": (1, 2, 3, 50, 2, 70, {"triv": 8, "se3": 48, "so3": 24, "so2": 24}, 6, 2),   # dh = 104 -> padded 128
 }
