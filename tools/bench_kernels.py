@@ -131,6 +131,40 @@ if __name__ == "__main__":
         for i2, nm in enumerate(names):
             print(f"   {nm:30s} {P[:,8+i2].mean():9.0f} cycles / WG   {P[:,8+i2].mean()/20:7.0f} per tile")
         print(f"   slow-path decisions per WG (of 19): mean {P[:,15].mean():.2f} max {P[:,15].max():.0f}")
+    if which == "ctx":
+        # the attention kernel in the bench's context: right behind the K/V pre-pass of the same step (instrumented build).
+        # Prints its span and shader clock there and in a back-to-back loop of itself.
+        import ctypes
+        q, k, v, packed, L = setup(B, 8, 5, 256, 5, 256, MS, 6, 2, torch.bfloat16)
+        VT = native.FLAG_V_TRANSFORM
+        out = torch.empty(B, 1280, 8, 96, device="cuda", dtype=torch.bfloat16).permute(0, 2, 1, 3)
+        desc = native.make_desc(q, k, v, out, MS, L, 5, 5, 96 ** -0.5, VT)
+        ws = torch.empty(native.attn_fwd_workspace_bytes(desc), device="cuda", dtype=torch.uint8)
+        fn_both, _ = raw_call(q, k, v, packed, MS, L, VT, ws)
+        fn_prep, _ = raw_call(q, k, v, packed, MS, L, VT | native.FLAG_PREP_ONLY, ws)
+        fn_flash, _ = raw_call(q, k, v, packed, MS, L, VT | native.FLAG_KV_READY, ws)
+        nwg = B * 8 * 10
+        def measure(label, warm, pre):
+            for _ in range(20):
+                warm()
+            prof = torch.zeros(nwg * 3, 8, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            pre()
+            native.lib().gta_debug_set_profile_buffer(ctypes.c_void_p(prof.data_ptr()))
+            fn_flash()
+            torch.cuda.synchronize()
+            native.lib().gta_debug_set_profile_buffer(None)
+            P = prof.cpu().double()[:nwg]
+            real = P[:, 6] - P[:, 5]
+            ok = real > 0
+            ghz = ((P[:, 4] - P[:, 0])[ok] / real[ok]).mean() * 0.1
+            span = (P[:, 6].max() - P[:, 5].min()) / 100.0
+            loop = (P[:, 3] - P[:, 2]).mean()
+            print(f"{label:44s} span {span:7.1f} us  clock {ghz:.3f} GHz  tile loop {loop:8.0f} cycles / workgroup", flush=True)
+        for _ in range(2):
+            measure("attention kernel after itself", fn_flash, lambda: None)
+            measure("attention kernel after the K/V pre-pass", fn_both, fn_prep)
+            measure("after the pre-pass + 100 us idle", fn_both, lambda: (fn_prep(), torch.cuda._sleep(200000)))
     if which == "timeline":
         import ctypes
         q, k, v, packed, L = setup(B, 8, 5, 256, 5, 256, MS, 6, 2, torch.bfloat16)
