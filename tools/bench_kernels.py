@@ -160,7 +160,8 @@ if __name__ == "__main__":
             ghz = ((P[:, 4] - P[:, 0])[ok] / real[ok]).mean() * 0.1
             span = (P[:, 6].max() - P[:, 5].min()) / 100.0
             loop = (P[:, 3] - P[:, 2]).mean()
-            print(f"{label:44s} span {span:7.1f} us  clock {ghz:.3f} GHz  tile loop {loop:8.0f} cycles / workgroup", flush=True)
+            print(f"{label:44s} span {span:7.1f} us  clock {ghz:.3f} GHz  kernel {span * ghz:7.1f}k cycles  "
+                  f"tile loop {loop:8.0f} cycles / workgroup", flush=True)
         for _ in range(2):
             measure("attention kernel after itself", fn_flash, lambda: None)
             measure("attention kernel after the K/V pre-pass", fn_both, fn_prep)
@@ -203,7 +204,8 @@ if __name__ == "__main__":
                 ok = real > 0
                 ghz = ((P[:, 4] - P[:, 0])[ok] / real[ok]).mean() * 0.1
                 span_us = (P[:, 6].max() - P[:, 5].min()) / 100.0
-                print(f"dbg={dbg}: kernel span {span_us:.1f} us by s_memrealtime; shader clock during the kernel {ghz:.3f} GHz")
+                print(f"dbg={dbg}: kernel span {span_us:.1f} us by s_memrealtime; shader clock during the kernel {ghz:.3f} GHz; "
+                      f"KERNEL CYCLES {span_us * ghz:.1f}k (span x clock: use this, not the span, to compare builds)")
             d = P[:, 7] - P[:, 0]
             print(f"   {'(start -> Q/cs loads issued)':28s} mean {d.mean():9.0f} ticks  min {d.min():9.0f} max {d.max():9.0f}")
             if not nw8:
