@@ -204,13 +204,15 @@ GTA_DEV void static_for(F&& f) { static_for_impl(static_cast<F&&>(f), std::make_
 #endif
 constexpr int ABL = GTA_ABL;
 constexpr int NSTAGE = 3;
-// Skewed tile loop in the 128-row kernel (QK^T of tile j+1 beside the softmax of tile j).  Measured on MI355X
-// (MSN encoder, B=32): 214 us vs 212 us un-skewed at 20 key tiles, 363 vs 372 us at 40, 105 vs 96 us at 5 --
-// the softmax VALU is already hidden by the co-resident wave (ablation: removing every exp saves 2 %), what is
-// left is MFMA + LDS-DMA issue + the per-workgroup prologue/epilogue.  Off by default (it also spills ~14 VGPRs
-// outside the loop at dh = 96); build with -DGTA_PIPE1=1 to select it.
+// Skewed tile loop in the 128-row kernel (QK^T of tile j+1 beside the softmax of tile j), used at dh = 96.
+// Measured on MI355X by CYCLE counts (tools/bench_kernels.py timeline on an instrumented build; MSN encoder, B=32):
+// 362-366k shader cycles per launch against 396-406k un-skewed (tile loop 48.5k vs 52.7k cycles per workgroup), -9 %.
+// In microseconds it first looked neutral (214 vs 212 us): the more efficient loop draws more power and is granted a
+// lower clock (1.88 vs 1.92 GHz), and timings from separate launches differ by more than that anyway (the clock moves
+// between 1.69 and 2.13 GHz, profiles/r01/README.md).  7 VGPRs spill outside the loop.  -DGTA_PIPE1=0 selects the
+// plain loop.
 #ifndef GTA_PIPE1
-#define GTA_PIPE1 0
+#define GTA_PIPE1 1
 #endif
 constexpr bool PIPE1 = GTA_PIPE1 != 0;
 constexpr float DEFER_THR = 8.0f;      // (pipelined kernel) running max moves when a row's tile max exceeds it by this

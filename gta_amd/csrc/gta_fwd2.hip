@@ -434,8 +434,18 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
         }
     }
     const bool has_tail = (p.Tk & (BN - 1)) != 0;
+    // loop-shape experiments (compile-time; compared by cycle counts with tools/bench_kernels.py timeline)
+#ifndef GTA_KSPLIT
+#define GTA_KSPLIT 0
+#endif
+#ifndef GTA_DMA_LATE
+#define GTA_DMA_LATE 0
+#endif
+#ifndef GTA_PRIO
+#define GTA_PRIO 0
+#endif
 
-    if constexpr (RB == 1 && PIPE1 && DHP <= 96) {
+    if constexpr (RB == 1 && PIPE1 && DHP == 96) {      // (dh = 64: 230 VGPRs would cost the third workgroup per CU)
     // ---- skewed tile loop (RB == 1): the QK^T MFMAs of tile j+1 issue beside the softmax VALU of tile j ----
     // Two of these waves share a SIMD (two workgroups per CU).  Measured (tests/probes/probe_coissue.hip): two
     // waves whose streams each mix MFMA and VALU reach the matrix-pipe rate together, while the unskewed loop
@@ -581,7 +591,7 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
         if (j + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
         else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (j + 2 < n_tiles) dma_stage<DHP, RB>(ring, (j + 2) % NSTAGE, kvimg + (long)(j + 2) * S::STAGE, wave, lane);
+        if (!GTA_DMA_LATE && j + 2 < n_tiles) dma_stage<DHP, RB>(ring, (j + 2) % NSTAGE, kvimg + (long)(j + 2) * S::STAGE, wave, lane);
 
         if constexpr (ABL & 512) {        // sensitivity experiment: 24 extra scalar issue slots per tile
             asm volatile("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n"
@@ -604,6 +614,38 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
 
         // ---- S^T = K' Q'^T for the RB row blocks: each K' fragment is read once and used RB times ----
         f32x16_t s[RB][2];
+        if (GTA_PRIO) __builtin_amdgcn_s_setprio(GTA_PRIO == 1 ? 1 : 0);
+        if constexpr (RB == 1 && GTA_KSPLIT && (KS % 2 == 0)) {
+            // K' fragments in two batches: the second is requested once the first batch's MFMAs have issued
+            constexpr int H2 = KS / 2;
+            bf16x8_t ka[H2], kb2[H2];
+#pragma unroll
+            for (int ks = 0; ks < H2; ++ks) {
+                ka[ks] = *reinterpret_cast<const bf16x8_t*>(kf + koff[ks]);
+                kb2[ks] = *reinterpret_cast<const bf16x8_t*>(kf + koff[ks] + 32 * CHP * 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            s[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[0], qf[0][0], msplat[0], 0, 0, 0);
+            s[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2[0], qf[0][0], msplat[0], 0, 0, 0);
+#pragma unroll
+            for (int ks = 1; ks < H2; ++ks) {
+                s[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], qf[0][ks], s[0][0], 0, 0, 0);
+                s[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2[ks], qf[0][ks], s[0][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8_t kc[H2], kd[H2];
+#pragma unroll
+            for (int ks = 0; ks < H2; ++ks) {
+                kc[ks] = *reinterpret_cast<const bf16x8_t*>(kf + koff[H2 + ks]);
+                kd[ks] = *reinterpret_cast<const bf16x8_t*>(kf + koff[H2 + ks] + 32 * CHP * 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < H2; ++ks) {
+                s[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc[ks], qf[0][H2 + ks], s[0][0], 0, 0, 0);
+                s[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kd[ks], qf[0][H2 + ks], s[0][1], 0, 0, 0);
+            }
+        } else
         {
             bf16x8_t ka[KS], kb2[KS];
 #pragma unroll
@@ -623,6 +665,8 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
                 }
             }
         }
+        if (GTA_DMA_LATE && j + 2 < n_tiles) dma_stage<DHP, RB>(ring, (j + 2) % NSTAGE, kvimg + (long)(j + 2) * S::STAGE, wave, lane);
+        if (GTA_PRIO) __builtin_amdgcn_s_setprio(GTA_PRIO == 1 ? 0 : 1);
         // the tile's key-norm bound (scalar load from the top of the iteration; the K' reads are consumed, so this
         // wait is free -- it must sit BEFORE the V' reads below or it would drain them too)
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(kn_bits));
@@ -653,6 +697,7 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
         }
 
         // ---- O^T += V'^T P^T, slab-major; reads stay one slab ahead (LDS returns in order) ----
+        if (GTA_PRIO) __builtin_amdgcn_s_setprio(GTA_PRIO == 1 ? 1 : 0);
         pv_reads_slab<DHP, 1>(vbase, voff, v1l, v1h);
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * DB) : "memory");
         __builtin_amdgcn_sched_barrier(0);
