@@ -465,14 +465,26 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
     auto s_fence1 = [&](f32x16_t (&s)[2]) { asm volatile("" : "+v"(s[0])); asm volatile("" : "+v"(s[1])); };
     auto step = [&](f32x16_t (&sc)[2], f32x16_t (&sn)[2], int j, auto LASTC) {
         constexpr bool LAST = decltype(LASTC)::value;
+#ifndef GTA_KNEARLY
+#define GTA_KNEARLY 1
+#endif
+#ifndef GTA_VEARLY
+#define GTA_VEARLY 0
+#endif
+        uint32_t kn_bits;
+        if (GTA_KNEARLY) {     // the tile's key-norm bound is asked for before the waits, so it is there when they are over
+            const float* kn_ptr = p.kn + __builtin_amdgcn_readfirstlane((b * p.H + h) * n_tiles + j);
+            asm volatile("s_load_dword %0, %1, 0x0" : "=s"(kn_bits) : "s"(kn_ptr) : "memory");
+        }
         // tile j+1 has landed, everyone is past B(j-1): its stage takes tile j+2
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if constexpr (!(ABL & 256)) __builtin_amdgcn_s_barrier();
         if (!(ABL & 32) && j + 2 < n_tiles) dma_stage<DHP, RB>(ring, (j + 2) % NSTAGE, kvimg + (long)(j + 2) * S::STAGE, wave, lane);
         const char* kf = ring + ((j + 1) % NSTAGE) * S::STAGE;          // K'(j+1)
         const uint32_t vbase = lds_addr(ring + (j % NSTAGE) * S::STAGE + S::IMG);   // V'(j)
-        uint32_t kn_bits;
-        {
+        if (GTA_KNEARLY) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(kn_bits));       // (nothing else is outstanding on that counter here)
+        } else {
             const float* kn_ptr = p.kn + __builtin_amdgcn_readfirstlane((b * p.H + h) * n_tiles + j);
             asm volatile("s_load_dword %0, %1, 0x0" : "=s"(kn_bits) : "s"(kn_ptr) : "memory");
         }
@@ -487,7 +499,7 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
         static_for<KLA>([&](auto KC) { k_load(KC); });
         // decision for tile j (sc = S'(j) relative to m_run): lazy-softmax full path only when needed
         {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(kn_bits));
+            if (!GTA_KNEARLY) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(kn_bits));
             const float kn_j = __uint_as_float(kn_bits);
             const bool tail = has_tail && j == n_tiles - 1;
             const bool need = (j == 0) || tail || (qn[0] * kn_j - m_run[0] > BOUND_THR);
@@ -499,8 +511,12 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
             s_fence1(sc);
         }
         __builtin_amdgcn_sched_barrier(0);
+        u32x2_t v0l[DB], v0h[DB];
         static_for<GA>([&](auto GC) {
             constexpr int g = decltype(GC)::value, ks = g >> 1, hh = g & 1;
+            // (VEARLY: slab 0 of V'(j) is requested three gaps before phase B needs it; no compiler-tracked LDS read is issued
+            //  after this gap, so the counted waits of phase B still see only the transpose-reads)
+            if constexpr (GTA_VEARLY != 0 && g == GA - GTA_VEARLY) pv_reads_slab<DHP, 0>(vbase, voff, v0l, v0h);
             if constexpr (!LAST) {
                 if constexpr (ABL & 64) { if (ks == 0) sn[hh] = msplat[0]; }
                 else if constexpr (ks == 0) sn[hh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[0][hh], qf[0][0], msplat[0], 0, 0, 0);
@@ -535,12 +551,12 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
             __builtin_amdgcn_sched_barrier(0);
         });
         // ---- B(j): O^T += V'^T P^T, slab-major; reads stay one slab ahead (LDS returns in order) ----
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (no compiler-tracked LDS read is in flight past here)
-        u32x2_t v0l[DB], v0h[DB], v1l[DB], v1h[DB], v2l[DB], v2h[DB], v3l[DB], v3h[DB];
+        if (GTA_VEARLY == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (no compiler-tracked LDS read is in flight past here)
+        u32x2_t v1l[DB], v1h[DB], v2l[DB], v2h[DB], v3l[DB], v3h[DB];
         bf16x8_t pfb[1][2][2];
         pfb[0][0][0] = __builtin_bit_cast(bf16x8_t, pfr[0][0]); pfb[0][0][1] = __builtin_bit_cast(bf16x8_t, pfr[0][1]);
         pfb[0][1][0] = __builtin_bit_cast(bf16x8_t, pfr[1][0]); pfb[0][1][1] = __builtin_bit_cast(bf16x8_t, pfr[1][1]);
-        pv_reads_slab<DHP, 0>(vbase, voff, v0l, v0h);
+        if (GTA_VEARLY == 0) pv_reads_slab<DHP, 0>(vbase, voff, v0l, v0h);
         pv_reads_slab<DHP, 1>(vbase, voff, v1l, v1h);
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * DB) : "memory");
         __builtin_amdgcn_sched_barrier(0);
