@@ -18,9 +18,19 @@ def short(name):
     return (m.group(1) + (m.group(2) or "")) if m else None
 
 
+def latest(files):
+    """gpurun merges every call's outputs into the same local directory: keep the newest run (highest numeric prefix)
+    of each directory only."""
+    by_dir = collections.defaultdict(list)
+    for f in files:
+        m = re.match(r"(\d+)_", f.rsplit("/", 1)[-1])
+        by_dir[f.rsplit("/", 1)[0]].append((int(m.group(1)) if m else -1, f))
+    return [max(v)[1] for v in by_dir.values()]
+
+
 def main(src, dst):
     out = {}
-    for f in glob.glob(f"{src}/stats/**/*_kernel_stats.csv", recursive=True):
+    for f in latest(glob.glob(f"{src}/stats/**/*_kernel_stats.csv", recursive=True)):
         for r in csv.DictReader(open(f)):
             k = short(r["Name"])
             if k:
@@ -28,7 +38,7 @@ def main(src, dst):
                 out[k]["avg_us"] = round(float(r["AverageNs"]) / 1e3, 2)
                 out[k]["min_us"] = round(float(r["MinNs"]) / 1e3, 2)
                 out[k]["pct_of_gpu_time"] = float(r["Percentage"])
-    for f in glob.glob(f"{src}/pmc_*/**/*_counter_collection.csv", recursive=True):
+    for f in latest(glob.glob(f"{src}/pmc_*/**/*_counter_collection.csv", recursive=True)):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
