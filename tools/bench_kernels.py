@@ -166,17 +166,23 @@ if __name__ == "__main__":
             measure("attention kernel after itself", fn_flash, lambda: None)
             measure("attention kernel after the K/V pre-pass", fn_both, fn_prep)
             measure("after the pre-pass + 100 us idle", fn_both, lambda: (fn_prep(), torch.cuda._sleep(200000)))
-    if which == "timeline":
+    if which in ("timeline", "timeline_dt"):
         import ctypes
-        q, k, v, packed, L = setup(B, 8, 5, 256, 5, 256, MS, 6, 2, torch.bfloat16)
+        if which == "timeline_dt":       # the dh = 64 pure-so2 shape (three workgroups per CU with the plain loop)
+            H_, Nv, Pv, FD, so2_, so3_ = 16, 1, 1024, {"so2": 64}, 16, 0
+        else:
+            H_, Nv, Pv, FD, so2_, so3_ = 8, 5, 256, MS, 6, 2
+        MS = FD
+        q, k, v, packed, L = setup(B, H_, Nv, Pv, Nv, Pv, MS, so2_, so3_, torch.bfloat16)
         VT = native.FLAG_V_TRANSFORM
-        out = torch.empty(B, 1280, 8, 96, device="cuda", dtype=torch.bfloat16).permute(0, 2, 1, 3)
-        desc = native.make_desc(q, k, v, out, MS, L, 5, 5, 96 ** -0.5, VT)
+        dh_ = sum(MS.values())
+        out = torch.empty(B, Nv * Pv, H_, dh_, device="cuda", dtype=torch.bfloat16).permute(0, 2, 1, 3)
+        desc = native.make_desc(q, k, v, out, MS, L, Nv, Nv, dh_ ** -0.5, VT)
         ws = torch.empty(native.attn_fwd_workspace_bytes(desc), device="cuda", dtype=torch.uint8)
         raw_call(q, k, v, packed, MS, L, VT, ws)[0]()
         fn, _ = raw_call(q, k, v, packed, MS, L, VT | native.FLAG_KV_READY, ws)
         for nw8 in (0,):
-          nwg = B * 8 * (5 if nw8 else 10)
+          nwg = B * H_ * ((Nv * Pv + 127) // 128)
           fn, _ = raw_call(q, k, v, packed, MS, L, VT | native.FLAG_KV_READY | (native.FLAG_WG8 if nw8 else 0), ws)
           for dbg in (0,):
             os.environ["GTA_DBG"] = str(dbg)
