@@ -434,16 +434,6 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
         }
     }
     const bool has_tail = (p.Tk & (BN - 1)) != 0;
-    // loop-shape experiments (compile-time; compared by cycle counts with tools/bench_kernels.py timeline)
-#ifndef GTA_KSPLIT
-#define GTA_KSPLIT 0
-#endif
-#ifndef GTA_DMA_LATE
-#define GTA_DMA_LATE 0
-#endif
-#ifndef GTA_PRIO
-#define GTA_PRIO 0
-#endif
 
     if constexpr (RB == 1 && PIPE1 && DHP == 96) {      // (dh = 64: 230 VGPRs would cost the third workgroup per CU)
     // ---- skewed tile loop (RB == 1): the QK^T MFMAs of tile j+1 issue beside the softmax VALU of tile j ----
@@ -465,14 +455,10 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
     auto s_fence1 = [&](f32x16_t (&s)[2]) { asm volatile("" : "+v"(s[0])); asm volatile("" : "+v"(s[1])); };
     auto step = [&](f32x16_t (&sc)[2], f32x16_t (&sn)[2], int j, auto LASTC) {
         constexpr bool LAST = decltype(LASTC)::value;
-#ifndef GTA_KNEARLY
-#define GTA_KNEARLY 1
-#endif
-#ifndef GTA_VEARLY
-#define GTA_VEARLY 0
-#endif
+        // the tile's key-norm bound is asked for BEFORE the waits below, so it is there when they are over (measured:
+        // awaiting it together with the first K' fragment reads cost 4 % of the loop's cycles)
         uint32_t kn_bits;
-        if (GTA_KNEARLY) {     // the tile's key-norm bound is asked for before the waits, so it is there when they are over
+        {
             const float* kn_ptr = p.kn + __builtin_amdgcn_readfirstlane((b * p.H + h) * n_tiles + j);
             asm volatile("s_load_dword %0, %1, 0x0" : "=s"(kn_bits) : "s"(kn_ptr) : "memory");
         }
@@ -482,12 +468,7 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
         if (!(ABL & 32) && j + 2 < n_tiles) dma_stage<DHP, RB>(ring, (j + 2) % NSTAGE, kvimg + (long)(j + 2) * S::STAGE, wave, lane);
         const char* kf = ring + ((j + 1) % NSTAGE) * S::STAGE;          // K'(j+1)
         const uint32_t vbase = lds_addr(ring + (j % NSTAGE) * S::STAGE + S::IMG);   // V'(j)
-        if (GTA_KNEARLY) {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(kn_bits));       // (nothing else is outstanding on that counter here)
-        } else {
-            const float* kn_ptr = p.kn + __builtin_amdgcn_readfirstlane((b * p.H + h) * n_tiles + j);
-            asm volatile("s_load_dword %0, %1, 0x0" : "=s"(kn_bits) : "s"(kn_ptr) : "memory");
-        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(kn_bits));           // (nothing else is outstanding on that counter here)
         bf16x8_t kfr[KS][2];
         auto k_load = [&](auto KC) {
             constexpr int ks = decltype(KC)::value;
@@ -499,7 +480,6 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
         static_for<KLA>([&](auto KC) { k_load(KC); });
         // decision for tile j (sc = S'(j) relative to m_run): lazy-softmax full path only when needed
         {
-            if (!GTA_KNEARLY) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(kn_bits));
             const float kn_j = __uint_as_float(kn_bits);
             const bool tail = has_tail && j == n_tiles - 1;
             const bool need = (j == 0) || tail || (qn[0] * kn_j - m_run[0] > BOUND_THR);
@@ -511,12 +491,8 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
             s_fence1(sc);
         }
         __builtin_amdgcn_sched_barrier(0);
-        u32x2_t v0l[DB], v0h[DB];
         static_for<GA>([&](auto GC) {
             constexpr int g = decltype(GC)::value, ks = g >> 1, hh = g & 1;
-            // (VEARLY: slab 0 of V'(j) is requested three gaps before phase B needs it; no compiler-tracked LDS read is issued
-            //  after this gap, so the counted waits of phase B still see only the transpose-reads)
-            if constexpr (GTA_VEARLY != 0 && g == GA - GTA_VEARLY) pv_reads_slab<DHP, 0>(vbase, voff, v0l, v0h);
             if constexpr (!LAST) {
                 if constexpr (ABL & 64) { if (ks == 0) sn[hh] = msplat[0]; }
                 else if constexpr (ks == 0) sn[hh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[0][hh], qf[0][0], msplat[0], 0, 0, 0);
@@ -551,12 +527,12 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
             __builtin_amdgcn_sched_barrier(0);
         });
         // ---- B(j): O^T += V'^T P^T, slab-major; reads stay one slab ahead (LDS returns in order) ----
-        if (GTA_VEARLY == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (no compiler-tracked LDS read is in flight past here)
-        u32x2_t v1l[DB], v1h[DB], v2l[DB], v2h[DB], v3l[DB], v3h[DB];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (no compiler-tracked LDS read is in flight past here)
+        u32x2_t v0l[DB], v0h[DB], v1l[DB], v1h[DB], v2l[DB], v2h[DB], v3l[DB], v3h[DB];
         bf16x8_t pfb[1][2][2];
         pfb[0][0][0] = __builtin_bit_cast(bf16x8_t, pfr[0][0]); pfb[0][0][1] = __builtin_bit_cast(bf16x8_t, pfr[0][1]);
         pfb[0][1][0] = __builtin_bit_cast(bf16x8_t, pfr[1][0]); pfb[0][1][1] = __builtin_bit_cast(bf16x8_t, pfr[1][1]);
-        if (GTA_VEARLY == 0) pv_reads_slab<DHP, 0>(vbase, voff, v0l, v0h);
+        pv_reads_slab<DHP, 0>(vbase, voff, v0l, v0h);
         pv_reads_slab<DHP, 1>(vbase, voff, v1l, v1h);
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * DB) : "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -607,7 +583,7 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
         if (j + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
         else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (!GTA_DMA_LATE && j + 2 < n_tiles) dma_stage<DHP, RB>(ring, (j + 2) % NSTAGE, kvimg + (long)(j + 2) * S::STAGE, wave, lane);
+        if (j + 2 < n_tiles) dma_stage<DHP, RB>(ring, (j + 2) % NSTAGE, kvimg + (long)(j + 2) * S::STAGE, wave, lane);
 
         if constexpr (ABL & 512) {        // sensitivity experiment: 24 extra scalar issue slots per tile
             asm volatile("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n"
@@ -630,38 +606,6 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
 
         // ---- S^T = K' Q'^T for the RB row blocks: each K' fragment is read once and used RB times ----
         f32x16_t s[RB][2];
-        if (GTA_PRIO) __builtin_amdgcn_s_setprio(GTA_PRIO == 1 ? 1 : 0);
-        if constexpr (RB == 1 && GTA_KSPLIT && (KS % 2 == 0)) {
-            // K' fragments in two batches: the second is requested once the first batch's MFMAs have issued
-            constexpr int H2 = KS / 2;
-            bf16x8_t ka[H2], kb2[H2];
-#pragma unroll
-            for (int ks = 0; ks < H2; ++ks) {
-                ka[ks] = *reinterpret_cast<const bf16x8_t*>(kf + koff[ks]);
-                kb2[ks] = *reinterpret_cast<const bf16x8_t*>(kf + koff[ks] + 32 * CHP * 16);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            s[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[0], qf[0][0], msplat[0], 0, 0, 0);
-            s[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2[0], qf[0][0], msplat[0], 0, 0, 0);
-#pragma unroll
-            for (int ks = 1; ks < H2; ++ks) {
-                s[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], qf[0][ks], s[0][0], 0, 0, 0);
-                s[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2[ks], qf[0][ks], s[0][1], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            bf16x8_t kc[H2], kd[H2];
-#pragma unroll
-            for (int ks = 0; ks < H2; ++ks) {
-                kc[ks] = *reinterpret_cast<const bf16x8_t*>(kf + koff[H2 + ks]);
-                kd[ks] = *reinterpret_cast<const bf16x8_t*>(kf + koff[H2 + ks] + 32 * CHP * 16);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ks = 0; ks < H2; ++ks) {
-                s[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc[ks], qf[0][H2 + ks], s[0][0], 0, 0, 0);
-                s[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kd[ks], qf[0][H2 + ks], s[0][1], 0, 0, 0);
-            }
-        } else
         {
             bf16x8_t ka[KS], kb2[KS];
 #pragma unroll
@@ -681,8 +625,6 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
                 }
             }
         }
-        if (GTA_DMA_LATE && j + 2 < n_tiles) dma_stage<DHP, RB>(ring, (j + 2) % NSTAGE, kvimg + (long)(j + 2) * S::STAGE, wave, lane);
-        if (GTA_PRIO) __builtin_amdgcn_s_setprio(GTA_PRIO == 1 ? 0 : 1);
         // the tile's key-norm bound (scalar load from the top of the iteration; the K' reads are consumed, so this
         // wait is free -- it must sit BEFORE the V' reads below or it would drain them too)
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(kn_bits));
@@ -713,7 +655,6 @@ __global__ __launch_bounds__(256, (RB == 1 ? 2 : 1)) void gta_fwd2_kernel(const 
         }
 
         // ---- O^T += V'^T P^T, slab-major; reads stay one slab ahead (LDS returns in order) ----
-        if (GTA_PRIO) __builtin_amdgcn_s_setprio(GTA_PRIO == 1 ? 1 : 0);
         pv_reads_slab<DHP, 1>(vbase, voff, v1l, v1h);
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * DB) : "memory");
         __builtin_amdgcn_sched_barrier(0);
