@@ -52,6 +52,10 @@ SHAPES = {
     "DT": (1, 16, 1, 1024, 1, 1024, {"so2": 64}, 16, 0),
     "ragged": (1, 3, 3, 37, 2, 45, {"triv": 8, "se3": 16, "so2": 8}, 2, 0),     # tails on both sides
     # the dh = 128 kernel instances: a full head, and 104 channels padded to 128 (13 of 16 chunks, odd count)
+    # dh = 96 (the skewed-loop instance) with 1, 2 and 3 key tiles, ragged tails on both sides
+    "ms-1tile": (1, 2, 2, 70, 1, 40, {"triv": 0, "se3": 48, "so3": 24, "so2": 24}, 6, 2),
+    "ms-2tiles": (1, 2, 2, 70, 2, 50, {"triv": 0, "se3": 48, "so3": 24, "so2": 24}, 6, 2),
+    "ms-3tiles": (2, 2, 3, 45, 3, 50, {"triv": 0, "se3": 48, "so3": 24, "so2": 24}, 6, 2),
     "many-views": (2, 2, 12, 20, 9, 28, {"triv": 0, "se3": 48, "so3": 24, "so2": 24}, 6, 2),   # 7 views inside one 128-row tile
     "wide": (1, 2, 2, 160, 2, 96, {"se3": 64, "so2": 64}, 16, 0),
     "wide-ragged": (1, 2, 3, 50, 2, 70, {"triv": 8, "se3": 48, "so3": 24, "so2": 24}, 6, 2),
