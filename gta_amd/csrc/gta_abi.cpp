@@ -19,7 +19,7 @@ int gta_fwd_dispatch(const GtaFwdParams& p, int dhp, int esz, bool dma, int n_wg
 long gta_fwd2_workspace_bytes(int B, int H, int Tk, int dhp);
 long gta_fwd2_image_bytes(int B, int H, int Tk, int dhp);
 int gta_fwd2_lds_bytes(int dhp, int nq);
-int gta_fwd2_dispatch(GtaFwdParams& p, int dhp, int esz, bool run_prep, bool run_flash, int nw, hipStream_t stream);
+int gta_fwd2_dispatch(GtaFwdParams& p, int dhp, int esz, bool run_prep, bool run_flash, hipStream_t stream);
 int gta_bwd_dispatch(const GtaBwdParams& p, int dhp, int esz, hipStream_t stream);
 
 namespace {
@@ -184,7 +184,7 @@ extern "C" int gta_attn_fwd(const GtaAttnDesc* d, const void* q, const void* k, 
         p.kp = workspace;
         p.kn = (float*)((char*)workspace + ((gta_fwd2_image_bytes(d->B, d->H, d->Tk, padded_dh(d->dh)) + 255) & ~255L));
         rc = gta_fwd2_dispatch(p, padded_dh(d->dh), esz, !(d->flags & GTA_FLAG_KV_READY), !(d->flags & GTA_FLAG_PREP_ONLY),
-                               (d->flags & GTA_FLAG_WG8) ? 8 : 4, (hipStream_t)stream);
+                               (hipStream_t)stream);
         if (rc) return fail(rc, rc == GTA_E_LAUNCH ? hipGetErrorString(hipGetLastError()) : "no kernel instance");
         return GTA_OK;
     }
@@ -259,7 +259,7 @@ extern "C" int gta_attn_bwd(const GtaAttnDesc* d, const void* q, const void* k, 
         f.B = d->B; f.H = d->H; f.Tq = d->Tq; f.Tk = d->Tk; f.Nq = d->Nq; f.Nk = d->Nk;
         f.Pq = d->Tq / d->Nq; f.Pk = d->Tk / d->Nk; f.invPq = 1.0f / f.Pq; f.invPk = 1.0f / f.Pk;
         f.dh = d->dh; f.nso2 = d->d_so2 / 2; f.flags = d->flags; f.scale = d->scale;
-        rc = gta_fwd2_dispatch(f, padded_dh(d->dh), esz, true, false, 4, (hipStream_t)stream);
+        rc = gta_fwd2_dispatch(f, padded_dh(d->dh), esz, true, false, (hipStream_t)stream);
         if (rc) return fail(rc, "K/V pre-pass launch failed");
         kv_images = ws + L.off_kv;
     }

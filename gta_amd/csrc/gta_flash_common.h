@@ -1,4 +1,4 @@
-// gta_flash_common.h -- pieces shared by the two-stage forward kernels (gta_prep.hip, gta_fwd2.hip, gta_fwd3.hip):
+// gta_flash_common.h -- pieces shared by the two-stage forward kernels (gta_prep.hip, gta_fwd2.hip):
 // LDS / transpose-read helpers, per-view record staging, the compile-time loop, tile constants and the
 // ablation switches.  Everything has internal linkage (anonymous namespace): each .hip is its own module.
 #pragma once
@@ -196,13 +196,6 @@ GTA_DEV void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std:
 template <int N, class F>
 GTA_DEV void static_for(F&& f) { static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
 
-// GTA_ABL: ablation mask for timing experiments only (results are WRONG with any bit set):
-//   1 no exp/sum   2 no pack   4 no row max / decision   8 no V' reads   16 no K' reads   32 no DMA in the loop
-//   64 no QK^T MFMAs   128 no PV MFMAs   256 no barrier
-#ifndef GTA_ABL
-#define GTA_ABL 0
-#endif
-constexpr int ABL = GTA_ABL;
 constexpr int NSTAGE = 3;
 // Skewed tile loop in the 128-row kernel (QK^T of tile j+1 beside the softmax of tile j), used at dh = 96.
 // Measured on MI355X by CYCLE counts (tools/bench_kernels.py timeline on an instrumented build; MSN encoder, B=32):
@@ -215,7 +208,6 @@ constexpr int NSTAGE = 3;
 #define GTA_PIPE1 1
 #endif
 constexpr bool PIPE1 = GTA_PIPE1 != 0;
-constexpr float DEFER_THR = 8.0f;      // (pipelined kernel) running max moves when a row's tile max exceeds it by this
 constexpr float BOUND_THR = 96.0f;     // exp2 arguments stay below this without looking at the scores
 
 }  // namespace

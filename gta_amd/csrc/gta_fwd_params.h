@@ -14,6 +14,8 @@ struct GtaFwdParams {
     int B, H, Tq, Tk, Nq, Nk, Pq, Pk;           // P* = tokens per view
     float invPq, invPk;
     int dh, nso2, n_qtiles;
+    int n_items;                                // work items of the attention kernel: B * H * n_qtiles
+    int nrec;                                   // q-side view records staged per item (views a 128-row tile can touch)
     uint32_t flags;
     unsigned long long* prof;                   // debug: per-workgroup phase timestamps (or null)
     uint32_t dbg;                               // ablation bits (GTA_DBG env; 0 in production)

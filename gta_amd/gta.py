@@ -344,8 +344,8 @@ def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: 
         flags |= native.FLAG_PRETRANSFORMED
     if not use_dma:
         flags |= native.FLAG_NO_DMA
-    if kv_mode == "prepass8":          # tuning knob: 8-wave (256-row) workgroups
-        flags |= native.FLAG_WG8
+    if kv_mode == "prepass_pg":        # tuning knob: persistent grid instead of one workgroup per query tile
+        flags |= native.FLAG_PERSIST
         kv_mode = "prepass"
     if kv_mode not in ("auto", "prepass", "fused"):
         raise ValueError(f"kv_mode {kv_mode!r}")

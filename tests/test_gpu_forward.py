@@ -62,7 +62,7 @@ SHAPES = {
 }
 
 
-@pytest.mark.parametrize("kv_mode", ["fused", "prepass", "prepass8"])
+@pytest.mark.parametrize("kv_mode", ["fused", "prepass", "prepass_pg"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", sorted(SHAPES))
 def test_baseline_shapes_vs_oracle(shape, dtype, kv_mode):
@@ -114,7 +114,7 @@ def test_global_frame_invariance_full_size():
     _check(b, a)
 
 
-@pytest.mark.parametrize("kv_mode", ["prepass", "prepass8"])
+@pytest.mark.parametrize("kv_mode", ["prepass", "prepass_pg"])
 @pytest.mark.parametrize("pattern", ["hot_logits", "late_spike", "early_spike"])
 def test_lazy_softmax_full_path(pattern, kv_mode):
     """The attention kernels skip the row max / rescale while |q'| max|k'| - m stays below 96 (log2 units).  These

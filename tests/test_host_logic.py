@@ -122,21 +122,21 @@ def test_no_cpu_fallback():
         gta_amd.Attention(32, 2, 16, attn_args={"method": {"name": "repast", "args": {}}})
 
 
-def test_pipelined_kernel_owns_its_accumulator_file():
-    """gta_fwd3_kernel addresses a[16:255] by literal number inside asm; hipcc must not park values there.
-    tools/audit_agpr.py compiles the kernel to assembly and checks: no scratch, no VGPR spills, every
-    compiler-generated AGPR access below a16 (cdna_hip_programming.md 5.7 item 4)."""
+def test_attention_kernel_is_spill_free():
+    """The persistent attention kernel must compile without scratch for the shipped layouts (a spilled load sits behind
+    a vmcnt(0) and serialises the prologue) and within 168 VGPRs at dh <= 64 (three workgroups per CU).
+    tools/audit_spills.py compiles gta_fwd2.hip to assembly and counts."""
     import importlib.util
     import os
     import shutil
     if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
         pytest.skip("hipcc not available")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("audit_agpr", os.path.join(root, "tools", "audit_agpr.py"))
+    spec = importlib.util.spec_from_file_location("audit_spills", os.path.join(root, "tools", "audit_spills.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     report, problems = mod.audit()
-    assert report, "no gta_fwd3_kernel instantiation found"
+    assert report, "no gta_fwd2_kernel instantiation found"
     assert not problems, problems
 
 

@@ -69,12 +69,12 @@ def report(name, B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, dtype=torch.bfloat16):
     fn_fill, _ = raw_call(q, k, v, packed, f_dims, L, VT, ws)
     fn_fill()
     fn_flash, _ = raw_call(q, k, v, packed, f_dims, L, VT | native.FLAG_KV_READY, ws)
-    fn_flash8, _ = raw_call(q, k, v, packed, f_dims, L, VT | native.FLAG_KV_READY | native.FLAG_WG8, ws)
+    fn_flash8, _ = raw_call(q, k, v, packed, f_dims, L, VT | native.FLAG_KV_READY | native.FLAG_PERSIST, ws)
     t_flash8 = time_call(fn_flash8)
     fn_fused, _ = raw_call(q, k, v, packed, f_dims, L, VT | native.FLAG_FUSED_KV, None)
     t_both, t_flash, t_fused = time_call(fn_both), time_call(fn_flash), time_call(fn_fused)
     print(f"{name:10s} B={B:3d} Tq={Tq:5d} Tk={Tk:5d} dh={dh:3d} | two-stage {t_both*1e3:7.1f} us  flash-only {t_flash*1e3:7.1f} us "
-          f"({flops/t_flash/1e9:6.1f} TF; 8-wave {t_flash8*1e3:7.1f} us)  prep ~{(t_both-t_flash)*1e3:6.1f} us | fused {t_fused*1e3:7.1f} us ({flops/t_fused/1e9:6.1f} TF)",
+          f"({flops/t_flash/1e9:6.1f} TF; persistent grid {t_flash8*1e3:7.1f} us)  prep ~{(t_both-t_flash)*1e3:6.1f} us | fused {t_fused*1e3:7.1f} us ({flops/t_fused/1e9:6.1f} TF)",
           flush=True)
 
 
@@ -88,49 +88,27 @@ if __name__ == "__main__":
     if which in ("all", "tiles"):
         for Pk in (64, 128, 256, 512):       # same Tq, varying number of key tiles
             report(f"MS Pk={Pk}", B, 8, 5, 256, 5, Pk, MS, 6, 2)
-    if which == "ablate":
-        q, k, v, packed, L = setup(B, 8, 5, 256, 5, 256, MS, 6, 2, torch.bfloat16)
+    if which == "ab":
+        # fair A/B of two flag sets of the attention kernel alone: alternate them, report the median of 7 rounds each
+        shapes = {"MS-enc": (8, 5, 256, 5, 256, MS, 6, 2), "MS-dec": (8, 5, 512, 5, 256, MS, 6, 2), "CL-enc": (6, 2, 300, 2, 300, CL, 8, 0),
+                  "CL-dec": (6, 3, 853, 2, 300, CL, 8, 0), "DT": (16, 1, 1024, 1, 1024, {"so2": 64}, 16, 0)}
         VT = native.FLAG_V_TRANSFORM
-        out = torch.empty(B, 1280, 8, 96, device="cuda", dtype=torch.bfloat16).permute(0, 2, 1, 3)
-        desc = native.make_desc(q, k, v, out, MS, L, 5, 5, 96 ** -0.5, VT)
-        ws = torch.empty(native.attn_fwd_workspace_bytes(desc), device="cuda", dtype=torch.uint8)
-        raw_call(q, k, v, packed, MS, L, VT, ws)[0]()
-        for nw8 in (0, 1):
-            fn, _ = raw_call(q, k, v, packed, MS, L, VT | native.FLAG_KV_READY | (native.FLAG_WG8 if nw8 else 0), ws)
-            for dbg, label in ((0, "baseline"), (8192, "stagger ~1.7k cycles"), (2048, "stagger long"), (4096, "setprio half"),
-                               (8192 + 4096, "stagger+setprio"), (1, "no loop DMA"), (2, "no barrier"), (3, "no DMA, no barrier"),
-                               (4, "no softmax math"), (8, "no PV"), (16, "no QK"), (12, "no softmax, no PV"),
-                               (28, "no QK/softmax/PV (loop skeleton)"), (31, "empty loop"),
-                               (31 + 32, "empty loop, no Q loads"), (31 + 64, "empty loop, no O stores"),
-                               (31 + 128, "empty loop, no rep staging"), (31 + 256, "empty loop, no epilogue"),
-                               (31 + 256 + 32 + 128, "empty loop, no epilogue/Q loads/reps"), (512, "bare launch")):
-                os.environ["GTA_DBG"] = str(dbg)
-                t = time_call(fn)
-                print(f"  {'8-wave' if nw8 else '4-wave'} dbg={dbg:2d} {label:36s} {t*1e3:7.1f} us", flush=True)
-            os.environ["GTA_DBG"] = "0"
-    if which == "pipe":          # region cycle sums of the pipelined kernel (needs a -DGTA_ABLATE build)
-        import ctypes
-        q, k, v, packed, L = setup(B, 8, 5, 256, 5, 256, MS, 6, 2, torch.bfloat16)
-        VT = native.FLAG_V_TRANSFORM
-        out = torch.empty(B, 1280, 8, 96, device="cuda", dtype=torch.bfloat16).permute(0, 2, 1, 3)
-        desc = native.make_desc(q, k, v, out, MS, L, 5, 5, 96 ** -0.5, VT)
-        ws = torch.empty(native.attn_fwd_workspace_bytes(desc), device="cuda", dtype=torch.uint8)
-        raw_call(q, k, v, packed, MS, L, VT, ws)[0]()
-        fn, _ = raw_call(q, k, v, packed, MS, L, VT | native.FLAG_KV_READY | native.FLAG_WG8, ws)
-        nwg = B * 8 * 5
-        for _ in range(3):
-            fn()
-        print(f"pipelined kernel: {time_call(fn)*1e3:.1f} us")
-        prof = torch.zeros(nwg, 16, dtype=torch.int64, device="cuda")
-        native.lib().gta_debug_set_profile_buffer(ctypes.c_void_p(prof.data_ptr()))
-        torch.cuda.synchronize(); fn(); torch.cuda.synchronize()
-        native.lib().gta_debug_set_profile_buffer(None)
-        P = prof.cpu().double()
-        print(f"  per WG cycles: prologue {(P[:,1]-P[:,0]).mean():8.0f}  tile0+loop {(P[:,2]-P[:,1]).mean():8.0f}  epilogue {(P[:,3]-P[:,2]).mean():8.0f}  total {(P[:,3]-P[:,0]).mean():8.0f}")
-        names = ["wait+barrier", "dma issue", "R3 (QK || exp,pack,V reads)", "R1 (PV || reads, max)", "decide", "R2 (PV || exp)", "rescale"]
-        for i2, nm in enumerate(names):
-            print(f"   {nm:30s} {P[:,8+i2].mean():9.0f} cycles / WG   {P[:,8+i2].mean()/20:7.0f} per tile")
-        print(f"   slow-path decisions per WG (of 19): mean {P[:,15].mean():.2f} max {P[:,15].max():.0f}")
+        for name, (H_, Nq_, Pq_, Nk_, Pk_, FD, so2_, so3_) in shapes.items():
+            q, k, v, packed, L = setup(B, H_, Nq_, Pq_, Nk_, Pk_, FD, so2_, so3_, torch.bfloat16)
+            dh_ = sum(FD.values())
+            out = torch.empty(B, Nq_ * Pq_, H_, dh_, device="cuda", dtype=torch.bfloat16).permute(0, 2, 1, 3)
+            desc = native.make_desc(q, k, v, out, FD, L, Nq_, Nk_, dh_ ** -0.5, VT)
+            ws = torch.empty(native.attn_fwd_workspace_bytes(desc), device="cuda", dtype=torch.uint8)
+            raw_call(q, k, v, packed, FD, L, VT, ws)[0]()
+            fns = {"default": raw_call(q, k, v, packed, FD, L, VT | native.FLAG_KV_READY, ws)[0],
+                   "persistent": raw_call(q, k, v, packed, FD, L, VT | native.FLAG_KV_READY | native.FLAG_PERSIST, ws)[0]}
+            res = {n: [] for n in fns}
+            for _ in range(7):
+                for n, fn in fns.items():
+                    res[n].append(time_call(fn, n=10, warm=2))
+            flops = 4.0 * B * H_ * Nq_ * Pq_ * Nk_ * Pk_ * dh_
+            msg = "  ".join(f"{n}: median {sorted(r)[3]*1e3:7.1f} us min {min(r)*1e3:7.1f} ({flops/sorted(r)[3]/1e9:6.1f} TF)" for n, r in res.items())
+            print(f"{name:8s} {msg}", flush=True)
     if which == "ctx":
         # the attention kernel in the bench's context: right behind the K/V pre-pass of the same step (instrumented build).
         # Prints its span and shader clock there and in a back-to-back loop of itself.
@@ -167,68 +145,64 @@ if __name__ == "__main__":
             measure("attention kernel after the K/V pre-pass", fn_both, fn_prep)
             measure("after the pre-pass + 100 us idle", fn_both, lambda: (fn_prep(), torch.cuda._sleep(200000)))
     if which in ("timeline", "timeline_dt"):
+        # per work item s_memtime stamps of the attention kernel (instrumented -DGTA_ABLATE build): persistent grid vs one
+        # workgroup per query tile, in one process.  Kernel cycles = span x clock: use that, not the span, to compare builds.
         import ctypes
-        if which == "timeline_dt":       # the dh = 64 pure-so2 shape (three workgroups per CU with the plain loop)
+        if which == "timeline_dt":       # the dh = 64 pure-so2 shape (three workgroups per CU)
             H_, Nv, Pv, FD, so2_, so3_ = 16, 1, 1024, {"so2": 64}, 16, 0
         else:
             H_, Nv, Pv, FD, so2_, so3_ = 8, 5, 256, MS, 6, 2
-        MS = FD
-        q, k, v, packed, L = setup(B, H_, Nv, Pv, Nv, Pv, MS, so2_, so3_, torch.bfloat16)
+        q, k, v, packed, L = setup(B, H_, Nv, Pv, Nv, Pv, FD, so2_, so3_, torch.bfloat16)
         VT = native.FLAG_V_TRANSFORM
-        dh_ = sum(MS.values())
+        dh_ = sum(FD.values())
         out = torch.empty(B, Nv * Pv, H_, dh_, device="cuda", dtype=torch.bfloat16).permute(0, 2, 1, 3)
-        desc = native.make_desc(q, k, v, out, MS, L, Nv, Nv, dh_ ** -0.5, VT)
+        desc = native.make_desc(q, k, v, out, FD, L, Nv, Nv, dh_ ** -0.5, VT)
         ws = torch.empty(native.attn_fwd_workspace_bytes(desc), device="cuda", dtype=torch.uint8)
-        raw_call(q, k, v, packed, MS, L, VT, ws)[0]()
-        fn, _ = raw_call(q, k, v, packed, MS, L, VT | native.FLAG_KV_READY, ws)
-        for nw8 in (0,):
-          nwg = B * H_ * ((Nv * Pv + 127) // 128)
-          fn, _ = raw_call(q, k, v, packed, MS, L, VT | native.FLAG_KV_READY | (native.FLAG_WG8 if nw8 else 0), ws)
-          for dbg in (0,):
-            os.environ["GTA_DBG"] = str(dbg)
+        raw_call(q, k, v, packed, FD, L, VT, ws)[0]()
+        nwg = B * H_ * ((Nv * Pv + 127) // 128)
+        for rnd in range(2):
+          for label, extra in (("one workgroup per tile", 0), ("persistent grid", native.FLAG_PERSIST)):
+            fn, _ = raw_call(q, k, v, packed, FD, L, VT | native.FLAG_KV_READY | extra, ws)
             for _ in range(3):
                 fn()
-            prof = torch.zeros(nwg * 3, 8, dtype=torch.int64, device="cuda")
+            t_us = time_call(fn) * 1e3
+            prof = torch.zeros(nwg, 8, dtype=torch.int64, device="cuda")
             native.lib().gta_debug_set_profile_buffer(ctypes.c_void_p(prof.data_ptr()))
             torch.cuda.synchronize()
             fn()
             torch.cuda.synchronize()
             native.lib().gta_debug_set_profile_buffer(None)
-            Pall = prof.cpu().double()
-            P = Pall[:nwg]
-            seg = Pall[nwg:].reshape(nwg, 2, 8)
-            print(f"== {'8-wave' if nw8 else '4-wave'} attention kernel")
-            if seg.abs().sum() > 0:
-                for i, nm in enumerate(["QK^T MFMAs", "softmax + V reads", "PV MFMAs", "barrier", "waits (vmcnt/lgkm)", "K/Q read issue | DMA issue"]):
-                    print(f"   {nm:26s} {seg[:,0,i].mean():9.0f} | {seg[:,1,i].mean():9.0f}   per tile {seg[:,0,i].mean()/20:7.0f} | {seg[:,1,i].mean()/20:7.0f}")
-            t0 = P[:, 0].min()
-            names = ["start->reps+Qloads landed", "Q rho+stage+frags", "main loop", "epilogue"]
-            if not nw8:
-                # s_memtime counts shader clocks, s_memrealtime the 100 MHz reference: their ratio is the clock the
-                # kernel actually ran at
-                real = (P[:, 6] - P[:, 5])
-                ok = real > 0
-                ghz = ((P[:, 4] - P[:, 0])[ok] / real[ok]).mean() * 0.1
-                span_us = (P[:, 6].max() - P[:, 5].min()) / 100.0
-                print(f"dbg={dbg}: kernel span {span_us:.1f} us by s_memrealtime; shader clock during the kernel {ghz:.3f} GHz; "
-                      f"KERNEL CYCLES {span_us * ghz:.1f}k (span x clock: use this, not the span, to compare builds)")
-            d = P[:, 7] - P[:, 0]
-            print(f"   {'(start -> Q/cs loads issued)':28s} mean {d.mean():9.0f} ticks  min {d.min():9.0f} max {d.max():9.0f}")
-            if not nw8:
-                X = Pall[nwg:2 * nwg]
-                for nm, a_, b_ in (("start -> before Q loads", P[:, 0], X[:, 0]), ("Q/cs loads issue", X[:, 0], X[:, 1]),
-                                   ("record load issue", X[:, 1], X[:, 2]), ("tile DMA issue", X[:, 2], P[:, 7]),
-                                   ("wait + record stores", P[:, 7], X[:, 3]), ("barrier", X[:, 3], P[:, 1])):
-                    d = b_ - a_
-                    print(f"     {nm:26s} mean {d.mean():9.0f}  min {d.min():9.0f} max {d.max():9.0f}")
-            for i, nm in enumerate(names):
-                d = P[:, i + 1] - P[:, i]
-                print(f"   {nm:28s} mean {d.mean():9.0f} ticks  min {d.min():9.0f} max {d.max():9.0f}")
-            st = (P[:, 0] - t0)
-            order = torch.argsort(st)
-            pass
-            pass
-        os.environ["GTA_DBG"] = "0"
+            P = prof.cpu().double()
+            if P.abs().sum() == 0:
+                print(f"== {label}: {t_us:.1f} us (no stamps: not an instrumented build)")
+                continue
+            real = P[:, 6] - P[:, 5]
+            ok = real > 0
+            ghz = ((P[:, 4] - P[:, 0])[ok] / real[ok]).mean() * 0.1
+            span_us = (P[:, 6].max() - P[:, 5].min()) / 100.0
+            print(f"== {label} (round {rnd}): {t_us:.1f} us by events; span {span_us:.1f} us by s_memrealtime; shader clock {ghz:.3f} GHz; "
+                  f"KERNEL CYCLES {span_us * ghz:.1f}k")
+            for nm, a_, b_ in (("start -> records staged, Q loads requested, barrier", 0, 1), ("rho_q", 1, 2), ("tile loop", 2, 3),
+                               ("epilogue", 3, 4), ("  (loop end -> epilogue loads + touches issued)", 3, 7), ("whole item", 0, 4)):
+                d = P[:, b_] - P[:, a_]
+                print(f"   {nm:52s} mean {d.mean():9.0f}  min {d.min():9.0f}  max {d.max():9.0f}")
+            # by round: items ranked by start time (100 MHz stamps), 512 per round
+            t0 = P[:, 5].min()
+            order = torch.argsort(P[:, 5])
+            nslot = 512
+            for r0 in range(0, nwg, nslot):
+                idx = order[r0:r0 + nslot]
+                Q = P[idx]
+                print(f"   round {r0 // nslot}: start {((Q[:, 5] - t0) / 100).mean():7.1f} us (spread {((Q[:, 5].max() - Q[:, 5].min()) / 100):6.1f})  "
+                      f"end {((Q[:, 6] - t0) / 100).mean():7.1f} us (spread {((Q[:, 6].max() - Q[:, 6].min()) / 100):6.1f})  item cycles: "
+                      f"prologue {(Q[:, 2] - Q[:, 0]).mean():7.0f}  loop {(Q[:, 3] - Q[:, 2]).mean():7.0f}  epilogue {(Q[:, 4] - Q[:, 3]).mean():7.0f}  "
+                      f"total {(Q[:, 4] - Q[:, 0]).mean():7.0f}")
+            # occupancy over time: how many items are in flight at 20 sample points
+            ends = (P[:, 6] - t0) / 100
+            starts = (P[:, 5] - t0) / 100
+            T = ends.max()
+            occ = [int(((starts <= x) & (ends > x)).sum()) for x in [T * i / 20 for i in range(1, 20)]]
+            print(f"   items in flight at 5%..95% of the span: {occ}")
     if which == "dt":            # dh = 64 shapes: these run three workgroups per CU (151 VGPRs, 51 KB LDS)
         report("DT", B, 16, 1, 1024, 1, 1024, {"so2": 64}, 16, 0)
         report("CL-dec", B, 6, 3, 853, 2, 300, CL, 8, 0)
