@@ -1,21 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- GTA-attention throughput on MI355X (contract: one JSON line on rank 0).
 
-A "step" is one pass of the hot path over one synthetic batch: build the per-view / per-token
-reps from poses and patch coordinates on device, then ONE fused GTA attention forward
-(`gta_attn_fwd`) on already-projected Q/K/V resident in HBM.  Default workload = BASELINE.json's
-metric configuration: the MSN-Hard `gta_so3` encoder attention (V=5 views of 128x128 images ->
-16x16 patches/view -> 1280 tokens, d=768 = 8 heads x 96 channels, f_dims se3 48 / so3 24 /
-so2 24), bf16, 32 scenes per GPU.
+A "step" is one pass of the hot path over one synthetic batch, inputs resident in HBM: build the per-view /
+per-token reps from poses and patch coordinates on device (`gta_build_reps`), then ONE GTA attention forward
+(`gta_attn_fwd`: K/V rep pre-pass + attention kernel) on already-projected Q/K/V.  Default workload = BASELINE.json's
+metric configuration: the MSN-Hard `gta_so3` encoder attention (V=5 views of 128x128 images -> 16x16 patches/view ->
+1280 tokens, d=768 = 8 heads x 96 channels, f_dims se3 48 / so3 24 / so2 24), bf16, 32 scenes per GPU.
 
     python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Multi-GPU: data-parallel replicas (one process per GPU, fixed per-GPU batch -> "weak"); the
-operator has no exchange step, so there is no data-path collective -- only the barrier and the
-MAX-over-ranks of the timed region go through RCCL.
+The step goes through the C ABI with pre-planned buffers (gta_amd.plan: what a serving loop does -- no allocation, no
+autograd bookkeeping per call).  The dominant kernel's duration is taken inside the timed region from HIP events
+attached to its own dispatch (hipExtLaunchKernelGGL through the library's profiling hook, on the launch stream).
+After the timed region the output of the full-size batch is checked against the CPU oracle on sampled scenes
+(`parity_max_abs`).  `oracle/` is imported for that check and for the `cpu_baseline` leg only.
+
+Multi-GPU: data-parallel replicas (one process per GPU, fixed per-GPU batch -> "weak"); the operator has no exchange
+step, so there is no data-path collective -- only the barrier and the MAX-over-ranks of the timed region go through RCCL.
 """
 import argparse
+import ctypes
+import glob
 import json
 import os
 import sys
@@ -39,23 +45,22 @@ WORKLOADS = {
 }
 
 
-def make_inputs(workload, B, dtype, device, seed):
-    from tests import _hip_cases as C
-    H, Nq, Pq, Nk, Pk, f_dims, so2, so3, _ = WORKLOADS[workload]
-    q, k, v, ex, ak, cross = C.synth_inputs(B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, dtype, seed=seed)
-    # Q/K/V as the module's packed projection leaves them: [B, T, H, dh] in memory, viewed [B, H, T, dh]
-    to_dev = lambda t: t.to(dtype).to(device).permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
-    exd = {kk: vv.to(device) for kk, vv in ex.items()}
-    return to_dev(q), to_dev(k), to_dev(v), exd, ak, cross, (q, k, v, ex)
+def oracle_forward(q, k, v, ex, ak, cross, trans_coeff):
+    """CPU oracle (oracle/gta_oracle.py: a restatement of the reference's PyTorch path, pinned to it by tests/golden)."""
+    from oracle import gta_oracle as O
+    reps = O.encoder_reps(ak, {kk: vv.float() for kk, vv in ex.items()})
+    if cross:
+        reps = O.decoder_reps(ak, {kk: vv.float() for kk, vv in ex.items()}, reps)
+    out, _ = O.gta_attention(q.float(), k.float(), v.float(), ak["f_dims"], reps, trans_coeff, True)
+    return out
 
 
 def cpu_baseline(workload, seed):
-    """The CPU oracle (a port of the reference's PyTorch path) on a bounded sample of the same
-    workload, all host cores.  Reported beside the GPU number; baseline only."""
-    from tests import _hip_cases as C
+    """The CPU oracle on a bounded sample of the same workload, host cores.  Reported beside the GPU number; baseline only."""
+    from gta_amd import synth
     H, Nq, Pq, Nk, Pk, f_dims, so2, so3, _ = WORKLOADS[workload]
     Bs = 2
-    q, k, v, ex, ak, cross = C.synth_inputs(Bs, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, torch.float32, seed=seed)
+    q, k, v, ex, ak, cross = synth.attention_inputs(Bs, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, seed=seed)
     ncpu = os.cpu_count() or 1
     best = None
     t_end = time.time() + 25.0
@@ -64,11 +69,11 @@ def cpu_baseline(workload, seed):
         if time.time() > t_end:
             break
         torch.set_num_threads(nthreads)
-        C.oracle_forward(q, k, v, ex, ak, cross, 0.01)          # warm-up
+        oracle_forward(q, k, v, ex, ak, cross, 0.01)          # warm-up
         times = []
         while len(times) < 5 and time.time() < t_end:
             t0 = time.perf_counter()
-            C.oracle_forward(q, k, v, ex, ak, cross, 0.01)
+            oracle_forward(q, k, v, ex, ak, cross, 0.01)
             times.append(time.perf_counter() - t0)
         if times:
             times.sort()
@@ -76,11 +81,33 @@ def cpu_baseline(workload, seed):
             if best is None or med_n < best[0]:
                 best = (med_n, nthreads, len(times))
     med, cores, nruns = best
-    times = [0] * nruns
     return {"value": Bs * Nq * Pq / med / 1e6, "unit": "Mtokens/s", "cores": cores, "host_cpus": ncpu,
             "kind": "port",
             "sample": f"oracle/gta_oracle.py fp32 (rep build + attention), B={Bs} scenes of the same workload, "
-                      f"median of {len(times)} runs, {med * 1e3:.1f} ms each"}
+                      f"median of {nruns} runs, {med * 1e3:.1f} ms each"}
+
+
+def parity_check(out, masters, ak, cross, scenes):
+    """Output of the timed configuration (full batch) against the oracle on a few scenes, all heads."""
+    q, k, v, ex = masters
+    idx = torch.tensor(scenes)
+    ref = oracle_forward(q[idx], k[idx], v[idx], {kk: vv[idx] for kk, vv in ex.items()}, ak, cross, 0.01)
+    got = out[idx.to(out.device)].float().cpu()
+    diff = (got - ref).abs()
+    return {"scenes": list(scenes), "parity_max_abs": float(diff.max()), "ref_max_abs": float(ref.abs().max()),
+            "rel_rms": float(((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()))}
+
+
+def latest_traffic(workload, B, dtype):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC measurement of this workload."""
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")), reverse=True):
+        try:
+            t = json.load(open(f))
+            if (t["workload"], t["batch"], t["dtype"]) == (workload, B, dtype):
+                return t["bytes_per_launch"], os.path.relpath(f, ROOT) + " (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)"
+        except (OSError, KeyError, ValueError):
+            pass
+    return None, None
 
 
 def main():
@@ -92,6 +119,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the full-batch output")
     ap.add_argument("--model-train-steps", type=int, default=0,
                     help="also time K optimizer steps of the whole MSN gta_so3 TransformingSRT (gta_amd.srt) on synthetic "
                          "multi-view batches, DDP over the ranks; reported as `srt_train`, not part of `value`")
@@ -103,7 +131,7 @@ def main():
     args = ap.parse_args()
 
     import gta_amd
-    from gta_amd import native
+    from gta_amd import native, plan, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -118,31 +146,46 @@ def main():
         dist = None
         torch.cuda.set_device(0)
     device = torch.device("cuda", local_rank if world > 1 else 0)
-    native.lib()   # fail loudly if the HIP library is missing
+    L = native.lib()   # fail loudly if the HIP library is missing
 
     H, Nq, Pq, Nk, Pk, f_dims, so2, so3, Bdef = WORKLOADS[args.workload]
     B = args.batch or Bdef
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    q, k, v, exd, ak, cross, _ = make_inputs(args.workload, B, dtype, device, seed=1234 + rank)
+    qm, km, vm, ex, ak, cross = synth.attention_inputs(B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, seed=1234 + rank)
+    # Q/K/V as the module's packed projection leaves them: [B, T, H, dh] in memory, viewed [B, H, T, dh]
+    q, k, v = (synth.as_projection(t, dtype, device) for t in (qm, km, vm))
+    exd = {kk: vv.to(device).contiguous() for kk, vv in ex.items()}
     tc = torch.tensor([0.01], device=device) if f_dims.get("se3", 0) > 0 else None
     Tq, Tk, dh = Nq * Pq, Nk * Pk, sum(f_dims.values())
+    need_view = f_dims.get("se3", 0) > 0 or f_dims.get("so3", 0) > 0
+    so3_deg = so3 if f_dims.get("so3", 0) > 0 else 0
+    fused = args.kv_mode == "fused"
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # ---- the planned step: rep build(s) + one gta_attn_fwd ----
+    reps_k = plan.RepPlan(B, Nk, Pk, so3_deg, so2, device=device) if (need_view and f_dims.get("so2", 0) > 0) else None
+    reps_q = plan.RepPlan(B, Nq, Pq, so3_deg, so2, device=device) if (reps_k is not None and cross) else None
+    fwd = plan.ForwardPlan(q, k, v, f_dims, so3_degree=so3_deg, Nq=Nq if need_view else 1, Nk=Nk if need_view else 1,
+                           flags=native.FLAG_FUSED_KV if fused else 0)
+    ev = [(L.gta_debug_event_create(), L.gta_debug_event_create()) for _ in range(args.steps)]
 
-    from gta_amd.gta import _GtaAttn
+    def build_reps():
+        if reps_k is not None:
+            vk, ck = reps_k(exd["input_transforms"], exd["input_coord"])
+            vq, cq = reps_q(exd["target_transforms"], exd["target_coord"]) if cross else (vk, ck)
+            return vq, vk, cq, ck
+        # layouts without a per-view part (or without so2): the general builders of gta_amd.reps
+        e2 = dict(exd)
+        gta_amd.pre_compute_reps_encoder(ak, e2)
+        if cross:
+            gta_amd.pre_compute_reps_decoder(ak, e2)
+        pk = gta_amd.pack_reps(e2, f_dims)
+        return pk.get("vrep_q"), pk.get("vrep_k"), pk.get("cs_q"), pk.get("cs_k")
 
     def step(i=None):
-        ex = dict(exd)                                   # reps are rebuilt every step (timed)
-        gta_amd.pre_compute_reps_encoder(ak, ex)
-        if cross:
-            gta_amd.pre_compute_reps_decoder(ak, ex)
-        packed = gta_amd.pack_reps(ex, f_dims)
-        # events bracket the dominant kernel (the attention kernel; the K/V pre-pass runs before them)
-        _GtaAttn.flash_events = ev[i] if i is not None else None
-        out = gta_amd.gta_attention(q, k, v, f_dims, packed, so3_degree=ex.get("gta_so3_degree", 0), trans_coeff=tc,
-                                    kv_mode=args.kv_mode)
-        _GtaAttn.flash_events = None
-        return out
+        vq, vk, cq, ck = build_reps()                      # reps are rebuilt every step (timed)
+        if i is not None and not fused:
+            L.gta_debug_time_next_attention_kernel(ctypes.c_void_p(ev[i][0]), ctypes.c_void_p(ev[i][1]))
+        return fwd(q, k, v, vq, vk, cq, ck, tc)
 
     for _ in range(args.warmup):
         step()
@@ -153,6 +196,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    t_host = time.perf_counter() - t0                      # (host side of the loop: how far ahead of the GPU it runs)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -163,22 +207,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps      # attention kernel only (same stream)
+    if fused:
+        kern_ms = None
+    else:
+        ks = [L.gta_debug_event_elapsed_ms(ctypes.c_void_p(a), ctypes.c_void_p(b)) for a, b in ev]
+        kern_ms = sum(ks) / len(ks)                         # attention kernel only (events of its own dispatch)
+    for a, b in ev:
+        L.gta_debug_event_destroy(ctypes.c_void_p(a)); L.gta_debug_event_destroy(ctypes.c_void_p(b))
+
+    parity = None
+    if rank == 0 and not args.no_parity:
+        scenes = sorted({0, B // 3, (2 * B) // 3, B - 1})
+        parity = parity_check(fwd.out, (qm, km, vm, ex), ak, cross, scenes)
 
     # forward + backward of the operator (gta_attn_bwd: q-side pre-pass, dQ, dK/dV), reported beside the headline
     fwd_bwd_ms = None
     if args.train_steps > 0:
         qg, kg, vg = (t.detach().clone().requires_grad_() for t in (q, k, v))
         tcg = tc.detach().clone().requires_grad_() if tc is not None else None
-        ex = dict(exd)
-        gta_amd.pre_compute_reps_encoder(ak, ex)
+        e2 = dict(exd)
+        gta_amd.pre_compute_reps_encoder(ak, e2)
         if cross:
-            gta_amd.pre_compute_reps_decoder(ak, ex)
-        packed = gta_amd.pack_reps(ex, f_dims)
+            gta_amd.pre_compute_reps_decoder(ak, e2)
+        packed = gta_amd.pack_reps(e2, f_dims)
         w = torch.randn_like(q)
 
         def train_step():
-            out = gta_amd.gta_attention(qg, kg, vg, f_dims, packed, so3_degree=ex.get("gta_so3_degree", 0), trans_coeff=tcg)
+            out = gta_amd.gta_attention(qg, kg, vg, f_dims, packed, so3_degree=e2.get("gta_so3_degree", 0), trans_coeff=tcg)
             out.backward(w)
             qg.grad = kg.grad = vg.grad = None
         for _ in range(3):
@@ -238,19 +293,8 @@ def main():
         del model, opt, batch
     flops = 4.0 * B * H * Tq * Tk * dh                               # QK^T + PV, 2 flop/MAC
     alg_bytes = (2 * Tq + 2 * Tk) * H * dh * q.element_size() * B    # read Q,K,V once, write O once
-    achieved = flops / (kern_ms * 1e-3) / 1e12
-
-    # HBM bytes per launch of the dominant kernel from the PMC counters (collected in separate rocprofv3 passes,
-    # tools/profile_r01.sh; the corrected per-launch figure is committed under profiles/): only quoted when
-    # the committed measurement is of this workload / batch / dtype
-    traffic, traffic_src = None, None
-    try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_traffic.json")) as f:
-            t = json.load(f)
-        if (t["workload"], t["batch"], t["dtype"]) == (args.workload, B, args.dtype) and args.kv_mode == "prepass":
-            traffic, traffic_src = t["bytes_per_launch"], "profiles/r01/pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)"
-    except (OSError, KeyError, ValueError):
-        pass
+    achieved = flops / (kern_ms * 1e-3) / 1e12 if kern_ms else None
+    traffic, traffic_src = latest_traffic(args.workload, B, args.dtype) if not fused else (None, None)
 
     if rank == 0:
         n = max(world, 1)
@@ -265,13 +309,17 @@ def main():
             "config": {"workload": f"{args.workload}: GTA attention forward (rep build + K/V rep pre-pass + attention kernel), "
                                    f"B={B}/GPU, H={H}, Tq={Tq}, Tk={Tk}, dh={dh}, f_dims={f_dims}, "
                                    f"views q/k={Nq}/{Nk}", "global_batch": n * B, "parallelism": f"dp{n}"},
-            "roofline": {"bound": "mfma", "kernel": "gta_fwd2_kernel" if args.kv_mode == "prepass" else "gta_fwd_kernel", "achieved": achieved,
-                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
-                         "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                         "kernel_ms": kern_ms, "algorithmic_flops": flops,
-                         "algorithmic_bytes": alg_bytes,
-                         "hbm_frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+            "host_ms_per_step": t_host / args.steps * 1e3,
         }
+        if achieved is not None:
+            line["roofline"] = {"bound": "mfma", "kernel": "gta_fwd2_kernel", "achieved": achieved,
+                                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
+                                "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                                "kernel_ms": kern_ms, "algorithmic_flops": flops, "algorithmic_bytes": alg_bytes,
+                                "hbm_frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                "step_frac": flops / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS}
+        if parity is not None:
+            line["parity"] = parity
         if fwd_bwd_ms is not None:
             line["fwd_bwd"] = {"ms_per_step": fwd_bwd_ms, "mtokens_s_per_gpu": B * Tq / (fwd_bwd_ms * 1e-3) / 1e6,
                                "tflops": 3.5 * flops / (fwd_bwd_ms * 1e-3) / 1e12,

@@ -17,10 +17,13 @@ def _strip_module(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     return {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
 
 
-def load_checkpoint(path: str, device=None, **modules) -> dict:
+def load_checkpoint(path: str, device=None, trusted: bool = False, **modules) -> dict:
     """``load_checkpoint(path, encoder=model.encoder, decoder=model.decoder, optimizer=opt)`` loads every
-    registered module found in the file (strict) and returns the remaining entries, like ``Checkpoint.load``."""
-    state = torch.load(path, map_location=device, weights_only=False)
+    registered module found in the file (strict) and returns the remaining entries, like ``Checkpoint.load``.
+
+    The file is read with ``weights_only=True`` (state dicts and scalars, which is all the reference's released
+    checkpoints hold); ``trusted=True`` allows arbitrary pickles for files you wrote yourself."""
+    state = torch.load(path, map_location=device, weights_only=not trusted)
     for name, mod in modules.items():
         if name not in state:
             raise KeyError(f"checkpoint {os.path.basename(path)} has no entry '{name}' (found: {sorted(state)})")

@@ -783,23 +783,12 @@ __global__ __launch_bounds__(1024) void gta_reduce_kernel(const float* __restric
     if (threadIdx.x == 0) *out = neg_div ? -sm[0] / *neg_div : sm[0];
 }
 
-template <typename K>
-int set_lds(K kern, int bytes) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess
-               ? GTA_OK : GTA_E_LAUNCH;
-}
-
 template <int DHP, int ESZ>
 int run_bwd(const GtaBwdParams& p, hipStream_t stream) {
     const int n_qt = (p.Tq + BN - 1) / BN;
-    static bool attr = false;
-    if (!attr) {
-        constexpr int lds_prep0 = BPrepSmem<DHP, ESZ>::TOTAL;
-        if (set_lds(&gta_bwd_prep_kernel<DHP, ESZ>, lds_prep0)) return GTA_E_LAUNCH;
-        if (set_lds(&gta_bwd_dq_kernel<DHP, ESZ>, DqSmem<DHP>::total(GTA_MAX_VIEWS))) return GTA_E_LAUNCH;
-        if (set_lds(&gta_bwd_dkv_kernel<DHP, ESZ>, DkvSmem<DHP>::total(GTA_MAX_VIEWS))) return GTA_E_LAUNCH;
-        attr = true;
-    }
+    if (int rc = gta_lds_optin<&gta_bwd_prep_kernel<DHP, ESZ>>(BPrepSmem<DHP, ESZ>::TOTAL)) return rc;
+    if (int rc = gta_lds_optin<&gta_bwd_dq_kernel<DHP, ESZ>>(DqSmem<DHP>::total(GTA_MAX_VIEWS))) return rc;
+    if (int rc = gta_lds_optin<&gta_bwd_dkv_kernel<DHP, ESZ>>(DkvSmem<DHP>::total(GTA_MAX_VIEWS))) return rc;
     constexpr int lds_prep = BPrepSmem<DHP, ESZ>::TOTAL;
     hipLaunchKernelGGL((gta_bwd_prep_kernel<DHP, ESZ>), dim3(n_qt, p.H, p.B), dim3(256), lds_prep, stream, p);
     const int n_dq = p.B * p.H * ((p.Tq + 127) / 128);

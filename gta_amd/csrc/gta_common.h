@@ -207,3 +207,19 @@ GTA_DEV int view_of(int t, int P, float invP) {
     if ((n + 1) * P <= t) ++n;
     return n;
 }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize (the opt-in above 64 KiB of dynamic LDS) is a per-DEVICE attribute of a
+// kernel: set it once per (kernel instantiation, device).  The flags are plain bools: two racing threads at worst
+// repeat the same idempotent call.
+template <auto Kernel>
+inline int gta_lds_optin(int bytes) {
+    constexpr int MAXDEV = 64;
+    static bool done[MAXDEV] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -5;                 // GTA_E_NODEVICE
+    if (dev >= 0 && dev < MAXDEV && done[dev]) return 0;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+        return -4;                                                   // GTA_E_LAUNCH
+    if (dev >= 0 && dev < MAXDEV) done[dev] = true;
+    return 0;
+}

@@ -482,13 +482,7 @@ __global__ __launch_bounds__(NTHREADS, (DHP <= 96 ? 2 : 1)) void gta_fwd_kernel(
 template <int DHP, int ESZ, bool DMA>
 int launch(const GtaFwdParams& p, int n_wg, hipStream_t stream) {
     using S = Smem<DHP, ESZ>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gta_fwd_kernel<DHP, ESZ, DMA>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, S::TOTAL) != hipSuccess)
-            return GTA_E_LAUNCH;
-        attr_set = true;
-    }
+    if (int rc = gta_lds_optin<&gta_fwd_kernel<DHP, ESZ, DMA>>(S::TOTAL)) return rc;
     hipLaunchKernelGGL((gta_fwd_kernel<DHP, ESZ, DMA>), dim3(n_wg), dim3(NTHREADS), S::TOTAL, stream, p);
     return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH;
 }

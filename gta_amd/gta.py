@@ -61,44 +61,60 @@ def _pack_so2(rep: torch.Tensor) -> torch.Tensor:
     return torch.stack([rep[..., 0, 0], rep[..., 1, 0]], -1).detach().to(torch.float32).contiguous()
 
 
+def _src_key(*tensors):
+    """Identity of the tensors a packed table was built from: storage address, shape and in-place version counter
+    (``id()`` can alias after garbage collection; a tensor replaced by the decoder changes at least the address)."""
+    out = []
+    for t in tensors:
+        if torch.is_tensor(t):
+            out.append((t.data_ptr(), tuple(t.shape), t._version))
+        elif isinstance(t, (list, tuple)):
+            out.append(tuple((u.data_ptr(), tuple(u.shape), u._version) for u in t))
+        else:
+            out.append(None)
+    return tuple(out)
+
+
 def pack_reps(reps: dict, f_dims: dict) -> dict:
     """Return (and cache in ``reps``) the packed tables for a reference-style ``reps`` dict.
 
     Accepts either the packed keys written by ``gta_amd.reps.pre_compute_reps_*``
-    (``gta_vrep_q/k``, ``gta_cs_q/k``) or the reference's own tensors (``se3rep_q/k``,
-    ``inv_se3rep_q``, ``so3rep_q/k`` lists, ``so2rep_q/k``; encoder.py:197,235-236,259).
+    (``gta_vrep_q/k``, ``gta_cs_q/k``, ``gta_coord_q/k``) or the reference's own tensors (``se3rep_q/k``,
+    ``inv_se3rep_q``, ``so3rep_q/k`` lists, ``so2rep_q/k``, ``t2rep_q/k``; encoder.py:197,208-215,235-236,259).
+    A table packed from reference tensors is tied to them (``*_src``): when the decoder replaces the q side of the
+    shared dict (decoder.py:283-311), the table is rebuilt -- for all three kinds.
     """
     need_view = f_dims.get("se3", 0) > 0 or f_dims.get("so3", 0) > 0
     need_so2 = f_dims.get("so2", 0) > 0
     out = {}
+
+    def cached(key, sources, build):
+        # tables written by gta_amd.reps carry no *_src: they are authoritative
+        if key in reps and (key + "_src") not in reps:
+            return reps[key]
+        src = _src_key(*sources)
+        if key not in reps or reps.get(key + "_src") != src:
+            reps[key] = build()
+            reps[key + "_src"] = src
+        return reps[key]
+
     if need_view:
         for side in ("q", "k"):
-            key = f"gta_vrep_{side}"
-            # the packed table is tied to the tensors it was built from (decoder replaces *_q)
-            src = (id(reps.get(f"se3rep_{side}")), id(reps.get("inv_se3rep_q")) if side == "q" else 0,
-                   id(reps.get(f"so3rep_{side}")))
-            if key not in reps or reps.get(key + "_src", src) != src:
-                Ds = list(reps.get(f"so3rep_{side}", [])) if f_dims.get("so3", 0) > 0 else []
-                reps[key] = _pack_view(reps.get("inv_se3rep_q") if side == "q" else None,
-                                       reps.get(f"se3rep_{side}"), Ds)
-                reps[key + "_src"] = src
-            out[f"vrep_{side}"] = reps[key]
+            inv = reps.get("inv_se3rep_q") if side == "q" else None
+            rep, so3 = reps.get(f"se3rep_{side}"), reps.get(f"so3rep_{side}")
+            Ds = list(so3 or []) if f_dims.get("so3", 0) > 0 else []
+            out[f"vrep_{side}"] = cached(f"gta_vrep_{side}", (rep, inv, so3), lambda: _pack_view(inv, rep, Ds))
     if f_dims.get("t2", 0) > 0:
         # make_T2mats (gta.py:72-89): T = [[1,0,0],[0,1,0],[cx,cy,1]] -> the kernel wants (cx, cy) per token
         for side in ("q", "k"):
-            key = f"gta_coord_{side}"
-            if key not in reps:
-                T = reps[f"t2rep_{side}"]
-                reps[key] = torch.stack([T[..., 2, 0], T[..., 2, 1]], -1).detach().float().contiguous()
-            out[f"coord_{side}"] = reps[key]
+            T = reps.get(f"t2rep_{side}")
+            out[f"coord_{side}"] = cached(
+                f"gta_coord_{side}", (T,),
+                lambda: torch.stack([T[..., 2, 0], T[..., 2, 1]], -1).detach().float().contiguous())
     if need_so2:
         for side in ("q", "k"):
-            key = f"gta_cs_{side}"
-            src = id(reps.get(f"so2rep_{side}"))
-            if key not in reps or reps.get(key + "_src", src) != src:
-                reps[key] = _pack_so2(reps[f"so2rep_{side}"])
-                reps[key + "_src"] = src
-            out[f"cs_{side}"] = reps[key]
+            R = reps.get(f"so2rep_{side}")
+            out[f"cs_{side}"] = cached(f"gta_cs_{side}", (R,), lambda: _pack_so2(R))
     return out
 
 
@@ -126,6 +142,24 @@ def _as_kernel_layout(t: torch.Tensor) -> torch.Tensor:
     return t if ok else t.contiguous()
 
 
+def _check_tables(q, k, f_dims, Nq, Nk, vrep_q, vrep_k, cs_q, cs_k, coord_q, coord_k, tc, ta, k_side=True):
+    """Shape / dtype / device validation of everything that reaches the kernels as a raw pointer."""
+    B, _, Tq, _ = q.shape
+    Tk = k.shape[2]
+    dev = q.device
+    if f_dims.get("se3", 0) > 0 or f_dims.get("so3", 0) > 0:
+        native.check_table("vrep_q", vrep_q, (B, Nq, native.VREP_STRIDE), dev)
+        native.check_table("vrep_k", vrep_k, (B, Nk, native.VREP_STRIDE), dev, allow_none=not k_side)
+    if f_dims.get("so2", 0) > 0:
+        native.check_table("cs_q", cs_q, (B, Tq, f_dims["so2"] // 2, 2), dev)
+        native.check_table("cs_k", cs_k, (B, Tk, f_dims["so2"] // 2, 2), dev, allow_none=not k_side)
+    if f_dims.get("t2", 0) > 0:
+        native.check_table("coord_q", coord_q, (B, Tq, 2), dev)
+        native.check_table("coord_k", coord_k, (B, Tk, 2), dev, allow_none=not k_side)
+    native.check_scalar("trans_coeff", tc, dev)
+    native.check_scalar("tau", ta, dev)
+
+
 class _GtaAttn(torch.autograd.Function):
     flash_events = None     # (start, end) torch.cuda.Event pair set by bench.py, else None
 
@@ -145,6 +179,8 @@ class _GtaAttn(torch.autograd.Function):
         tc = trans_coeff.detach().to(torch.float32).reshape(-1) if trans_coeff is not None else None
         ta = tau.detach().to(torch.float32).reshape(-1) if tau is not None else None
         desc = native.make_desc(q, k, v, out, f_dims, so3_degree, Nq, Nk, scale, flags)
+        _check_tables(q, k, f_dims, Nq, Nk, vrep_q, vrep_k, cs_q, cs_k, None, None, tc, ta,
+                      k_side=not (flags & native.FLAG_PRETRANSFORMED))
         ws = None
         if not (flags & (native.FLAG_FUSED_KV | native.FLAG_PRETRANSFORMED)):
             if kv_cache is not None and kv_cache.get("images") is not None:
@@ -221,6 +257,8 @@ class _GenericAttn(torch.autograd.Function):
         pitch = (Tk + 63) // 64 * 64
         kbias = torch.zeros(B, H, pitch, device=q.device, dtype=torch.float32) if euclid else None
         vq, vk = packed.get("vrep_q"), packed.get("vrep_k")
+        _check_tables(q, k, f_dims, Nq, Nk, vq, vk, packed.get("cs_q"), packed.get("cs_k"), packed.get("coord_q"),
+                      packed.get("coord_k"), tc, ta)
         native.rep_apply(desc, 0, q, vq, packed.get("cs_q"), packed.get("coord_q"), tc, qp[..., :dh])
         native.rep_apply(desc, 1, k, vk, packed.get("cs_k"), packed.get("coord_k"), tc, kp[..., :dh], kbias, scale)
         if v_transform:
@@ -371,6 +409,25 @@ def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: 
                           packed.get("cs_q"), packed.get("cs_k"))
 
 
+def _closure_has_tau(attn_fn) -> bool:
+    """True when ``attn_fn`` is one of the reference's ``AttnFn`` / ``EuclidAttnFn`` instances (layers.py:202-224) --
+    modules whose ``forward`` closes over the constructor's local ``tau`` -- and that ``tau`` is a tensor, i.e. the
+    parameter of ``TemperatureAdjsutableSoftmax`` (layers.py:135-143,195-197) rather than the constant 1.0."""
+    for fn in (getattr(attn_fn, "forward", None), attn_fn):
+        fn = getattr(fn, "__func__", fn)
+        code, cells = getattr(fn, "__code__", None), getattr(fn, "__closure__", None)
+        if code is None or not cells:
+            continue
+        for name, cell in zip(code.co_freevars, cells):
+            try:
+                val = cell.cell_contents
+            except ValueError:
+                continue
+            if name == "tau" and torch.is_tensor(val):
+                return True
+    return False
+
+
 def multihead_geometric_transform_attention(q, k, v, attn_fn=None, f_dims=None, reps=None,
                                             trans_coeff=1.0, v_transform=True, euclid=False, **kwargs):
     """Drop-in for gta.py:92-279.  Returns ``(out_t, None)``.
@@ -378,6 +435,15 @@ def multihead_geometric_transform_attention(q, k, v, attn_fn=None, f_dims=None, 
     Args mirror the reference: q [B,H,Nq*Tq,C]; k, v [B,H,Nk*Tk,C]; ``f_dims`` the slab sizes;
     ``reps`` the dict filled by ``pre_compute_reps`` (reference-style tensors or this package's
     packed tables); ``trans_coeff`` a scalar or the layer's 1-element parameter.
+
+    Softmax temperature (``softmax: adjustable``, layers.py:135-143,195-200): the reference's ``AttnFn`` /
+    ``EuclidAttnFn`` capture tau in a closure and expose only ``.scale``, so a reference-style ``attn_fn`` cannot
+    hand it over -- pass ``tau=self.attend.tau`` (level 2).  An ``attn_fn`` that is one of the
+    reference's closures over a module with a ``tau`` parameter and no ``tau=`` keyword raises instead of silently
+    running with tau = 1.
+
+    Arithmetic: products run on the bf16 MFMA with fp32 accumulation for fp32 inputs too (rho and the softmax are
+    fp32); see DESIGN.md section 5 for the measured gap to the fp32 reference.
     """
     if f_dims is None or reps is None:
         raise TypeError("f_dims and reps are required")
@@ -385,6 +451,9 @@ def multihead_geometric_transform_attention(q, k, v, attn_fn=None, f_dims=None, 
     packed = pack_reps(reps, f_dims)
     scale = getattr(attn_fn, "scale", None)
     tau = kwargs.get("tau", getattr(attn_fn, "tau", None))
+    if "tau" not in kwargs and not hasattr(attn_fn, "tau") and _closure_has_tau(attn_fn):
+        raise native.GtaError("attn_fn closes over a softmax temperature (softmax: adjustable, layers.py:195-200) that "
+                              "this drop-in cannot see: pass tau=self.attend.tau")
     if f_dims.get("se3", 0) <= 0:
         trans_coeff = None
     out = gta_attention(q, k, v, f_dims, packed, so3_degree=_so3_degree(f_dims, packed, reps),

@@ -36,6 +36,8 @@ ABI_SYMBOLS = (
     "gta_attn_fwd_launch_info", "gta_attn_fwd_workspace_bytes", "gta_attn_bwd", "gta_attn_bwd_workspace_bytes",
     "gta_rep_apply", "gta_attn_fwd_plain",
     "gta_strerror", "gta_abi_version", "gta_sizeof_attn_desc",
+    "gta_debug_time_next_attention_kernel", "gta_debug_event_create", "gta_debug_event_destroy", "gta_debug_event_elapsed_ms",
+    "gta_debug_set_profile_buffer",
 )
 
 
@@ -95,6 +97,15 @@ def lib():
                                     c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int64), c_void_p, c_float, c_int64, c_void_p]
         L.gta_attn_fwd_plain.argtypes = [ctypes.POINTER(GtaAttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                          c_void_p, c_void_p, c_void_p, c_void_p]
+        L.gta_debug_time_next_attention_kernel.argtypes = [c_void_p, c_void_p]
+        L.gta_debug_time_next_attention_kernel.restype = None
+        L.gta_debug_event_create.restype = c_void_p
+        L.gta_debug_event_destroy.argtypes = [c_void_p]
+        L.gta_debug_event_destroy.restype = None
+        L.gta_debug_event_elapsed_ms.argtypes = [c_void_p, c_void_p]
+        L.gta_debug_event_elapsed_ms.restype = c_float
+        L.gta_debug_set_profile_buffer.argtypes = [c_void_p]
+        L.gta_debug_set_profile_buffer.restype = None
         _lib = L
     return _lib
 
@@ -116,6 +127,29 @@ def _require_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
             raise GtaError("gta_amd kernels need CUDA/HIP tensors (MI355X); there is no CPU path")
+
+
+def check_table(name: str, t: Optional[torch.Tensor], shape, device, allow_none: bool = False):
+    """The kernels index the rep tables from the descriptor alone (vrep[b*N+n], cs[(b*T+t)*d_so2], coord[(b*T+t)*2]):
+    a table of another batch / token count / frequency count, or one that lives on the host, must raise here like the
+    reference's reshape / einsum would -- not read out of bounds on the device."""
+    if t is None:
+        if allow_none:
+            return
+        raise GtaError(f"{name} is required for this f_dims layout")
+    if not t.is_cuda or t.device != device:
+        raise GtaError(f"{name} must live on {device} (got {t.device})")
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise GtaError(f"{name} must be a contiguous float32 tensor (got {t.dtype}, contiguous={t.is_contiguous()})")
+    if tuple(t.shape) != tuple(shape):
+        raise GtaError(f"{name} has shape {tuple(t.shape)}, the kernels expect {tuple(shape)} for this q/k/f_dims")
+
+
+def check_scalar(name: str, t: Optional[torch.Tensor], device):
+    if t is None:
+        return
+    if not t.is_cuda or t.device != device or t.dtype != torch.float32 or t.numel() < 1:
+        raise GtaError(f"{name} must be a float32 tensor on {device} (it is read through a device pointer)")
 
 
 def build_view_reps(transforms: torch.Tensor, so3_degree: int) -> torch.Tensor:

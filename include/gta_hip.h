@@ -197,6 +197,18 @@ int gta_attn_fwd_supported(const GtaAttnDesc* desc);
 int gta_attn_fwd_launch_info(const GtaAttnDesc* desc, int32_t* lds_bytes, int32_t* n_workgroups,
                              int32_t* threads_per_wg);
 
+/* Profiling hooks (diagnostics; bench.py and tools/ use them, no product path does):
+ *   gta_debug_time_next_attention_kernel: the next attention-kernel launch made by THIS thread through gta_attn_fwd is
+ *     bracketed by the two events through the dispatch packet itself (hipExtLaunchKernelGGL), i.e. without the marker
+ *     packets of hipEventRecord that push neighbouring kernels apart.  One-shot.
+ *   gta_debug_event_*: thin wrappers so a ctypes caller needs no second HIP binding.
+ *   gta_debug_set_profile_buffer: per-work-item s_memtime stamps (only -DGTA_ABLATE builds write them). */
+void gta_debug_time_next_attention_kernel(void* start_event, void* stop_event);
+void* gta_debug_event_create(void);
+void gta_debug_event_destroy(void* event);
+float gta_debug_event_elapsed_ms(void* start_event, void* stop_event);
+void gta_debug_set_profile_buffer(void* device_buffer);
+
 const char* gta_strerror(int code);
 int gta_abi_version(void);
 int gta_sizeof_attn_desc(void);   /* sizeof(GtaAttnDesc) as compiled: binding self-check */

@@ -49,20 +49,9 @@ def golden_forward(case, dtype, use_dma=True, builder="packed", device="cuda", k
 
 def synth_inputs(B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, dtype, seed=0, device="cuda", cross=None,
                  coord_mode="grid"):
-    """Seeded synthetic (q,k,v,extras) following SURVEY 8d.  Returns CPU fp32 masters + device copies."""
-    g = torch.Generator().manual_seed(seed)
-    dh = sum(f_dims.values())
-    cross = (Nq, Pq) != (Nk, Pk) if cross is None else cross
-    ex = {"input_transforms": O.random_extrinsics(B, Nk, g)}
-    ex["input_coord"] = torch.rand(B, Nk, Pk, 2, generator=g)
-    if cross:
-        ex["target_transforms"] = O.random_extrinsics(B, Nq, g)
-        ex["target_coord"] = torch.rand(B, Nq, Pq, 2, generator=g)
-    q = torch.randn(B, H, Nq * Pq, dh, generator=g)
-    k = torch.randn(B, H, Nk * Pk, dh, generator=g)
-    v = torch.randn(B, H, Nk * Pk, dh, generator=g)
-    ak = {"f_dims": dict(f_dims), "so2": so2, "so3": so3, "max_freq_h": 1, "max_freq_w": 1}
-    return q, k, v, ex, ak, cross
+    """Seeded synthetic (q,k,v,extras) following SURVEY 8d (gta_amd.synth).  Returns CPU fp32 masters."""
+    from gta_amd import synth
+    return synth.attention_inputs(B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, seed=seed, cross=cross)
 
 
 def oracle_forward(q, k, v, ex, ak, cross, trans_coeff, v_transform=True, dtype=torch.float32):

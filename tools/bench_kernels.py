@@ -109,6 +109,54 @@ if __name__ == "__main__":
             flops = 4.0 * B * H_ * Nq_ * Pq_ * Nk_ * Pk_ * dh_
             msg = "  ".join(f"{n}: median {sorted(r)[3]*1e3:7.1f} us min {min(r)*1e3:7.1f} ({flops/sorted(r)[3]/1e9:6.1f} TF)" for n, r in res.items())
             print(f"{name:8s} {msg}", flush=True)
+    if which == "prep":
+        # the K/V pre-pass alone (FLAG_PREP_ONLY) at the BASELINE shapes: time and effective bandwidth on algorithmic bytes
+        shapes = {"MS-enc": (8, 5, 256, 5, 256, MS, 6, 2), "CL-enc": (6, 2, 300, 2, 300, CL, 8, 0), "DT": (16, 1, 1024, 1, 1024, {"so2": 64}, 16, 0)}
+        VT = native.FLAG_V_TRANSFORM
+        for name, (H_, Nq_, Pq_, Nk_, Pk_, FD, so2_, so3_) in shapes.items():
+            q, k, v, packed, L = setup(B, H_, Nq_, Pq_, Nk_, Pk_, FD, so2_, so3_, torch.bfloat16)
+            dh_ = sum(FD.values())
+            out = torch.empty(B, Nq_ * Pq_, H_, dh_, device="cuda", dtype=torch.bfloat16).permute(0, 2, 1, 3)
+            desc = native.make_desc(q, k, v, out, FD, L, Nq_, Nk_, dh_ ** -0.5, VT)
+            ws = torch.empty(native.attn_fwd_workspace_bytes(desc), device="cuda", dtype=torch.uint8)
+            fn = raw_call(q, k, v, packed, FD, L, VT | native.FLAG_PREP_ONLY, ws)[0]
+            ts = sorted(time_call(fn, n=20, warm=3) for _ in range(5))
+            byts = 2.0 * B * H_ * Nk_ * Pk_ * dh_ * 2 * 2          # read K,V + write K',V' (bf16)
+            print(f"{name:8s} prep median {ts[2]*1e3:6.1f} us  min {ts[0]*1e3:6.1f} us   {byts/ts[2]/1e9:6.2f} TB/s on {byts/1e6:.0f} MB algorithmic", flush=True)
+    if which == "ctx2":
+        # the attention kernel timed by its own dispatch events (gta_debug_time_next_attention_kernel) in three contexts:
+        # back to back with itself, behind the K/V pre-pass of the same call (the bench's order), behind pre-pass + rep build
+        import ctypes
+        Lb = native.lib()
+        q, k, v, packed, L = setup(B, 8, 5, 256, 5, 256, MS, 6, 2, torch.bfloat16)
+        VT = native.FLAG_V_TRANSFORM
+        out = torch.empty(B, 1280, 8, 96, device="cuda", dtype=torch.bfloat16).permute(0, 2, 1, 3)
+        desc = native.make_desc(q, k, v, out, MS, L, 5, 5, 96 ** -0.5, VT)
+        ws = torch.empty(native.attn_fwd_workspace_bytes(desc), device="cuda", dtype=torch.uint8)
+        fn_both, _ = raw_call(q, k, v, packed, MS, L, VT, ws)
+        fn_flash, _ = raw_call(q, k, v, packed, MS, L, VT | native.FLAG_KV_READY, ws)
+        fn_both()
+        n = 30
+        evs = [(Lb.gta_debug_event_create(), Lb.gta_debug_event_create()) for _ in range(n)]
+        def run(label, fn, pre=None):
+            for _ in range(5):
+                if pre: pre()
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for a, b in evs:
+                if pre: pre()
+                Lb.gta_debug_time_next_attention_kernel(ctypes.c_void_p(a), ctypes.c_void_p(b))
+                fn()
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t0) / n * 1e6
+            ks = sorted(Lb.gta_debug_event_elapsed_ms(ctypes.c_void_p(a), ctypes.c_void_p(b)) * 1e3 for a, b in evs)
+            print(f"{label:44s} attention kernel median {ks[n // 2]:7.1f} us  min {ks[0]:7.1f}  max {ks[-1]:7.1f}   loop period {wall:7.1f} us", flush=True)
+        import time
+        for _ in range(2):
+            run("attention after itself", fn_flash)
+            run("attention behind the K/V pre-pass", fn_both)
+            run("behind pre-pass, 300 us idle in front", fn_both, pre=lambda: torch.cuda._sleep(600000))
     if which == "ctx":
         # the attention kernel in the bench's context: right behind the K/V pre-pass of the same step (instrumented build).
         # Prints its span and shader clock there and in a back-to-back loop of itself.
