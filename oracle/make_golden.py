@@ -289,6 +289,59 @@ def srt_case(name, seed):
     np.savez_compressed(os.path.join(OUT, f"srt_{name}.npz"), **rec)
 
 
+def vecrep_case(name, seed):
+    """The ``elementwise_mul`` ablation, as far as the reference can run it: ``pre_compute_reps`` builds the flattened reps
+    (encoder.py:200-206,238-243,263-265), the ``rep_to_vec`` Linear of ``Attention(elementwise_mul=True)``
+    (layers.py:265-271) maps them to per-token vectors, and ``multihead_vecrep_attention`` (gta.py:282-298) is called
+    with them -- forward and autograd gradients.  ``Attention.forward`` itself cannot be recorded: layers.py:422-428
+    passes ``reps=extras`` to a function whose parameter is named ``extras`` and raises TypeError (dead path in the
+    checkout; asserted below so a fixed reference would be noticed).  Pins ``O.vecrep_attention``."""
+    torch.manual_seed(seed)
+    g = gen(seed)
+    dtype = torch.float64
+    f_dims = {"se3": 16, "so2": 16}
+    B, N, P, H, dh, dim = 2, 2, 9, 2, 32, 24
+    ak = attn_kwargs(f_dims, 4, 0, elementwise_mul=True)
+    aa = {"method": {"name": "gta", "args": ak}}
+    att = ref_layers.Attention(dim=dim, heads=H, dim_head=dh, dropout=0.0, attn_args=aa).double()
+    extras = {"input_transforms": O.random_extrinsics(B, N, g, dtype), "input_coord": rand_coords(B, N, P, g)}
+    ref_enc.ImprovedSRTEncoder.pre_compute_reps(None, ak, extras)
+    try:
+        att(torch.randn(B, N * P, dim, generator=g, dtype=dtype), extras=dict(extras))
+        raise AssertionError("the reference's elementwise_mul module path now runs: record it")
+    except TypeError:
+        pass
+    T = N * P
+    q = torch.randn(B, H, T, dh, generator=g, dtype=dtype).requires_grad_()
+    k = torch.randn(B, H, T, dh, generator=g, dtype=dtype).requires_grad_()
+    v = torch.randn(B, H, T, dh, generator=g, dtype=dtype).requires_grad_()
+    w = torch.randn(B, H, T, dh, generator=g, dtype=dtype)
+    with torch.no_grad():
+        vecs = {"vecrep_q": att.rep_to_vec(extras["flattened_rep_q"]), "vecrep_k": att.rep_to_vec(extras["flattened_rep_k"]),
+                "vecinvrep_q": att.rep_to_vec(extras["flattened_invrep_q"])}
+    out, attn = ref_gta.multihead_vecrep_attention(q, k, v, att.attn_fn, vecs)
+    (out * w).sum().backward()
+    q2, k2, v2 = (t.detach().clone().requires_grad_() for t in (q, k, v))
+    out_o, attn_o = O.vecrep_attention(q2, k2, v2, vecs["vecrep_q"], vecs["vecrep_k"], vecs["vecinvrep_q"], dh ** -0.5)
+    (out_o * w).sum().backward()
+    dev = {"out": (out_o - out).abs().max().item(), "attn": (attn_o - attn).abs().max().item(),
+           "dq": (q2.grad - q.grad).abs().max().item(), "dk": (k2.grad - k.grad).abs().max().item(),
+           "dv": (v2.grad - v.grad).abs().max().item()}
+    worst = max(dev.values())
+    print(f"{name:28s} oracle-vs-reference max dev {worst:.2e}  (multihead_vecrep_attention + grads)")
+    assert worst < 5e-12, dev
+    rec = {"q": q.detach().numpy(), "k": k.detach().numpy(), "v": v.detach().numpy(), "w": w.numpy(),
+           "out": out.detach().numpy(), "dq": q.grad.numpy(), "dk": k.grad.numpy(), "dv": v.grad.numpy(),
+           "scale": np.float64(dh ** -0.5),
+           "rep_to_vec.weight": att.rep_to_vec.weight.detach().numpy(), "rep_to_vec.bias": att.rep_to_vec.bias.detach().numpy(),
+           "meta": np.array(repr(dict(f_dims=f_dims, so2=4, so3=0, dim=dim, H=H, dh=dh, B=B, N=N, P=P)))}
+    rec.update({k_: v_.numpy() for k_, v_ in vecs.items()})
+    rec.update(flat("extras.", {k_: v_ for k_, v_ in extras.items()
+                                if k_ in ("input_transforms", "input_coord", "flattened_rep_q", "flattened_rep_k",
+                                          "flattened_invrep_q")}))
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **rec)
+
+
 def wigner_case():
     """Reference rotmat_to_wigner_d_matrices on random + gimbal rotations (J unpinned)."""
     g = gen(7)
@@ -371,6 +424,7 @@ if __name__ == "__main__":
     operator_case("euclid_tau", {"se3": 6, "so2": 8}, 2, 0, H=2, B=2, Nq=2, Pq=5, Nk=2, Pk=5, seed=13,
                   cross=False, euclid=True, tau=1.3)
     srt_case("ms_tiny", seed=30)
+    vecrep_case("vecrep_attn", seed=40)
     module_case("enc_cl", CL, 2, 0, dim=32, depth=2, H=2, dh=16, B=2, Nq=2, Pq=6, Nk=2, Pk=6, seed=20,
                 cross=False)
     module_case("dec_ms", MS, 2, 2, dim=20, depth=2, H=2, dh=24, B=1, Nq=3, Pq=7, Nk=2, Pk=5, seed=21,

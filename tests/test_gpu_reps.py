@@ -47,6 +47,42 @@ def test_view_reps_gimbal_rows_follow_the_reference_formula():
     assert (got[:, native.VREP_D2:native.VREP_D2 + 25].reshape(-1, 5, 5) - Ds[1].reshape(-1, 5, 5).float()).abs().amax() <= 5e-6
 
 
+def test_view_reps_r22_minus_one_rows_follow_the_reference_formula():
+    """R22 = -1 takes the reference's other masked branch, gamma1 = atan2(-R10, -R00) (wigner_d.py:46-47) -- whose
+    output is NOT the closed-form representation (a quirk kept on purpose).  The rotations of
+    fixture wigner.npz (the last one is that gimbal case) go through the HIP builder as inverse(E) blocks and must
+    reproduce the REFERENCE's matrices, quirk included."""
+    from tests import _golden as G
+    d, _ = G.load("wigner")
+    R = torch.from_numpy(d["R"])                                   # [n, 3, 3] fp64; R = inverse(E)[:3,:3]
+    n = R.shape[0]
+    assert abs(float(R[-1, 2, 2]) + 1.0) < 1e-12                    # the R22 = -1 case is in the fixture
+    E = torch.eye(4, dtype=torch.float64).repeat(n, 1, 1)
+    E[:, :3, :3] = R.transpose(-1, -2)                              # E = inverse of [R | 0]
+    got = native.build_view_reps(E.float().reshape(1, n, 4, 4).cuda(), 2).cpu()[0].double()
+    D1 = got[:, native.VREP_D1:native.VREP_D1 + 9].reshape(n, 3, 3)
+    D2 = got[:, native.VREP_D2:native.VREP_D2 + 25].reshape(n, 5, 5)
+    assert (D1 - torch.from_numpy(d["D1"])).abs().amax() <= 2e-5
+    assert (D2 - torch.from_numpy(d["D2"])).abs().amax() <= 4e-5
+    # the quirk is visible: on that row the reference (and the builder) is far from the closed form
+    D1c, _ = O.wigner_d_closed_form(R)
+    assert (D1[-1] - D1c[-1]).abs().max() > 0.5
+
+
+def test_flattened_reps_match_reference():
+    """``flattened_rep_q`` / ``flattened_invrep_q`` of the elementwise_mul ablation (encoder.py:200-206,238-243,263-265)
+    rebuilt from the HIP tables against the reference's tensors (fixture vecrep_attn.npz)."""
+    import gta_amd
+    from tests import _golden as G
+    d, meta = G.load("vecrep_attn")
+    ak = {"f_dims": meta["f_dims"], "so2": meta["so2"], "so3": 0, "max_freq_h": 1, "max_freq_w": 1, "elementwise_mul": True}
+    ex = {"input_transforms": torch.from_numpy(d["extras.input_transforms"]).float().cuda(),
+          "input_coord": torch.from_numpy(d["extras.input_coord"]).float().cuda()}
+    gta_amd.pre_compute_reps_encoder(ak, ex)
+    for key in ("flattened_rep_q", "flattened_rep_k", "flattened_invrep_q"):
+        assert (ex[key].cpu().double() - torch.from_numpy(d["extras." + key])).abs().max() < 5e-6, key
+
+
 @pytest.mark.parametrize("shared", [False, True])
 def test_so2_table_matches_oracle(shared):
     g = torch.Generator().manual_seed(5)

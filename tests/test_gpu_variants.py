@@ -170,6 +170,73 @@ def test_vecrep_attention_forward_backward():
         assert st["finite"] and st["rel_rms"] < 2e-2, (name, st)
 
 
+def test_vecrep_fixture_forward_backward():
+    """``multihead_vecrep_attention`` against the REFERENCE's own output and autograd gradients (fixture vecrep_attn.npz,
+    gta.py:282-298 run on vectors from the reference's pre_compute_reps + rep_to_vec)."""
+    from tests import _golden as G
+    d, meta = G.load("vecrep_attn")
+    q, k, v = (torch.from_numpy(d[n]).float().cuda().requires_grad_() for n in "qkv")
+    ex = {n: torch.from_numpy(d[n]).float().cuda() for n in ("vecrep_q", "vecrep_k", "vecinvrep_q")}
+    out, _ = gta_amd.multihead_vecrep_attention(q, k, v, attn_fn=SimpleNamespace(scale=float(d["scale"])), extras=ex)
+    (out * torch.from_numpy(d["w"]).float().cuda()).sum().backward()
+    torch.cuda.synchronize()
+    for name, a, b in (("out", out.detach(), d["out"]), ("dq", q.grad, d["dq"]), ("dk", k.grad, d["dk"]), ("dv", v.grad, d["dv"])):
+        st = C.err_stats(a.cpu(), torch.from_numpy(b).float())
+        assert st["finite"] and st["rel_rms"] < 2e-2 and st["max_abs"] < 4e-2 * st["ref_max"], (name, st)
+
+
+def test_t2_dict_shared_by_encoder_and_decoder():
+    """Level-2 drop-in: ONE reference-style reps dict goes through an encoder call (q side = k side,
+    600 tokens) and then a decoder call that replaced the q side with the target's tensors (more query tokens than keys).
+    The packed coordinate / (cos,sin) tables cached in the dict must follow the replacement (a stale q-side
+    t2 table of the encoder would be indexed out of bounds)."""
+    from oracle import gta_oracle as O
+    f_dims = {"so2": 8, "t2": 6}
+    ak = {"f_dims": f_dims, "so2": 2, "so3": 0, "max_freq_h": 1, "max_freq_w": 1}
+    g = torch.Generator().manual_seed(11)
+    B, H, Nk, Pk, Nq, Pq = 1, 2, 2, 20, 3, 30
+    ex = {"input_transforms": O.random_extrinsics(B, Nk, g).double(), "input_coord": torch.rand(B, Nk, Pk, 2, generator=g).double(),
+          "target_transforms": O.random_extrinsics(B, Nq, g).double(), "target_coord": torch.rand(B, Nq, Pq, 2, generator=g).double()}
+    dh = sum(f_dims.values())
+    qe, ke, ve = (torch.randn(B, H, Nk * Pk, dh, generator=g) for _ in range(3))
+    qd = torch.randn(B, H, Nq * Pq, dh, generator=g)
+    reps = O.encoder_reps(ak, ex)                                 # reference-style tensors (t2rep_q/k, so2rep_q/k)
+    ref_e, _ = O.gta_attention(qe.double(), ke.double(), ve.double(), f_dims, reps, None, True)
+    shared = {kk: ([u.float().cuda() for u in vv] if isinstance(vv, list) else vv.float().cuda()) for kk, vv in reps.items()
+              if torch.is_tensor(vv) or isinstance(vv, list)}
+    fn = SimpleNamespace(scale=dh ** -0.5)
+    out_e, _ = gta_amd.multihead_geometric_transform_attention(qe.cuda(), ke.cuda(), ve.cuda(), attn_fn=fn, f_dims=f_dims, reps=shared)
+    reps_d = O.decoder_reps(ak, ex, reps)
+    ref_d, _ = O.gta_attention(qd.double(), ke.double(), ve.double(), f_dims, reps_d, None, True)
+    for kk, vv in reps_d.items():                                  # the decoder overwrites entries of the SAME dict
+        if torch.is_tensor(vv):
+            shared[kk] = vv.float().cuda()
+    out_d, _ = gta_amd.multihead_geometric_transform_attention(qd.cuda(), ke.cuda(), ve.cuda(), attn_fn=fn, f_dims=f_dims, reps=shared)
+    torch.cuda.synchronize()
+    for name, a, b in (("encoder", out_e, ref_e), ("decoder", out_d, ref_d)):
+        st = C.err_stats(a.float().cpu(), b.float())
+        assert st["finite"] and st["rel_rms"] < 1.5e-2, (name, st)
+
+
+def test_rep_tables_are_validated():
+    """Tables of another batch / token count, on the host, or of the wrong dtype raise before any kernel sees them."""
+    f_dims = {"se3": 16, "so2": 16}
+    q, k, v, ex, ak, _ = C.synth_inputs(2, 2, 2, 20, 2, 20, f_dims, 4, 0, torch.float32, seed=1)
+    exd = {kk: vv.cuda() for kk, vv in ex.items()}
+    gta_amd.pre_compute_reps_encoder(ak, exd)
+    packed = gta_amd.pack_reps(exd, f_dims)
+    qd, kd, vd = q.cuda(), k.cuda(), v.cuda()
+    gta_amd.gta_attention(qd, kd, vd, f_dims, packed, trans_coeff=0.01)                       # fine
+    for key, bad in (("vrep_q", packed["vrep_q"][:1]), ("cs_q", packed["cs_q"][:, :10]), ("cs_k", packed["cs_k"].cpu()),
+                     ("vrep_k", packed["vrep_k"].double()), ("cs_q", packed["cs_q"][..., :4, :])):
+        broken = dict(packed)
+        broken[key] = bad
+        with pytest.raises(gta_amd.native.GtaError):
+            gta_amd.gta_attention(qd, kd, vd, f_dims, broken, trans_coeff=0.01)
+    with pytest.raises(gta_amd.native.GtaError):
+        gta_amd.gta_attention(qd, kd, vd, f_dims, packed, trans_coeff=torch.tensor([0.01]))    # host scalar
+
+
 def test_elementwise_mul_module_runs_and_trains():
     ak = {"f_dims": {"se3": 16, "so2": 16}, "so2": 4, "so3": 0, "max_freq_h": 1, "max_freq_w": 1, "elementwise_mul": True}
     att = gta_amd.Attention(48, heads=2, dim_head=32, attn_args={"method": {"name": "gta", "args": ak}}).cuda()

@@ -65,6 +65,23 @@ def test_transformer_module_matches_reference(case):
         assert np.abs(p.grad.numpy() - d["grad." + n]).max() < TOL, n
 
 
+def test_vecrep_operator_matches_reference():
+    """``multihead_vecrep_attention`` (gta.py:282-298, the elementwise_mul ablation) with autograd gradients: fixture
+    vecrep_attn.npz was produced by the reference function on vectors from the reference's ``pre_compute_reps`` +
+    ``rep_to_vec`` (oracle/make_golden.py::vecrep_case)."""
+    d, meta = G.load("vecrep_attn")
+    q, k, v = (torch.from_numpy(d[n]).requires_grad_() for n in "qkv")
+    vq, vk, vi = (torch.from_numpy(d[n]) for n in ("vecrep_q", "vecrep_k", "vecinvrep_q"))
+    out, _ = O.vecrep_attention(q, k, v, vq, vk, vi, float(d["scale"]))
+    (out * torch.from_numpy(d["w"])).sum().backward()
+    assert np.abs(out.detach().numpy() - d["out"]).max() < TOL
+    for n, t in (("dq", q), ("dk", k), ("dv", v)):
+        assert np.abs(t.grad.numpy() - d[n]).max() < TOL, n
+    # and the vectors themselves are rep_to_vec of the reference's flattened reps
+    W, b = torch.from_numpy(d["rep_to_vec.weight"]), torch.from_numpy(d["rep_to_vec.bias"])
+    assert (torch.from_numpy(d["extras.flattened_rep_q"]) @ W.T + b - vq).abs().max() < TOL
+
+
 def test_wigner_euler_matches_reference():
     d, _ = G.load("wigner")
     R = torch.from_numpy(d["R"])
