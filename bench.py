@@ -110,6 +110,50 @@ def latest_traffic(workload, B, dtype):
     return None, None
 
 
+def dry_run(args):
+    """The multi-process control flow of main() on CPU: rendezvous from the launcher's environment, barrier, timed loop,
+    barrier, MAX over ranks, per-rank times gathered, one JSON line on rank 0.  No kernel runs; `value` is meaningless."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    dist = None
+    if args.gpus > 1 or world > 1:
+        import torch.distributed as dist
+        assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
+        dist.init_process_group("gloo")
+    H, Nq, Pq, Nk, Pk, f_dims, so2, so3, Bdef = WORKLOADS[args.workload]
+    B = args.batch or Bdef
+    x = torch.zeros(8)
+    for _ in range(args.warmup):
+        x += 1
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x += 1
+        time.sleep(0.001 * (1 + rank))
+    if dist is not None:
+        dist.barrier()
+    elapsed = mine = time.perf_counter() - t0
+    per_rank = [mine / args.steps * 1e3]
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        g = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(g, torch.tensor([mine / args.steps * 1e3], dtype=torch.float64))
+        per_rank = [float(u.item()) for u in g]
+    if rank == 0:
+        n = max(world, 1)
+        print(json.dumps({"metric": "GTA-attn Mtokens/s (V=5,H=W=128,d=768)", "value": n * B * Nq * Pq * args.steps / elapsed / 1e6,
+                          "unit": "Mtokens/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": elapsed / args.steps * 1e3, "per_rank_ms_per_step": per_rank,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+                          "data": "synthetic", "dry_run": True,
+                          "config": {"workload": args.workload, "global_batch": n * B, "parallelism": f"dp{n}"}}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,7 +172,12 @@ def main():
                     help="extra (untimed-for-`value`) forward+backward steps reported as fwd_bwd_* fields; 0 = skip")
     ap.add_argument("--kv-mode", dest="kv_mode", default="prepass", choices=["prepass", "fused"],
                     help="execution plan of gta_attn_fwd (see include/gta_hip.h)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="plumbing check without a GPU: same launch contract, rendezvous (gloo), barriers, MAX-over-ranks and "
+                         "JSON line, the step itself replaced by a host no-op (tests/test_ddp_gloo.py runs this at world size 2)")
     args = ap.parse_args()
+    if args.dry_run:
+        return dry_run(args)
 
     import gta_amd
     from gta_amd import native, plan, synth
@@ -201,11 +250,15 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = mine = time.perf_counter() - t0
+    per_rank = [mine / args.steps * 1e3]
     if dist is not None:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        g = [torch.zeros(1, device=device, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(g, torch.tensor([mine / args.steps * 1e3], device=device, dtype=torch.float64))
+        per_rank = [float(u.item()) for u in g]
 
     if fused:
         kern_ms = None
@@ -253,8 +306,9 @@ def main():
         from gta_amd import srt, ddp
         torch.manual_seed(1234 + rank)
         model = srt.TransformingSRT(srt.msn_gta_so3_cfg()).to(device)
+        bucket_log = None
         if dist is not None:
-            model = ddp.wrap_ddp(model, local_rank)
+            model, bucket_log = ddp.wrap_ddp_logged(model, local_rank)
         opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
         batch = srt.synthetic_batch(args.model_batch, device=device, seed=99 + rank)
 
@@ -268,6 +322,8 @@ def main():
         for _ in range(2):
             model_step()
         torch.cuda.synchronize()
+        if bucket_log is not None:
+            bucket_log.reset()
         if dist is not None:
             dist.barrier()
         tm0 = time.perf_counter()
@@ -290,6 +346,8 @@ def main():
                                f"views, 1280 scene tokens, 2560 query rays), {args.model_batch} scenes/GPU, "
                                f"AdamW, {args.dtype} autocast, dp{n_}",
                      "note": "whole-model optimizer step on synthetic batches (SURVEY 8 f2); not part of `value`"}
+        if bucket_log is not None:
+            srt_train["grad_allreduce"] = bucket_log.summary(args.model_train_steps)
         del model, opt, batch
     flops = 4.0 * B * H * Tq * Tk * dh                               # QK^T + PV, 2 flop/MAC
     alg_bytes = (2 * Tq + 2 * Tk) * H * dh * q.element_size() * B    # read Q,K,V once, write O once
@@ -309,7 +367,7 @@ def main():
             "config": {"workload": f"{args.workload}: GTA attention forward (rep build + K/V rep pre-pass + attention kernel), "
                                    f"B={B}/GPU, H={H}, Tq={Tq}, Tk={Tk}, dh={dh}, f_dims={f_dims}, "
                                    f"views q/k={Nq}/{Nk}", "global_batch": n * B, "parallelism": f"dp{n}"},
-            "host_ms_per_step": t_host / args.steps * 1e3,
+            "host_ms_per_step": t_host / args.steps * 1e3, "per_rank_ms_per_step": per_rank,
         }
         if achieved is not None:
             line["roofline"] = {"bound": "mfma", "kernel": "gta_fwd2_kernel", "achieved": achieved,

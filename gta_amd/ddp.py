@@ -97,6 +97,56 @@ def wrap_ddp(model: torch.nn.Module, local_rank: int = 0, bucket_mb: int = XGMI_
     return DDP(model, bucket_cap_mb=bucket_mb)
 
 
+class BucketLog:
+    """DDP communication hook that does what the default hook does (all-reduce the bucket, divide by the world size)
+    and keeps a timeline: per bucket its bytes and -- on CUDA -- events around the collective on the stream it runs on.
+    ``summary()`` after a synchronise gives bytes, bucket count and the summed all-reduce time of the logged steps, so
+    ``bench.py --model-train-steps`` can report the collective beside the step."""
+
+    def __init__(self):
+        self.rows = []
+
+    def reset(self):
+        self.rows = []
+
+    def hook(self, state, bucket):
+        t = bucket.buffer()
+        w = dist.get_world_size()
+        ev = None
+        if t.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        fut = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True).get_future()
+        row = {"bytes": t.numel() * t.element_size(), "events": ev}
+        self.rows.append(row)
+
+        def done(f):
+            out = f.value()[0]
+            out.div_(w)
+            if ev is not None:
+                ev[1].record()
+            return out
+        return fut.then(done)
+
+    def summary(self, steps: int = 1):
+        if not self.rows:
+            return None
+        ms = [r["events"][0].elapsed_time(r["events"][1]) for r in self.rows if r["events"] is not None]
+        return {"buckets_per_step": len(self.rows) / max(steps, 1), "bytes_per_step": sum(r["bytes"] for r in self.rows) / max(steps, 1),
+                "allreduce_ms_per_step": (sum(ms) / max(steps, 1)) if ms else None,
+                "note": "events around each bucket's all-reduce (issue -> result scaled); buckets overlap the backward"}
+
+
+def wrap_ddp_logged(model: torch.nn.Module, local_rank: int = 0, bucket_mb: int = XGMI_BUCKET_MB):
+    """wrap_ddp + a BucketLog registered as the communication hook: (model, log); (model, None) when single process."""
+    m = wrap_ddp(model, local_rank, bucket_mb)
+    if m is model:
+        return m, None
+    log = BucketLog()
+    m.register_comm_hook(None, log.hook)
+    return m, log
+
+
 def max_over_ranks(seconds: float, device=None) -> float:
     """MAX of a host-measured duration over ranks (bench.py contract)."""
     r, w = world()

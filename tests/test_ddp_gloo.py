@@ -47,12 +47,14 @@ def _worker(rank, world, port, q):
 
     # single-process reference gradient on the GLOBAL batch
     ref = {n: torch.autograd.grad(loss_of(model, batch), p, retain_graph=False)[0] for n, p in model.named_parameters()}
-    dmodel = ddp.wrap_ddp(model)
+    dmodel, blog = ddp.wrap_ddp_logged(model)          # DDP + the bucket timeline hook (bench.py --model-train-steps)
     local = ddp.shard_batch(batch, rank, world)
     assert local["x"].shape[0] == B // world
     loss = loss_of(dmodel, local)
     loss.backward()
     err = max((p.grad - ref[n]).abs().max().item() for n, p in model.named_parameters())
+    summ = blog.summary(1)
+    assert summ["buckets_per_step"] >= 1 and summ["bytes_per_step"] == sum(p.numel() * 8 for p in model.parameters())
     red = ddp.reduce_dict({"loss": loss.detach().reshape(1), "rank": torch.tensor([float(rank)])})
     ga = ddp.gather_all(torch.tensor([rank * 10, rank * 10 + 1]))
     tmax = ddp.max_over_ranks(1.0 + rank)
@@ -86,3 +88,27 @@ def test_shard_batch_rejects_uneven():
         ddp.shard_batch({"x": torch.zeros(5, 3)}, 0, 2)
     assert ddp.shard_batch({"x": torch.arange(6).reshape(6, 1)}, 1, 3)["x"].flatten().tolist() == [2, 3]
     assert ddp.init_ddp() == (0, 1, 0) or "WORLD_SIZE" in os.environ
+
+
+def test_bench_launch_contract_dry_run_world2():
+    """bench.py under the driver's own launch line (torch.distributed.run, --nproc-per-node 2, 127.0.0.1 rendezvous) in
+    --dry-run mode: the rendezvous from the environment, both barriers, the MAX over ranks, the per-rank gather and the
+    single JSON line on rank 0 run for real (gloo, CPU); only the step is a host no-op.  The first real multi-GPU run
+    must not fail on plumbing."""
+    import json
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--dry-run"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout                       # exactly one JSON line (rank 0 only)
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak" and rec["dry_run"]
+    assert len(rec["per_rank_ms_per_step"]) == 2
+    # MAX over ranks: rank 1 sleeps twice as long per step as rank 0
+    assert rec["ms_per_step"] >= max(rec["per_rank_ms_per_step"]) * 0.95
+    assert rec["per_rank_ms_per_step"][1] > rec["per_rank_ms_per_step"][0]
+    assert rec["config"]["global_batch"] == 64 and rec["config"]["parallelism"] == "dp2"
