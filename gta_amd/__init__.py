@@ -10,5 +10,6 @@ from .gta import (multihead_geometric_transform_attention, make_2dcoord, make_SO
 from .layers import Attention, Transformer, PreNorm, FeedForward, JaxLinear, ViTLinear  # noqa: F401
 from .reps import pre_compute_reps_encoder, pre_compute_reps_decoder  # noqa: F401
 from .srt import ImprovedSRTEncoder, ImprovedSRTDecoder, TransformingSRT  # noqa: F401
+from .image2d import GTA2DTransformer  # noqa: F401
 
 __version__ = "0.1.0"

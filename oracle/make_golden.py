@@ -429,6 +429,10 @@ if __name__ == "__main__":
                 cross=False)
     module_case("dec_ms", MS, 2, 2, dim=20, depth=2, H=2, dh=24, B=1, Nq=3, Pq=7, Nk=2, Pk=5, seed=21,
                 cross=True, kv_dim=48)
+    # the encoder attention of runs/clevrtr/GTA/gta_no3demb (f_dims {so2: 64}, so2: 16): pure-SO(2) GTA, the case the
+    # DiT branch (README.md:24,36) uses -- one "view" whose tokens are the patches of a 6 x 6 grid
+    module_case("dit_so2", {"so2": 64}, 16, 0, dim=32, depth=1, H=2, dh=64, B=2, Nq=1, Pq=36, Nk=1, Pk=36, seed=22,
+                cross=False)
     wigner_case()
     so2_case()
     print("golden fixtures written to", OUT)

@@ -161,3 +161,76 @@ def test_render_image_chunked_decode():
     assert st["finite"] and st["max_abs"] < 1e-2, st
     mse = ((img_c.cpu() - ref) ** 2).mean()
     assert mse < 1e-5, mse
+
+
+def test_render_image_full_size_view():
+    """Full-image decode at the evaluation size (trainer.py:137-181, evaluate.py:122-131): one 128 x 128 target view per
+    scene = 16 384 query rays in 2 048-ray chunks with the per-layer K/V cache, against the oracle decoding all pixels
+    in one call under the reference's weights (fixture srt_ms_tiny).  Every pixel is compared."""
+    from gta_amd import srt
+    from oracle import gta_oracle as O
+    import ast
+    import numpy as np
+    d, model, data = _srt()
+    model.eval()
+    h = w = 128
+    B = data["input_images"].shape[0]
+    g = torch.Generator().manual_seed(5)
+    rays = torch.nn.functional.normalize(torch.randn(B, h, w, 3, generator=g), dim=-1).cuda()
+    cam = torch.randn(B, 3, generator=g).cuda()
+    extras = {"input_transforms": data["input_transforms"], "input_coord": data["input_coord"],
+              "target_transforms": data["target_transforms"][:, 1:2]}
+    with torch.no_grad():
+        z, extras = model.encoder(data["input_images"], data["input_camera_pos"], data["input_rays"], extras)
+        img, _ = srt.render_image(model, z, cam, rays, extras, max_num_rays=2048, reuse_kv=True)
+    torch.cuda.synchronize()
+    assert img.shape == (B, h, w, 3)
+    cfg = ast.literal_eval(str(np.load(G.GOLDEN + "/srt_ms_tiny.npz")["meta"]))
+    om = O.OracleSRT(cfg)
+    om.load_state_dict({k[len("param."):]: torch.from_numpy(v).float() for k, v in d.items() if k.startswith("param.")},
+                       strict=True)
+    om.eval()
+    coord = torch.from_numpy(gta_amd.gta.make_2dcoord(h, w)).flatten(0, 1)[None, None].expand(B, 1, -1, -1)
+    ex_o = {"input_transforms": data["input_transforms"].cpu(), "input_coord": data["input_coord"].cpu(),
+            "target_transforms": data["target_transforms"][:, 1:2].cpu(), "target_coord": coord}
+    with torch.no_grad():
+        ref = om(data["input_images"].cpu(), None, None, None, rays.cpu().flatten(1, 2), ex_o).view(B, h, w, 3)
+    st = C.err_stats(img.cpu(), ref)
+    assert st["finite"] and st["max_abs"] < 1e-2, st
+    assert ((img.cpu() - ref) ** 2).mean() < 1e-5
+
+
+def test_gta2d_transformer_dit_shape_vs_oracle():
+    """The pure-SO(2) 2-D GTA block at the DiT stress shape (BASELINE config 5: 32 x 32 patch grid = 1024 tokens, 16
+    heads x 64 channels, so2 = 16 frequencies) against the oracle's Transformer under the same weights; forward, input
+    gradient and parameter gradients.  (The reference fixture of this layout is mod_dit_so2, run by
+    test_transformer_forward_backward_vs_reference.)"""
+    from oracle import gta_oracle as O
+    torch.manual_seed(0)
+    dim, depth, H, dh, grid, B = 128, 1, 16, 64, (32, 32), 2
+    m = gta_amd.GTA2DTransformer(dim, depth, H, dh, 2 * dim, grid).cuda()
+    ak = dict(m.attn_kwargs)
+    om = O.OracleTransformer(dim, depth, H, dh, 2 * dim, 0.0, True, None, False, {"method": {"name": "gta", "args": ak}})
+    om.load_state_dict({k: v.detach().cpu() for k, v in m.transformer.state_dict().items()}, strict=True)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, grid[0] * grid[1], dim, generator=g)
+    wgt = torch.randn(B, grid[0] * grid[1], dim, generator=g)
+    coord = torch.from_numpy(gta_amd.make_2dcoord(*grid)).reshape(1, 1, -1, 2).expand(B, 1, -1, -1).float()
+    reps = O.encoder_reps(ak, {"input_coord": coord, "input_transforms": torch.eye(4).repeat(B, 1, 1, 1)})
+    xo = x.clone().requires_grad_()
+    yo = om(xo, None, reps)
+    (yo * wgt).sum().backward()
+    xd = x.cuda().requires_grad_()
+    yd = m(xd)
+    (yd * wgt.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    st = C.err_stats(yd.detach().cpu(), yo.detach())
+    assert st["finite"] and st["rel_rms"] < 1e-2 and st["max_abs"] < 3e-2 * st["ref_max"], st
+    st = C.err_stats(xd.grad.cpu(), xo.grad)
+    assert st["finite"] and st["rel_rms"] < 3e-2, st
+    go = dict(om.named_parameters())
+    for n, p in m.transformer.named_parameters():
+        st = C.err_stats(p.grad.cpu(), go[n].grad)
+        assert st["finite"] and st["max_abs"] <= 5e-2 * max(st["ref_max"], 1e-3) + 1e-5, (n, st)
+    # the module reuses its coordinate table and the kernels ran the SO2 layout (no view records, dh = 64)
+    assert m.reps(B, xd.device)["gta_cs_q"].shape == (B, 1024, 32, 2)

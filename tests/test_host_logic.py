@@ -180,3 +180,40 @@ def test_reference_checkpoint_layout_round_trip(tmp_path):
     checkpoint.save_checkpoint(out, {"it": 1}, encoder=model.encoder, decoder=model.decoder)
     again = torch.load(out, weights_only=False)
     assert sorted(again) == ["decoder", "encoder", "it"] and list(again["encoder"]) == list(ref_file["encoder"])
+
+
+def test_j_convention_check(tmp_path):
+    """a J_dense.pt is compared with the build's J before a released so3 checkpoint is served.  The real
+    blob is not in the image, so the check itself is tested: identical J -> trivial signs; a sign-conjugated J (another
+    real-SH sign convention) -> the conjugating S is found and the oracle's Wigner-D under that J is S D S; anything
+    else raises.  The build's constants equal the oracle's (which make_golden.py uses as the stand-in blob)."""
+    from gta_amd import checkpoint
+    from oracle import gta_oracle as O
+    for l, mine in ((1, checkpoint.J1), (2, checkpoint.J2)):
+        assert torch.allclose(torch.tensor(mine, dtype=torch.float64), O.J_MATRICES[l], atol=1e-15)
+    blob = [O.J_MATRICES[l].clone() for l in range(3)]
+    path = str(tmp_path / "J_dense.pt")
+    torch.save(blob, path)
+    S = checkpoint.check_j_convention(path)
+    assert all((S[l] == 1).all() for l in (1, 2))
+    s1 = torch.tensor([-1.0, 1.0, -1.0], dtype=torch.float64)
+    s2 = torch.tensor([-1.0, 1.0, 1.0, 1.0, -1.0], dtype=torch.float64)
+    flipped = [blob[0], s1[:, None] * blob[1] * s1[None], s2[:, None] * blob[2] * s2[None]]
+    S = checkpoint.check_j_convention(flipped)
+    assert torch.equal(S[1], s1) and torch.equal(S[2], s2)
+    # what that means for the reps: D under the flipped J is S D S
+    g = torch.Generator().manual_seed(0)
+    R = O.random_extrinsics(1, 4, g, torch.float64)[0, :, :3, :3]
+    D = O.wigner_d_euler(2, R)
+    saved = {l: O.J_MATRICES[l] for l in (1, 2)}
+    try:
+        O.J_MATRICES[1], O.J_MATRICES[2] = flipped[1], flipped[2]
+        Df = O.wigner_d_euler(2, R)
+    finally:
+        O.J_MATRICES[1], O.J_MATRICES[2] = saved[1], saved[2]
+    assert (Df[1] - s1[:, None] * D[1] * s1[None]).abs().max() < 1e-12
+    assert (Df[2] - s2[:, None] * D[2] * s2[None]).abs().max() < 1e-12
+    with pytest.raises(ValueError):
+        checkpoint.check_j_convention([blob[0], torch.eye(3, dtype=torch.float64), blob[2]])
+    with pytest.raises(ValueError):
+        checkpoint.check_j_convention([blob[0], blob[1], blob[2].roll(1, 0)])
