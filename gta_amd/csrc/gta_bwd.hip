@@ -184,8 +184,18 @@ __global__ __launch_bounds__(256) void gta_bwd_prep_kernel(const GtaBwdParams p)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int n_qt = gridDim.x;
+    // work map as in gta_kv_prep_kernel: the H workgroups of one 64-row tile are consecutive on ONE XCD (L % 8), whose L2
+    // then serves the 128-B lines that neighbouring heads of the packed q / dout / out rows share
+    const int n_qt = (p.Tq + BN - 1) / BN;
+    int j, h, b;
+    {
+        const int L = blockIdx.x, x = L & 7, i = L >> 3;
+        const int r = x + 8 * (i / p.H);
+        h = i - (i / p.H) * p.H;
+        if (r >= p.B * n_qt) return;
+        b = r / n_qt;
+        j = r - b * n_qt;
+    }
     const int ch_real = p.dh >> 3, real_units = p.dh * ESZ / 16;
 
     const char* qg = (const char*)p.q + ((long)b * p.q_sb + (long)h * p.q_sh) * ESZ;
@@ -790,7 +800,9 @@ int run_bwd(const GtaBwdParams& p, hipStream_t stream) {
     if (int rc = gta_lds_optin<&gta_bwd_dq_kernel<DHP, ESZ>>(DqSmem<DHP>::total(GTA_MAX_VIEWS))) return rc;
     if (int rc = gta_lds_optin<&gta_bwd_dkv_kernel<DHP, ESZ>>(DkvSmem<DHP>::total(GTA_MAX_VIEWS))) return rc;
     constexpr int lds_prep = BPrepSmem<DHP, ESZ>::TOTAL;
-    hipLaunchKernelGGL((gta_bwd_prep_kernel<DHP, ESZ>), dim3(n_qt, p.H, p.B), dim3(256), lds_prep, stream, p);
+    const long prep_grid = ((long)p.B * n_qt + 7) / 8 * 8 * p.H;
+    if (prep_grid > 0x7fffffffL) return GTA_E_UNSUPPORTED;
+    hipLaunchKernelGGL((gta_bwd_prep_kernel<DHP, ESZ>), dim3((unsigned)prep_grid), dim3(256), lds_prep, stream, p);
     const int n_dq = p.B * p.H * ((p.Tq + 127) / 128);
     hipLaunchKernelGGL((gta_bwd_dq_kernel<DHP, ESZ>), dim3(n_dq), dim3(256), DqSmem<DHP>::total(p.vrep_q ? p.Nq : 0), stream, p);
     const int n_dkv = p.B * p.H * ((p.Tk + 127) / 128);
