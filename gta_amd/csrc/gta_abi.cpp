@@ -177,7 +177,9 @@ extern "C" int gta_attn_fwd(const GtaAttnDesc* d, const void* q, const void* k, 
 #endif
     const long n_wg = (long)d->B * d->H * p.n_qtiles;
     if (n_wg > 0x7fffffffL) return fail(GTA_E_UNSUPPORTED, "grid too large");
-    if (workspace && !(d->flags & GTA_FLAG_FUSED_KV) && !pre) {
+    if ((d->flags & GTA_FLAG_FP32_PRODUCTS) && d->dtype != GTA_DTYPE_F32)
+        return fail(GTA_E_BADARG, "GTA_FLAG_FP32_PRODUCTS is for fp32 inputs (bf16 inputs ask for bf16 arithmetic)");
+    if (workspace && !(d->flags & (GTA_FLAG_FUSED_KV | GTA_FLAG_FP32_PRODUCTS)) && !pre) {
         if (workspace_bytes < gta_fwd2_workspace_bytes(d->B, d->H, d->Tk, padded_dh(d->dh)))
             return fail(GTA_E_BADARG, "workspace smaller than gta_attn_fwd_workspace_bytes()");
         if (d->H > 65535 || d->B > 65535) return fail(GTA_E_UNSUPPORTED, "B or H above 65535");
@@ -313,7 +315,9 @@ extern "C" int gta_attn_fwd_plain(const GtaAttnDesc* d, const void* q, const voi
     p.o_sb = d->o_stride[0]; p.o_sh = d->o_stride[1]; p.o_st = d->o_stride[2];
     p.B = d->B; p.H = d->H; p.Tq = d->Tq; p.Tk = d->Tk; p.Nq = 1; p.Nk = 1; p.Pq = d->Tq; p.Pk = d->Tk;
     p.invPq = 1.0f / p.Pq; p.invPk = 1.0f / p.Pk;
-    p.dh = d->dh; p.nso2 = 0; p.n_qtiles = (d->Tq + 127) / 128; p.flags = 0; p.scale = d->scale;
+    p.dh = d->dh; p.nso2 = 0; p.n_qtiles = (d->Tq + 127) / 128; p.scale = d->scale;
+    p.flags = d->flags & GTA_FLAG_FP32_PRODUCTS;
+    if (p.flags && d->dtype != GTA_DTYPE_F32) return fail(GTA_E_BADARG, "GTA_FLAG_FP32_PRODUCTS is for fp32 inputs");
     const long n_wg = (long)d->B * d->H * p.n_qtiles;
     int rc = gta_fwd_dispatch(p, padded_dh(d->dh), esz, true, (int)n_wg, (hipStream_t)stream);
     if (rc) return fail(rc, rc == GTA_E_LAUNCH ? hipGetErrorString(hipGetLastError()) : "no kernel instance");

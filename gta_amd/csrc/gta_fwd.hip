@@ -21,6 +21,13 @@
 //   epilogue   O/l -> LDS (fp32) -> lane == row applies rho_q^-1 per chunk, stores out + LSE
 // Next K/V tile's DMA is in flight while the MFMAs of the current one run; two workgroups per CU
 // overlap one's VALU phases with the other's MFMA phases.
+//
+// X3 (GTA_FLAG_FP32_PRODUCTS, fp32 inputs): every operand of the two contractions is kept as a bf16 PAIR
+// (hi = bf16(x), lo = bf16(x - hi): 16 significant bits) and every product is three MFMAs, lo*hi + hi*lo + hi*hi
+// (the lo*lo term is below 2^-16 of the product).  The matrix cores have no fp32 input form at a usable rate
+// (v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 rate); the split costs 3x the MFMAs and twice the LDS tiles and gives
+// fp32-class results (measured against the fp64 oracle: see tests/test_gpu_precise.py) for the reference's
+// ``mixed_prec: False`` configs (runs/clevrtr/GTA/gta/config.yaml:55).
 #include "gta_common.h"
 #include "gta_fwd_params.h"
 #include "../../include/gta_hip.h"
@@ -33,27 +40,40 @@ constexpr int NTHREADS = 256;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
-template <int DHP, int ESZ>
+template <int DHP, int ESZ, bool X3 = false>
 struct Smem {
+    static constexpr int NPL = X3 ? 2 : 1;                 // bf16 planes per operand tile: hi (and lo)
     static constexpr int CHP = DHP / 8;                    // padded chunks per row
     static constexpr int RAW_UNITS = DHP * ESZ / 16;       // 16-B units per raw row
     static constexpr int REP_BYTES = GTA_MAX_VIEWS * (GTA_QREC + GTA_KREC) * 4;
     static constexpr int RAW_BYTES = BN * DHP * ESZ;       // one raw tile (K or V)
-    static constexpr int KF_BYTES = BN * DHP * 2;          // K' bf16 [64][DHP]
-    static constexpr int VT_BYTES = DHP * BN * 2;          // V'^T bf16 [DHP][64]
+    static constexpr int KF_BYTES = BN * DHP * 2;          // one plane of K' bf16 [64][DHP]
+    static constexpr int VT_BYTES = DHP * BN * 2;          // one plane of V'^T bf16 [DHP][64]
     static constexpr int OROW = DHP + 4;                   // padded fp32 row of the O staging tile
     static constexpr int OST_BYTES = BM * OROW * 4;
     static constexpr int OFF_REP = 0;
     static constexpr int OFF_RAWK = REP_BYTES;
     static constexpr int OFF_RAWV = OFF_RAWK + RAW_BYTES;
-    static constexpr int OFF_KF = OFF_RAWV + RAW_BYTES;
-    static constexpr int OFF_VT = OFF_KF + KF_BYTES;
-    static constexpr int TILE_END = OFF_VT + VT_BYTES;
-    static constexpr int OFF_QS = OFF_KF;                  // Q' staging aliases K'/V'^T (BM*DHP*2 == KF+VT)
+    static constexpr int OFF_KF = OFF_RAWV + RAW_BYTES;    // K' planes, then V'^T planes
+    static constexpr int OFF_VT = OFF_KF + NPL * KF_BYTES;
+    static constexpr int TILE_END = OFF_VT + NPL * VT_BYTES;
+    static constexpr int QS_PLANE = BM * DHP * 2;          // one plane of the Q' staging tile
+    static constexpr int OFF_QS = OFF_KF;                  // Q' staging aliases K'/V'^T (BM*DHP*2 == KF+VT per plane)
     static constexpr int OFF_OST = OFF_RAWK;               // O staging aliases raw + final tiles
     static constexpr int TOTAL = (OFF_OST + OST_BYTES > TILE_END) ? OFF_OST + OST_BYTES : TILE_END;
     static_assert(BM * DHP * 2 == KF_BYTES + VT_BYTES, "Q staging must fit the final tiles");
+    static_assert(TOTAL <= 160 * 1024, "LDS budget");
 };
+
+// x -> (hi, lo) bf16 planes: hi = bf16(x), lo = bf16(x - hi)
+GTA_DEV void split8(const float* x, u32x4_t& hi, u32x4_t& lo) {
+    hi = pack8(x);
+    float xh[8], r[8];
+    unpack8(hi, xh);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = x[i] - xh[i];
+    lo = pack8(r);
+}
 
 // ------------------------------------------------------------------------------------------
 // global <-> register helpers for one 8-channel chunk
@@ -132,10 +152,11 @@ GTA_DEV void stage_raw_tile(char* smem_raw, const char* gbase, long row_stride_b
 // ------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------
-template <int DHP, int ESZ, bool DMA>
-__global__ __launch_bounds__(NTHREADS, (DHP <= 96 ? 2 : 1)) void gta_fwd_kernel(const GtaFwdParams p) {
-    using S = Smem<DHP, ESZ>;
+template <int DHP, int ESZ, bool DMA, bool X3 = false>
+__global__ __launch_bounds__(NTHREADS, ((DHP <= 96 && !X3) ? 2 : 1)) void gta_fwd_kernel(const GtaFwdParams p) {
+    using S = Smem<DHP, ESZ, X3>;
     constexpr int CHP = S::CHP;
+    constexpr int NPL = S::NPL;
     constexpr int KS = DHP / 16;   // MFMA k-steps of Q K^T
     constexpr int DB = DHP / 32;   // 32-channel blocks of O^T
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -253,17 +274,26 @@ __global__ __launch_bounds__(NTHREADS, (DHP <= 96 ? 2 : 1)) void gta_fwd_kernel(
 #pragma unroll
                 for (int i = 0; i < 8; ++i) x[0][i] = 0.f;
             }
-            *reinterpret_cast<u32x4_t*>(qs + (r * CHP + swz<CHP>(r, c)) * 16) = pack8(x[0]);
+            if constexpr (X3) {
+                u32x4_t hi, lo;
+                split8(x[0], hi, lo);
+                *reinterpret_cast<u32x4_t*>(qs + (r * CHP + swz<CHP>(r, c)) * 16) = hi;
+                *reinterpret_cast<u32x4_t*>(qs + S::QS_PLANE + (r * CHP + swz<CHP>(r, c)) * 16) = lo;
+            } else {
+                *reinterpret_cast<u32x4_t*>(qs + (r * CHP + swz<CHP>(r, c)) * 16) = pack8(x[0]);
+            }
         }
     }
     __syncthreads();
-    bf16x8_t qf[KS];
+    bf16x8_t qf[NPL][KS];
     {
         const char* qs = smem + S::OFF_QS;
         const int r = wave * 32 + l31;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            qf[ks] = *reinterpret_cast<const bf16x8_t*>(qs + (r * CHP + swz<CHP>(r, 2 * ks + lh)) * 16);
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                qf[pl][ks] = *reinterpret_cast<const bf16x8_t*>(qs + pl * S::QS_PLANE + (r * CHP + swz<CHP>(r, 2 * ks + lh)) * 16);
     }
     // (the barrier at the top of the first loop iteration orders these reads before the first
     //  transform overwrites the aliased K'/V'^T region)
@@ -316,14 +346,19 @@ __global__ __launch_bounds__(NTHREADS, (DHP <= 96 ? 2 : 1)) void gta_fwd_kernel(
 #pragma unroll
                     for (int i = 0; i < 8; ++i) { x[0][i] = 0.f; x[1][i] = 0.f; }
                 }
-                *reinterpret_cast<u32x4_t*>(kf + (r * CHP + swz<CHP>(r, c)) * 16) = pack8(x[0]);
-                const u32x4_t wv = pack8(x[1]);
-                const uint32_t wvv[4] = {wv.x, wv.y, wv.z, wv.w};
+                u32x4_t kpl[2], vpl[2];
+                if constexpr (X3) { split8(x[0], kpl[0], kpl[1]); split8(x[1], vpl[0], vpl[1]); }
+                else { kpl[0] = pack8(x[0]); vpl[0] = pack8(x[1]); }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int d = 8 * c + i;
-                    const uint16_t hv = (uint16_t)((i & 1) ? (wvv[i >> 1] >> 16) : (wvv[i >> 1] & 0xffffu));
-                    *reinterpret_cast<uint16_t*>(vt + d * 128 + swz<8>(d, pos >> 3) * 16 + (pos & 7) * 2) = hv;
+                for (int pl = 0; pl < NPL; ++pl) {
+                    *reinterpret_cast<u32x4_t*>(kf + pl * S::KF_BYTES + (r * CHP + swz<CHP>(r, c)) * 16) = kpl[pl];
+                    const uint32_t wvv[4] = {vpl[pl].x, vpl[pl].y, vpl[pl].z, vpl[pl].w};
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int d = 8 * c + i;
+                        const uint16_t hv = (uint16_t)((i & 1) ? (wvv[i >> 1] >> 16) : (wvv[i >> 1] & 0xffffu));
+                        *reinterpret_cast<uint16_t*>(vt + pl * S::VT_BYTES + d * 128 + swz<8>(d, pos >> 3) * 16 + (pos & 7) * 2) = hv;
+                    }
                 }
             }
         }
@@ -346,8 +381,16 @@ __global__ __launch_bounds__(NTHREADS, (DHP <= 96 ? 2 : 1)) void gta_fwd_kernel(
                 const int u = 2 * ks + lh;
                 const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(kf + (l31 * CHP + swz<CHP>(l31, u)) * 16);
                 const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(kf + ((32 + l31) * CHP + swz<CHP>(32 + l31, u)) * 16);
-                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[ks], s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[ks], s1, 0, 0, 0);
+                if constexpr (X3) {      // small terms first: lo*hi + hi*lo + hi*hi
+                    const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(kf + S::KF_BYTES + (l31 * CHP + swz<CHP>(l31, u)) * 16);
+                    const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(kf + S::KF_BYTES + ((32 + l31) * CHP + swz<CHP>(32 + l31, u)) * 16);
+                    s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, qf[0][ks], s0, 0, 0, 0);
+                    s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, qf[0][ks], s1, 0, 0, 0);
+                    s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[NPL - 1][ks], s0, 0, 0, 0);
+                    s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[NPL - 1][ks], s1, 0, 0, 0);
+                }
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[0][ks], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[0][ks], s1, 0, 0, 0);
             }
         }
         if (p.kbias) {     // additive per-key bias (euclid: -scale |k'|^2 / 2), given before the temperature
@@ -394,21 +437,28 @@ __global__ __launch_bounds__(NTHREADS, (DHP <= 96 ? 2 : 1)) void gta_fwd_kernel(
             for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
 
         // P fragments: k-slot e of slab (kb,t) == accumulator register 8t+e (see header comment)
-        bf16x8_t pf[2][2];
+        bf16x8_t pf[NPL][2][2];
         {
-            u32x4_t w;
-            w.x = pack_bf16x2(s0[0], s0[1]); w.y = pack_bf16x2(s0[2], s0[3]);
-            w.z = pack_bf16x2(s0[4], s0[5]); w.w = pack_bf16x2(s0[6], s0[7]);
-            pf[0][0] = __builtin_bit_cast(bf16x8_t, w);
-            w.x = pack_bf16x2(s0[8], s0[9]); w.y = pack_bf16x2(s0[10], s0[11]);
-            w.z = pack_bf16x2(s0[12], s0[13]); w.w = pack_bf16x2(s0[14], s0[15]);
-            pf[0][1] = __builtin_bit_cast(bf16x8_t, w);
-            w.x = pack_bf16x2(s1[0], s1[1]); w.y = pack_bf16x2(s1[2], s1[3]);
-            w.z = pack_bf16x2(s1[4], s1[5]); w.w = pack_bf16x2(s1[6], s1[7]);
-            pf[1][0] = __builtin_bit_cast(bf16x8_t, w);
-            w.x = pack_bf16x2(s1[8], s1[9]); w.y = pack_bf16x2(s1[10], s1[11]);
-            w.z = pack_bf16x2(s1[12], s1[13]); w.w = pack_bf16x2(s1[14], s1[15]);
-            pf[1][1] = __builtin_bit_cast(bf16x8_t, w);
+            auto frag = [](const f32x16_t& sv, int t8) {
+                u32x4_t w;
+                w.x = pack_bf16x2(sv[t8 + 0], sv[t8 + 1]); w.y = pack_bf16x2(sv[t8 + 2], sv[t8 + 3]);
+                w.z = pack_bf16x2(sv[t8 + 4], sv[t8 + 5]); w.w = pack_bf16x2(sv[t8 + 6], sv[t8 + 7]);
+                return w;
+            };
+            const u32x4_t h00 = frag(s0, 0), h01 = frag(s0, 8), h10 = frag(s1, 0), h11 = frag(s1, 8);
+            pf[0][0][0] = __builtin_bit_cast(bf16x8_t, h00); pf[0][0][1] = __builtin_bit_cast(bf16x8_t, h01);
+            pf[0][1][0] = __builtin_bit_cast(bf16x8_t, h10); pf[0][1][1] = __builtin_bit_cast(bf16x8_t, h11);
+            if constexpr (X3) {
+                auto resid = [](f32x16_t& sv, const u32x4_t& h, int t8) {          // sv[t8..t8+7] -= float(hi)
+                    float xh[8];
+                    unpack8(h, xh);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) sv[t8 + i] -= xh[i];
+                };
+                resid(s0, h00, 0); resid(s0, h01, 8); resid(s1, h10, 0); resid(s1, h11, 8);
+                pf[NPL - 1][0][0] = __builtin_bit_cast(bf16x8_t, frag(s0, 0)); pf[NPL - 1][0][1] = __builtin_bit_cast(bf16x8_t, frag(s0, 8));
+                pf[NPL - 1][1][0] = __builtin_bit_cast(bf16x8_t, frag(s1, 0)); pf[NPL - 1][1][1] = __builtin_bit_cast(bf16x8_t, frag(s1, 8));
+            }
         }
 
         // ---- O^T += V'^T P^T ----
@@ -423,7 +473,13 @@ __global__ __launch_bounds__(NTHREADS, (DHP <= 96 ? 2 : 1)) void gta_fwd_kernel(
                     for (int t = 0; t < 2; ++t) {
                         const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(
                             vt + row * 128 + swz<8>(row, 4 * kb + 2 * t + lh) * 16);
-                        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf[kb][t], oacc[d], 0, 0, 0);
+                        if constexpr (X3) {
+                            const bf16x8_t al = *reinterpret_cast<const bf16x8_t*>(
+                                vt + S::VT_BYTES + row * 128 + swz<8>(row, 4 * kb + 2 * t + lh) * 16);
+                            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, pf[0][kb][t], oacc[d], 0, 0, 0);
+                            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf[NPL - 1][kb][t], oacc[d], 0, 0, 0);
+                        }
+                        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf[0][kb][t], oacc[d], 0, 0, 0);
                     }
             }
         }
@@ -479,11 +535,11 @@ __global__ __launch_bounds__(NTHREADS, (DHP <= 96 ? 2 : 1)) void gta_fwd_kernel(
     }
 }
 
-template <int DHP, int ESZ, bool DMA>
+template <int DHP, int ESZ, bool DMA, bool X3 = false>
 int launch(const GtaFwdParams& p, int n_wg, hipStream_t stream) {
-    using S = Smem<DHP, ESZ>;
-    if (int rc = gta_lds_optin<&gta_fwd_kernel<DHP, ESZ, DMA>>(S::TOTAL)) return rc;
-    hipLaunchKernelGGL((gta_fwd_kernel<DHP, ESZ, DMA>), dim3(n_wg), dim3(NTHREADS), S::TOTAL, stream, p);
+    using S = Smem<DHP, ESZ, X3>;
+    if (int rc = gta_lds_optin<&gta_fwd_kernel<DHP, ESZ, DMA, X3>>(S::TOTAL)) return rc;
+    hipLaunchKernelGGL((gta_fwd_kernel<DHP, ESZ, DMA, X3>), dim3(n_wg), dim3(NTHREADS), S::TOTAL, stream, p);
     return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH;
 }
 
@@ -503,8 +559,11 @@ int gta_fwd_lds_bytes(int dhp, int esz) {
 }
 
 int gta_fwd_dispatch(const GtaFwdParams& p, int dhp, int esz, bool dma, int n_wg, hipStream_t stream) {
+    const bool x3 = (p.flags & GTA_FLAG_FP32_PRODUCTS) != 0;
+    if (x3 && esz != 4) return GTA_E_UNSUPPORTED;      // (the split serves fp32 inputs; bf16 inputs are bf16 arithmetic by request)
 #define GTA_CASE(D)                                                                       \
     case D:                                                                               \
+        if (x3) return launch<D, 4, true, true>(p, n_wg, stream);                         \
         if (esz == 2) return dma ? launch<D, 2, true>(p, n_wg, stream) : launch<D, 2, false>(p, n_wg, stream); \
         else          return dma ? launch<D, 4, true>(p, n_wg, stream) : launch<D, 4, false>(p, n_wg, stream);
     switch (dhp) {

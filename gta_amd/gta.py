@@ -238,7 +238,7 @@ class _GenericAttn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v, trans_coeff, tau, cfg, packed):
-        f_dims, so3_degree, scale, v_transform, euclid = cfg
+        f_dims, so3_degree, scale, v_transform, euclid, precise = cfg
         dt = q.dtype
         if dt not in (torch.float32, torch.bfloat16):
             raise native.GtaError(f"unsupported dtype {dt}")
@@ -265,7 +265,7 @@ class _GenericAttn(torch.autograd.Function):
             native.rep_apply(desc, 1, v, vk, packed.get("cs_k"), packed.get("coord_k"), tc, vp[..., :dh])
         else:
             vp[..., :dh] = v
-        pdesc = native.make_desc(qp, kp, vp, op, {"triv": dhp}, 0, 1, 1, scale, 0)
+        pdesc = native.make_desc(qp, kp, vp, op, {"triv": dhp}, 0, 1, 1, scale, native.FLAG_FP32_PRODUCTS if precise else 0)
         lse = torch.empty(B, H, Tq, device=q.device, dtype=torch.float32)
         native.attn_fwd_plain(pdesc, qp, kp, vp, kbias, ta, op, lse)
         if v_transform:
@@ -282,7 +282,7 @@ class _GenericAttn(torch.autograd.Function):
     def backward(ctx, dout):
         from . import backward as _bw
         q, k, v, qp, kp, vp, op, lse, tc, ta = ctx.saved_tensors
-        f_dims, so3_degree, scale, v_transform, euclid = ctx.cfg
+        f_dims, so3_degree, scale, v_transform, euclid, _precise = ctx.cfg
         packed = ctx.packed
         want_dtau = ta is not None and ctx.needs_input_grad[4]
         dt = q.dtype
@@ -352,22 +352,31 @@ class _GenericAttn(torch.autograd.Function):
         return dq, dk, dv, dtc, dta, None, None
 
 
-def _generic_forward(q, k, v, f_dims, packed, so3_degree, trans_coeff, tau, scale, v_transform, euclid):
+def _generic_forward(q, k, v, f_dims, packed, so3_degree, trans_coeff, tau, scale, v_transform, euclid, precise=False):
     """Generic path entry (forward + backward through _GenericAttn)."""
     tc = trans_coeff if torch.is_tensor(trans_coeff) else None
     ta = tau if torch.is_tensor(tau) else None
-    return _GenericAttn.apply(q, k, v, tc, ta, (f_dims, so3_degree, scale, v_transform, euclid), packed)
+    return _GenericAttn.apply(q, k, v, tc, ta, (f_dims, so3_degree, scale, v_transform, euclid, precise), packed)
+
+
+# Module-level default of ``gta_attention(precise=None)``: True makes every float32 call use the split-bf16 products
+# (GTA_FLAG_FP32_PRODUCTS) -- the setting for the reference's ``mixed_prec: False`` configs (runs/clevrtr/GTA/gta).
+PRECISE_FP32 = False
 
 
 def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: int = 0,
                   trans_coeff=None, tau=None, scale: Optional[float] = None, v_transform: bool = True,
                   euclid: bool = False, pretransformed: bool = False, use_dma: bool = True,
-                  kv_mode: str = "auto", kv_cache: Optional[dict] = None) -> torch.Tensor:
+                  kv_mode: str = "auto", kv_cache: Optional[dict] = None, precise: Optional[bool] = None) -> torch.Tensor:
     """Fused GTA attention on packed reps.  q [B,H,Tq,dh], k/v [B,H,Tk,dh] -> out [B,H,Tq,dh].
 
     kv_mode: 'prepass' = K/V rep pre-pass + lean attention kernel (two launches);
              'fused'   = one kernel, rho_k applied inside the attention loop;
              'auto'    = 'prepass' when several query tiles share each key tile, else 'fused'.
+    precise: float32 inputs only.  False (default unless ``gta.PRECISE_FP32``): operands are rounded to bf16 once, after
+             rho, and the two contractions run on the bf16 MFMA (fp32 accumulation) -- the reference's bf16-autocast
+             accuracy.  True: operands are kept as bf16 hi+lo pairs and every product is three MFMAs -- fp32-class results
+             (max |error| ~1e-5 of max |out|) at 3x the matrix work, single-kernel plan; the backward stays bf16-product.
     kv_cache: a dict owned by the caller (inference only).  The first call stores the K'/V' tile images of the
              pre-pass in it; later calls with the same keys, reps and trans_coeff (e.g. the next query chunk of a
              full-image decode, trainer.py:137-181) stream them again without re-running the pre-pass."""
@@ -387,6 +396,15 @@ def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: 
         kv_mode = "prepass"
     if kv_mode not in ("auto", "prepass", "fused"):
         raise ValueError(f"kv_mode {kv_mode!r}")
+    if precise is None:
+        precise = PRECISE_FP32 and q.dtype == torch.float32
+    if precise:
+        if q.dtype != torch.float32:
+            raise native.GtaError("precise=True is for float32 inputs (bf16 inputs ask for bf16 arithmetic)")
+        if kv_cache is not None:
+            raise native.GtaError("precise=True runs the single-kernel plan: no kv_cache")
+        flags |= native.FLAG_FP32_PRODUCTS
+        kv_mode = "fused"
     if kv_cache is not None:
         if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in (q, k, v, trans_coeff)):
             raise native.GtaError("kv_cache is an inference feature: call under torch.no_grad()")
@@ -403,7 +421,8 @@ def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: 
     if q.is_cuda and not pretransformed:
         probe = native.make_desc(q, k, v, q, f_dims, so3_degree, Nq, Nk, scale, flags)
         if native.attn_fwd_supported(probe) == -3:       # GTA_E_UNSUPPORTED: valid request, no fused kernel
-            return _generic_forward(q, k, v, f_dims, packed, so3_degree, trans_coeff, tau, scale, v_transform, euclid)
+            return _generic_forward(q, k, v, f_dims, packed, so3_degree, trans_coeff, tau, scale, v_transform, euclid,
+                                    precise=bool(precise))
     cfg = ({k_: int(v_) for k_, v_ in f_dims.items()}, int(so3_degree), Nq, Nk, float(scale), flags)
     return _GtaAttn.apply(q, k, v, trans_coeff, tau, kv_cache, cfg, packed.get("vrep_q"), packed.get("vrep_k"),
                           packed.get("cs_q"), packed.get("cs_k"))
@@ -458,7 +477,8 @@ def multihead_geometric_transform_attention(q, k, v, attn_fn=None, f_dims=None, 
         trans_coeff = None
     out = gta_attention(q, k, v, f_dims, packed, so3_degree=_so3_degree(f_dims, packed, reps),
                         trans_coeff=trans_coeff, tau=tau, scale=scale, v_transform=v_transform, euclid=euclid,
-                        use_dma=kwargs.get("use_dma", True), kv_mode=kwargs.get("kv_mode", "auto"))
+                        use_dma=kwargs.get("use_dma", True), kv_mode=kwargs.get("kv_mode", "auto"),
+                        precise=kwargs.get("precise"))
     return out, None
 
 
