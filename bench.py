@@ -131,9 +131,10 @@ def dry_run(args):
     for _ in range(args.steps):
         x += 1
         time.sleep(0.001 * (1 + rank))
+    mine = time.perf_counter() - t0                        # this rank's own loop (before it waits for the others)
     if dist is not None:
         dist.barrier()
-    elapsed = mine = time.perf_counter() - t0
+    elapsed = time.perf_counter() - t0
     per_rank = [mine / args.steps * 1e3]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -247,10 +248,11 @@ def main():
         step(i)
     t_host = time.perf_counter() - t0                      # (host side of the loop: how far ahead of the GPU it runs)
     torch.cuda.synchronize()
+    mine = time.perf_counter() - t0                        # this rank's own K steps (before it waits for the others)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    elapsed = mine = time.perf_counter() - t0
+    elapsed = time.perf_counter() - t0
     per_rank = [mine / args.steps * 1e3]
     if dist is not None:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
