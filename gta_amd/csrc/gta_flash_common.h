@@ -152,11 +152,15 @@ GTA_DEV void qrec_seg_load(QrecItem& q, const float* vrep_q, int b, int Nq, int 
     q.dst = n * GTA_QREC + e;
     q.val = base[(long)n * GTA_VREP_STRIDE + src];
 }
-GTA_DEV void qrec_seg_store(const QrecItem& q, float* qrec, float tc) {
+// fwd_scale multiplies the matrices that act on Q (Aq, D1q, D2q: record offsets below GTA_QREC_O, and D1 / D2), not the
+// output-side ones (Oq, D1q^T, D2q^T): the attention kernel folds its scale * log2(e) / tau there.
+GTA_DEV void qrec_seg_store(const QrecItem& q, float* qrec, float tc, float fwd_scale = 1.0f) {
     if (q.dst < 0) return;
     float v = q.val;
     if (q.kind == 0) v *= (q.rr == 3) ? (q.cc == 3 ? 1.f : 0.f) : (q.cc == 3 ? tc : 1.f);
     else if (q.kind == 2) v = 0.f;
+    const int e = q.dst % GTA_QREC;
+    if (e < GTA_QREC_O || (e >= GTA_QREC_D1 && e < GTA_QREC_D1T)) v *= fwd_scale;
     qrec[q.dst] = v;
 }
 // items a wave's segment list holds for cnt views

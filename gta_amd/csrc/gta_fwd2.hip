@@ -68,20 +68,48 @@ struct Smem2 {
     __host__ __device__ static int total(int nrec) { return RING_BYTES + 2 * nrec * GTA_QREC * 4; }
 };
 
-// issue the LDS-DMA of one K'/V' tile image pair (STAGE bytes, linear) into ring stage `st`
+// issue the LDS-DMA of one K'/V' tile image pair (STAGE bytes, linear) into ring stage `st`: each wave moves PER_WAVE
+// consecutive KiB.  Written as asm in the scalar-base form -- global address = SGPR pair + 32-bit lane offset + immediate,
+// LDS address = M0 + the same immediate + 16 * lane -- so a group of four pieces needs ONE s_mov to M0 and no vector
+// arithmetic at all; through the builtin hipcc forms a 64-bit per-lane address and a new M0 for every piece (17 VALU
+// instructions per tile and wave in a loop whose issue slots are the scarce resource).  The compiler does not see these
+// as memory operations: every consumer sits behind an explicit s_waitcnt vmcnt + barrier (as with the builtin).
+template <int NP>
+GTA_DEV void dma_group(uint32_t lds, const char* base, unsigned voff) {
+    static_assert(NP >= 1 && NP <= 4, "13-bit immediates: four 1-KiB pieces per base");
+    if constexpr (NP == 1)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(voff), "s"(base) : "memory");
+    else if constexpr (NP == 2)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024"
+                     ::"s"(lds), "v"(voff), "s"(base) : "memory");
+    else if constexpr (NP == 3)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:2048" ::"s"(lds), "v"(voff), "s"(base) : "memory");
+    else
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072"
+                     ::"s"(lds), "v"(voff), "s"(base) : "memory");
+}
 template <int DHP>
 GTA_DEV void dma_stage(char* ring, int st, const char* img, int wave, int lane) {
     using S = Smem2<DHP>;
     constexpr int PIECES = S::STAGE / 1024;             // 1 KiB per wave-instruction
     constexpr int PER_WAVE = PIECES / 4;
     static_assert(PIECES % 4 == 0, "stage must split evenly over the waves");
+    const unsigned voff = (unsigned)lane * 16u;
+    const char* base = img + wave * (PER_WAVE * 1024);
+    const uint32_t lds = lds_addr(ring + st * S::STAGE + wave * (PER_WAVE * 1024));
+#ifdef GTA_DMA_BUILTIN
 #pragma unroll
-    for (int i = 0; i < PER_WAVE; ++i) {
-        const int piece = wave * PER_WAVE + i;
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(img + piece * 1024 + lane * 16),
-            (__attribute__((address_space(3))) void*)(ring + st * S::STAGE + piece * 1024), 16, 0, 0);
-    }
+    for (int i = 0; i < PER_WAVE; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + i * 1024 + voff),
+                                         (__attribute__((address_space(3))) void*)(ring + st * S::STAGE + (wave * PER_WAVE + i) * 1024), 16, 0, 0);
+#else
+    static_for<(PER_WAVE + 3) / 4>([&](auto GC) {
+        constexpr int g = decltype(GC)::value, np = PER_WAVE - 4 * g < 4 ? PER_WAVE - 4 * g : 4;
+        dma_group<np>(lds + g * 4096, base + g * 4096, voff);
+    });
+#endif
 }
 
 // Full path of the lazy softmax (tile 0, masked tail, violated bound): true row max of S' (= S - m_run), move
@@ -298,11 +326,12 @@ __global__ __launch_bounds__(256, (DHP <= 64 ? 3 : 2)) void gta_fwd2_kernel(cons
     float* qrec = reinterpret_cast<float*>(smem + S::OFF_QREC) + par * pp->nrec * GTA_QREC;
     // ---- prologue, second half: view records -> LDS (this item's buffer), rho_q on the lane's chunks -> qf ----
     if (pp->vrep_q) {
-        qrec_seg_store(rb0, qrec, tc);
+        const float rs = qscale;          // (the matrices that act on Q carry the score scale: see q_xform)
+        qrec_seg_store(rb0, qrec, tc, rs);
         for (int idx = lane + 64; idx < qrec_seg_count(wave, n_cnt); idx += 64) {       // (more than one view per tile only)
             QrecItem it;
             qrec_seg_load(it, pp->vrep_q, b, pp->Nq, n_first, n_cnt, wave, idx);
-            qrec_seg_store(it, qrec, tc);
+            qrec_seg_store(it, qrec, tc, rs);
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -329,23 +358,33 @@ __global__ __launch_bounds__(256, (DHP <= 64 ? 3 : 2)) void gta_fwd2_kernel(cons
                         }
                     }
                     if (GTA_DL(ks)) chunk_apply<false, 1>(GTA_DL(ks), rec_q + GTA_QREC_A, rec_q + GTA_QREC_D1, rec_q + GTA_QREC_D2, qcs[ks], x);
+                    // (the q-side matrices were staged pre-multiplied by qscale: only identity / so2 halves still need it)
+                    {
+                        const uint32_t dl = GTA_DL(ks);
+                        const bool m_lo = (dl & GTA_CHUNK_SO3) || cd_lo(dl) == GTA_HALF_SE3, m_hi = (dl & GTA_CHUNK_SO3) || cd_hi(dl) == GTA_HALF_SE3;
+                        if (!m_lo) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) x[0][i] *= qscale;
+                            for (int i = 0; i < 4; ++i) x[0][i] *= qscale;
+                        }
+                        if (!m_hi) {
+#pragma unroll
+                            for (int i = 4; i < 8; ++i) x[0][i] *= qscale;
+                        }
+                    }
                 } else {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) x[0][i] = 0.f;
                 }
                 const u32x4_t qw = pack8(x[0]);
                 qf[ks] = __builtin_bit_cast(bf16x8_t, qw);
-                float qr[8];
-                unpack8(qw, qr);
+                // |q'|^2 from the fp32 values; rounding to bf16 moves a value by at most 2^-8 of itself (covered by the factor below)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) qsq += qr[i] * qr[i];
+                for (int i = 0; i < 8; ++i) qsq += x[0][i] * x[0][i];
             }
         };
         if (full) q_xform(std::true_type{}); else q_xform(std::false_type{});
         qsq += __shfl_xor(qsq, 32);                                          // the row's other chunk parity
-        qn = sqrtf(qsq) * 1.0001f;
+        qn = sqrtf(qsq) * 1.0041f;
     }
     GTA_STAMP(V, 2);
 
@@ -361,10 +400,11 @@ __global__ __launch_bounds__(256, (DHP <= 64 ? 3 : 2)) void gta_fwd2_kernel(cons
 #pragma unroll
         for (int d = 0; d < DB; ++d) {
             const int u = 4 * d + 2 * (g16 & 1) + ((p16 & 3) >> 1);
+            const int hb = (p16 & 1) * 8;
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 const int r = 4 * (lane_i >> 5) + (p16 >> 2) + 8 * hf;
-                voff[d][hf] = (r * CHP + swz<CHP>(r, u)) * 16 + (p16 & 1) * 8;
+                voff[d][hf] = (r * CHP + swz<CHP>(r, u)) * 16 + hb;
             }
         }
     }
@@ -616,22 +656,24 @@ __global__ __launch_bounds__(256, (DHP <= 64 ? 3 : 2)) void gta_fwd2_kernel(cons
         for (int i = 0; i < 4; ++i) ocs[kp][i] = f32x2_t{1.f, 0.f};
     const bool fast = full && q0 + BM <= pp->Tq;          // no ragged channel, no ragged row: no per-lane guards
     const float* csrow_o = (xo && pp->cs_q) ? pp->cs_q + ((long)b * pp->Tq + tC) * 2 * pp->nso2 : nullptr;
+#define GTA_CE(kp) (2 * (kp) + lh)
+#define GTA_DLE(kp) GTA_DL(kp)
     if (csrow_o) {
 #pragma unroll
         for (int kp = 0; kp < NP; ++kp)
-            if (fast || 2 * kp + lh < ch_real) load_cs(GTA_DL(kp), csrow_o, ocs[kp]);
+            if (fast || GTA_CE(kp) < ch_real) load_cs(GTA_DLE(kp), csrow_o, ocs[kp]);
     }
     GTA_STAMP(V, 7);
     if (pp->lse && lh == 0 && rowok) pp->lse[((long)b * pp->H + h) * pp->Tq + tE] = (m_run + __log2f(l_tot)) * LN2;
     {
         const float* rec_o = qrec + (view_of(tC, pp->Pq, pp->invPq) - n_first) * GTA_QREC;
-        char* orow = (char*)pp->o + ((long)b * pp->o_sb + (long)h * pp->o_sh + (long)tC * pp->o_st) * ESZ + lh * 8 * ESZ;   // chunk 2kp + lh goes to + kp * 16 * ESZ
+        char* orow = (char*)pp->o + ((long)b * pp->o_sb + (long)h * pp->o_sh + (long)tC * pp->o_st) * ESZ;
         auto o_items = [&](auto FASTC) {
             constexpr bool FAST = decltype(FASTC)::value;
 #pragma unroll
             for (int kp = 0; kp < NP; ++kp) {
-                const int d = (2 * kp) >> 2, ge = (2 * kp) & 3;
                 float x[1][8];
+                const int d = (2 * kp) >> 2, ge = (2 * kp) & 3;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const uint32_t ua = __float_as_uint(oacc[d][4 * ge + i] * inv_l);         // half lh of the even chunk
@@ -640,15 +682,17 @@ __global__ __launch_bounds__(256, (DHP <= 64 ? 3 : 2)) void gta_fwd2_kernel(cons
                     x[0][i] = __uint_as_float(sw[0]);
                     x[0][4 + i] = __uint_as_float(sw[1]);
                 }
-                if (FAST || (rowok && 2 * kp + lh < ch_real)) {
-                    if (xo && GTA_DL(kp)) chunk_apply<true, 1>(GTA_DL(kp), rec_o + GTA_QREC_O, rec_o + GTA_QREC_D1T, rec_o + GTA_QREC_D2T, ocs[kp], x);
-                    gstore_chunk2<ESZ>(orow + kp * 16 * ESZ, 0, x[0]);
+                if (FAST || (rowok && GTA_CE(kp) < ch_real)) {
+                    if (xo && GTA_DLE(kp)) chunk_apply<true, 1>(GTA_DLE(kp), rec_o + GTA_QREC_O, rec_o + GTA_QREC_D1T, rec_o + GTA_QREC_D2T, ocs[kp], x);
+                    gstore_chunk2<ESZ>(orow + GTA_CE(kp) * 8 * ESZ, 0, x[0]);
                 }
             }
         };
         if (fast) o_items(std::true_type{}); else o_items(std::false_type{});
     }
     }
+#undef GTA_CE
+#undef GTA_DLE
     GTA_STAMP(V, 4); GTA_STAMPR(V, 6);
     par ^= 1;
     }
@@ -679,8 +723,7 @@ int launch_fwd2(const GtaFwdParams& p, hipStream_t stream) {
 #ifdef GTA_ABLATE
     if (const char* e = getenv("GTA_LDS_PAD")) {        // occupancy experiment: inflate LDS so fewer workgroups share a CU
         lds += atoi(e);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gta_fwd2_kernel<DHP, ESZ, LAYOUT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     }
     if (const char* e = getenv("GTA_GRID")) { const long g = atol(e); if (g > 0) grid = g < p.n_items ? g : p.n_items; }
 #endif

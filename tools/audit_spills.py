@@ -22,7 +22,7 @@ def audit():
     src = os.path.join(ROOT, "gta_amd", "csrc", "gta_fwd2.hip")
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "fwd2.s")
-        subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-S",
+        subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-fno-slp-vectorize", "-S",
                         "--cuda-device-only", "-o", out, src], check=True, stderr=subprocess.DEVNULL)
         text = open(out).read()
     report, problems = [], []

@@ -209,7 +209,8 @@ if __name__ == "__main__":
         raw_call(q, k, v, packed, FD, L, VT, ws)[0]()
         nwg = B * H_ * ((Nv * Pv + 127) // 128)
         for rnd in range(2):
-          for label, extra in (("one workgroup per tile", 0), ("persistent grid", native.FLAG_PERSIST)):
+          for label, extra in ((("one workgroup per tile", 0),) if os.environ.get("GTA_TL_DEFAULT_ONLY") else
+                               (("one workgroup per tile", 0), ("persistent grid", native.FLAG_PERSIST))):
             fn, _ = raw_call(q, k, v, packed, FD, L, VT | native.FLAG_KV_READY | extra, ws)
             for _ in range(3):
                 fn()
