@@ -300,6 +300,7 @@ struct DqSmem {
 
 template <int BYTES>
 GTA_DEV void dma_linear4(char* dst, const char* src, int wave, int lane) {     // 4 waves, 1 KiB pieces
+#ifdef GTA_DMA_BUILTIN
     constexpr int PER_WAVE = BYTES / 1024 / 4;
     static_assert(BYTES % 4096 == 0, "piece split");
 #pragma unroll
@@ -308,6 +309,9 @@ GTA_DEV void dma_linear4(char* dst, const char* src, int wave, int lane) {     /
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024 + lane * 16),
                                          (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
     }
+#else
+    dma_linear_4waves<BYTES>(dst, src, wave, lane);      // scalar-base asm form (gta_common.h): no per-piece vector arithmetic
+#endif
 }
 
 template <int DHP, int ESZ>

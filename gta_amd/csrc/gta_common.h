@@ -25,6 +25,14 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
 
 #define GTA_DEV __device__ __forceinline__
 
+#include <type_traits>
+#include <utility>
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{})
+template <class F, int... Is>
+GTA_DEV void gta_static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+GTA_DEV void gta_static_for(F&& f) { gta_static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
+
 // ---- chunk descriptor -----------------------------------------------------------------------
 #define GTA_HALF_ID  0u
 #define GTA_HALF_SE3 1u
@@ -206,6 +214,42 @@ GTA_DEV int view_of(int t, int P, float invP) {
     if (n * P > t) --n;
     if ((n + 1) * P <= t) ++n;
     return n;
+}
+
+// LDS-DMA of consecutive 1-KiB pieces (global -> LDS, 16 B per lane).  Written as asm in the scalar-base form -- global address = SGPR pair + 32-bit lane offset + immediate,
+// LDS address = M0 + the same immediate + 16 * lane -- so a group of four pieces needs ONE s_mov to M0 and no vector
+// arithmetic at all; through the builtin hipcc forms a 64-bit per-lane address and a new M0 for every piece (17 VALU
+// instructions per tile and wave in a loop whose issue slots are the scarce resource).  The compiler does not see these
+// as memory operations: every consumer sits behind an explicit s_waitcnt vmcnt + barrier (as with the builtin).
+template <int NP>
+GTA_DEV void dma_group(uint32_t lds, const char* base, unsigned voff) {
+    static_assert(NP >= 1 && NP <= 4, "13-bit immediates: four 1-KiB pieces per base");
+    if constexpr (NP == 1)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(voff), "s"(base) : "memory");
+    else if constexpr (NP == 2)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024"
+                     ::"s"(lds), "v"(voff), "s"(base) : "memory");
+    else if constexpr (NP == 3)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:2048" ::"s"(lds), "v"(voff), "s"(base) : "memory");
+    else
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072"
+                     ::"s"(lds), "v"(voff), "s"(base) : "memory");
+}
+
+// `bytes` consecutive bytes (a multiple of 4 KiB) split over the 4 waves of a 256-thread workgroup
+template <int BYTES>
+GTA_DEV void dma_linear_4waves(char* dst, const char* src, int wave, int lane) {
+    constexpr int PER_WAVE = BYTES / 1024 / 4;
+    static_assert(BYTES % 4096 == 0, "piece split");
+    const unsigned voff = (unsigned)lane * 16u;
+    const char* base = src + wave * (PER_WAVE * 1024);
+    const uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(dst + wave * (PER_WAVE * 1024));
+    gta_static_for<(PER_WAVE + 3) / 4>([&](auto GC) {
+        constexpr int g = decltype(GC)::value, np = PER_WAVE - 4 * g < 4 ? PER_WAVE - 4 * g : 4;
+        dma_group<np>(lds + g * 4096, base + g * 4096, voff);
+    });
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize (the opt-in above 64 KiB of dynamic LDS) is a per-DEVICE attribute of a

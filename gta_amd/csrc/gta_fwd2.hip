@@ -68,28 +68,7 @@ struct Smem2 {
     __host__ __device__ static int total(int nrec) { return RING_BYTES + 2 * nrec * GTA_QREC * 4; }
 };
 
-// issue the LDS-DMA of one K'/V' tile image pair (STAGE bytes, linear) into ring stage `st`: each wave moves PER_WAVE
-// consecutive KiB.  Written as asm in the scalar-base form -- global address = SGPR pair + 32-bit lane offset + immediate,
-// LDS address = M0 + the same immediate + 16 * lane -- so a group of four pieces needs ONE s_mov to M0 and no vector
-// arithmetic at all; through the builtin hipcc forms a 64-bit per-lane address and a new M0 for every piece (17 VALU
-// instructions per tile and wave in a loop whose issue slots are the scarce resource).  The compiler does not see these
-// as memory operations: every consumer sits behind an explicit s_waitcnt vmcnt + barrier (as with the builtin).
-template <int NP>
-GTA_DEV void dma_group(uint32_t lds, const char* base, unsigned voff) {
-    static_assert(NP >= 1 && NP <= 4, "13-bit immediates: four 1-KiB pieces per base");
-    if constexpr (NP == 1)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(voff), "s"(base) : "memory");
-    else if constexpr (NP == 2)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024"
-                     ::"s"(lds), "v"(voff), "s"(base) : "memory");
-    else if constexpr (NP == 3)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-                     "global_load_lds_dwordx4 %1, %2 offset:2048" ::"s"(lds), "v"(voff), "s"(base) : "memory");
-    else
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-                     "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072"
-                     ::"s"(lds), "v"(voff), "s"(base) : "memory");
-}
+// issue the LDS-DMA of one K'/V' tile image pair (STAGE bytes, linear) into ring stage `st` (dma_group: gta_common.h)
 template <int DHP>
 GTA_DEV void dma_stage(char* ring, int st, const char* img, int wave, int lane) {
     using S = Smem2<DHP>;
@@ -98,7 +77,7 @@ GTA_DEV void dma_stage(char* ring, int st, const char* img, int wave, int lane) 
     static_assert(PIECES % 4 == 0, "stage must split evenly over the waves");
     const unsigned voff = (unsigned)lane * 16u;
     const char* base = img + wave * (PER_WAVE * 1024);
-    const uint32_t lds = lds_addr(ring + st * S::STAGE + wave * (PER_WAVE * 1024));
+    const uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(ring + st * S::STAGE + wave * (PER_WAVE * 1024));
 #ifdef GTA_DMA_BUILTIN
 #pragma unroll
     for (int i = 0; i < PER_WAVE; ++i)
