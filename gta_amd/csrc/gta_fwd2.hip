@@ -17,13 +17,16 @@
 //                        K/V path at all); S^T = K' Q'^T and O^T = V'^T P^T on v_mfma_f32_32x32x16_bf16; V'^T operands
 //                        come from the row-major V' image with ds_read_b64_tr_b16; online softmax in registers.
 //                        Epilogue in registers: rho_q^-1 per chunk (gta.py:246-276) -> out, LSE.
-//                        The kernel body is an ITEM LOOP: by default the grid has one workgroup per item (one iteration);
-//                        with GTA_FLAG_PERSIST the resident workgroups walk the items and the DMA ring runs on as ONE
-//                        stream across them (the last two tile steps of an item request tiles 0 and 1 of the next).
-//                        Measured r02 (profiles/r02/README.md): the persistent grid is 3-9 % SLOWER at every BASELINE shape
-//                        but the 600-token CLEVR-TR encoder -- the two workgroups of a CU stay phase-locked, the older one
-//                        wins the issue arbitration every time, and half the chains finish at 80 % of the span -- so it
-//                        stays opt-in.  What the rewrite did buy is a spill-free kernel (see the three notes in the body).
+//                        The kernel body is an ITEM LOOP: by default the grid has one workgroup per item (one iteration).
+//                        With GTA_FLAG_PERSIST the resident workgroups walk the items, the DMA ring runs on as ONE stream
+//                        across them (the last two tile steps of an item request tiles 0 and 1 of the next), and the
+//                        workgroups that share a CU take turns at the raised issue priority, one item each, which keeps
+//                        their chains of items the same length.  Measured r02 (profiles/r02/README.md): in SHADER CYCLES
+//                        that grid is the fastest form (324k against 338k per launch; 352k without the turns), in
+//                        MICROSECONDS it is 3-12 % slower at every BASELINE shape but the 600-token CLEVR-TR encoder --
+//                        the better-filled matrix pipes draw more power and the part answers with a lower clock
+//                        (1.40-1.66 GHz against 1.66-1.83).  Wall time is what counts: it stays opt-in.
+//                        What the rewrite did buy is a spill-free kernel (see the three notes in the body).
 // Measured dead ends (r01, profiles/r01/README.md): an explicit ping-pong of an 8-wave kernel, 64 query rows per wave
 // with an asm-owned accumulator file (one wave per SIMD), 8-wave workgroups sharing one ring -- none beat two 4-wave
 // workgroups per CU; the sources of those variants are in the history (gta_fwd3.hip, removed in r02).
@@ -253,6 +256,16 @@ __global__ __launch_bounds__(256, (DHP <= 64 ? 3 : 2)) void gta_fwd2_kernel(cons
     asm volatile("" : "+v"(tid_i));
     const int lane = tid_i & 63, l31 = lane & 31, lh = lane >> 5;
     GTA_STAMP(V, 0); GTA_STAMPR(V, 5);
+    // Persistent grid (GTA_FLAG_PERSIST): the workgroups that share a CU take turns at the raised issue priority, one item each.  Without it
+    // the one that started first wins the age-based arbitration (MI355X_MICROARCH.md, "two waves per SIMD") on EVERY item,
+    // its chain of items ends at 80 % of the kernel's span and the CU idles half-empty behind it (measured r02: 352k ->
+    // 324k cycles).  Which workgroups share a CU is not architecturally defined; observed: an XCD deals its consecutive
+    // workgroups over its 32 CUs, so workgroup L sits in "slot" (L >> 8) of its CU.  A wrong guess costs nothing.
+    if (G < n_items) {
+        const int per_cu = pp->per_cu > 1 ? pp->per_cu : 2;
+        const int turn = ((V - (int)blockIdx.x) / G + ((int)blockIdx.x >> 8)) % per_cu;
+        if (__builtin_amdgcn_readfirstlane(turn) == 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+    }
     // ---- prologue, first half: every load of the item is requested up front ----
     // (defined on every path: a variable of the item loop's body that is only conditionally assigned becomes a
     //  loop-carried value -- "whatever the last iteration left" -- and then lives through the tile loop)
@@ -687,17 +700,20 @@ int launch_fwd2(const GtaFwdParams& p, hipStream_t stream) {
     const void* kfn = reinterpret_cast<const void*>(&gta_fwd2_kernel<DHP, ESZ, LAYOUT>);
     if (int rc = gta_lds_optin<&gta_fwd2_kernel<DHP, ESZ, LAYOUT>>(S::total(GTA_MAX_VIEWS))) return rc;
     int lds = S::total(p.vrep_q ? p.nrec : 0);
+    // Default: one workgroup per item.  GTA_FLAG_PERSIST: a persistent grid of as many workgroups as are resident at once
+    // (registers and LDS: two per CU at dh = 96, three at dh = 64), a multiple of 8 so that the virtual ids of a workgroup
+    // stay on its XCD.
+    GtaFwdParams pl = p;
     long grid = p.n_items;
+    pl.per_cu = 0;
     if (p.flags & GTA_FLAG_PERSIST) {
-        // persistent grid: as many workgroups as are resident at once (registers and LDS: two per CU at dh = 96, three at
-        // dh = 64), a multiple of 8 so that the virtual ids of a workgroup stay on its XCD
         int dev = 0, cus = 0, per_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess) return GTA_E_NODEVICE;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
         long g = (long)cus * per_cu;
         g -= g % 8;
-        if (g >= 8 && g < grid) grid = g;
+        if (g >= 8 && g < grid) { grid = g; pl.per_cu = per_cu; }
     }
 #ifdef GTA_ABLATE
     if (const char* e = getenv("GTA_LDS_PAD")) {        // occupancy experiment: inflate LDS so fewer workgroups share a CU
@@ -710,10 +726,10 @@ int launch_fwd2(const GtaFwdParams& p, hipStream_t stream) {
         // profiling hook (bench.py): start / stop events taken from the dispatch itself -- no marker packets, so the
         // kernel's neighbours in the stream are not pushed apart the way two hipEventRecord calls push them (~3 us each)
         hipExtLaunchKernelGGL((gta_fwd2_kernel<DHP, ESZ, LAYOUT>), dim3((unsigned)grid), dim3(256), lds, stream,
-                              (hipEvent_t)g_fwd2_ev_start, (hipEvent_t)g_fwd2_ev_stop, 0, p);
+                              (hipEvent_t)g_fwd2_ev_start, (hipEvent_t)g_fwd2_ev_stop, 0, pl);
         g_fwd2_ev_start = g_fwd2_ev_stop = nullptr;
     } else {
-        hipLaunchKernelGGL((gta_fwd2_kernel<DHP, ESZ, LAYOUT>), dim3((unsigned)grid), dim3(256), lds, stream, p);
+        hipLaunchKernelGGL((gta_fwd2_kernel<DHP, ESZ, LAYOUT>), dim3((unsigned)grid), dim3(256), lds, stream, pl);
     }
     return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH;
 }

@@ -15,6 +15,7 @@ struct GtaFwdParams {
     float invPq, invPk;
     int dh, nso2, n_qtiles;
     int n_items;                                // work items of the attention kernel: B * H * n_qtiles
+    int per_cu;                                 // persistent grid: workgroups resident per CU (0: one workgroup per item)
     int nrec;                                   // q-side view records staged per item (views a 128-row tile can touch)
     uint32_t flags;
     unsigned long long* prof;                   // debug: per-workgroup phase timestamps (or null)

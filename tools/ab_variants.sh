@@ -2,7 +2,7 @@
 # usage (on the GPU box): tools/ab_variants.sh NAME1 NAME2 ...   -- kernel cycles of each instrumented variant library
 # (tools/build_variant.sh), interleaved over 3 passes; compare KERNEL CYCLES and the per-phase means, not microseconds.
 cd "$(dirname "$0")/.."
-export GTA_TL_DEFAULT_ONLY=1
+[ -z "$GTA_TL_BOTH" ] && export GTA_TL_DEFAULT_ONLY=1
 for r in 1 2 3; do
   for v in "$@"; do
     GTA_HIP_LIB=$PWD/gta_amd/csrc/libgta_var_$v.so python tools/bench_kernels.py timeline 2>&1 | python -c "
