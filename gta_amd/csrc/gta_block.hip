@@ -1,0 +1,401 @@
+// gta_block.hip -- the row kernels of the fused Transformer block (include/gta_block.h): LayerNorm forward / backward,
+// exact GELU forward / backward, column sums.  All of them are HBM-bound: one pass over their operands, 16-byte accesses,
+// fp32 arithmetic, no re-reads.  gfx950 only.
+//
+// Reference semantics: nn.LayerNorm (source/layers.py:149), nn.GELU (source/layers.py:162), the `+ x` skip connections
+// of Transformer.forward (source/layers.py:483-487) whose gradient the LayerNorm backward folds in.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include "../../include/gta_hip.h"
+#include "../../include/gta_block.h"
+
+#define BLK_DEV __device__ __forceinline__
+
+namespace {
+
+BLK_DEV float bf16_to_f(uint32_t h) { return __uint_as_float(h << 16); }
+BLK_DEV uint32_t f_to_bf16(float f) {            // round to nearest even (inputs are finite)
+    uint32_t u = __float_as_uint(f);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+// eight consecutive elements of a row <-> eight floats, for both element types
+template <int DT> struct Vec8;
+template <> struct Vec8<GTA_DTYPE_F32> {
+    static BLK_DEV void load(const void* p, int64_t e, float (&v)[8]) {
+        const float4* q = reinterpret_cast<const float4*>(static_cast<const float*>(p) + e);
+        float4 a = q[0], b = q[1];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    static BLK_DEV void store(void* p, int64_t e, const float (&v)[8]) {
+        float4* q = reinterpret_cast<float4*>(static_cast<float*>(p) + e);
+        q[0] = make_float4(v[0], v[1], v[2], v[3]);
+        q[1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+};
+template <> struct Vec8<GTA_DTYPE_BF16> {
+    static BLK_DEV void load(const void* p, int64_t e, float (&v)[8]) {
+        uint4 a = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(p) + e);
+        uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = bf16_to_f(w[i] & 0xffffu); v[2 * i + 1] = bf16_to_f(w[i] >> 16); }
+    }
+    static BLK_DEV void store(void* p, int64_t e, const float (&v)[8]) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = f_to_bf16(v[2 * i]) | (f_to_bf16(v[2 * i + 1]) << 16);
+        *reinterpret_cast<uint4*>(static_cast<uint16_t*>(p) + e) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+
+BLK_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm forward: one 64-lane wave per row, the row held in registers (NJ chunks of 8 elements per lane, d <= 512 NJ).
+// ---------------------------------------------------------------------------------------------------------------
+template <int XDT, int YDT, int NJ>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps, int64_t rows, int d,
+                                                     void* __restrict__ y, float* __restrict__ mean_out,
+                                                     float* __restrict__ rstd_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t base = row * d;
+    float v[NJ][8];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int e = (lane + 64 * j) * 8;
+        if (e < d) {
+            Vec8<XDT>::load(x, base + e, v[j]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += v[j][i];
+        }
+    }
+    const float inv_d = 1.0f / (float)d;
+    const float mean = wave_sum(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int e = (lane + 64 * j) * 8;
+        if (e < d) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float c = v[j][i] - mean; q += c * c; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) * inv_d + eps);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int e = (lane + 64 * j) * 8;
+        if (e < d) {
+            float g[8], b[8], o[8];
+            Vec8<GTA_DTYPE_F32>::load(gamma, e, g);
+            Vec8<GTA_DTYPE_F32>::load(beta, e, b);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (v[j][i] - mean) * rstd * g[i] + b[i];
+            Vec8<YDT>::store(y, base + e, o);
+        }
+    }
+    if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm backward.  Grid of G workgroups of 4 waves; wave w of workgroup g walks rows (4g + w), + 4G, ...
+// dgamma / dbeta partial sums live in registers across the walk, are reduced over the 4 waves through LDS and written
+// to part[g][2][d]; colsum_finish_kernel adds the G partials in a fixed order.
+// ---------------------------------------------------------------------------------------------------------------
+template <int GDT, int XDT, int NJ>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, int64_t rows, int d,
+                                                     const void* dres, void* dx, float* __restrict__ part) {
+    extern __shared__ float lds[];            // [4][2][d]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float ag[NJ][8], ab[NJ][8], gm[NJ][8];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int e = (lane + 64 * j) * 8;
+        if (e < d) Vec8<GTA_DTYPE_F32>::load(gamma, e, gm[j]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { ag[j][i] = 0.f; ab[j][i] = 0.f; }
+    }
+    const float inv_d = 1.0f / (float)d;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const int64_t base = row * d;
+        const float mu = mean[row], rs = rstd[row];
+        float g[NJ][8], xh[NJ][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int e = (lane + 64 * j) * 8;
+            if (e < d) {
+                float dyv[8], xv[8];
+                Vec8<GDT>::load(dy, base + e, dyv);
+                Vec8<XDT>::load(x, base + e, xv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    xh[j][i] = (xv[i] - mu) * rs;
+                    g[j][i] = dyv[i] * gm[j][i];
+                    s1 += g[j][i];
+                    s2 += g[j][i] * xh[j][i];
+                    ag[j][i] += dyv[i] * xh[j][i];
+                    ab[j][i] += dyv[i];
+                }
+            }
+        }
+        const float m1 = wave_sum(s1) * inv_d, m2 = wave_sum(s2) * inv_d;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int e = (lane + 64 * j) * 8;
+            if (e < d) {
+                float o[8];
+                if (dres) Vec8<XDT>::load(dres, base + e, o);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o[i] = 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] += rs * (g[j][i] - m1 - xh[j][i] * m2);
+                Vec8<XDT>::store(dx, base + e, o);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int e = (lane + 64 * j) * 8;
+        if (e < d) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                lds[(wave * 2 + 0) * d + e + i] = ag[j][i];
+                lds[(wave * 2 + 1) * d + e + i] = ab[j][i];
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * d; c += 256)
+        part[(int64_t)blockIdx.x * 2 * d + c] = (lds[c] + lds[2 * d + c]) + (lds[4 * d + c] + lds[6 * d + c]);
+}
+
+// out[c] = sum_p part[p][c], p in a fixed order: 256 threads = 8 row groups x 32 columns, tree over the groups.
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int np, int n,
+                                                           float* __restrict__ out0, float* __restrict__ out1, int split) {
+    __shared__ float red[8][33];
+    const int cx = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    float s = 0.f;
+    if (c < n)
+        for (int p = rg; p < np; p += 8) s += part[(int64_t)p * n + c];
+    red[rg][cx] = s;
+    __syncthreads();
+    if (rg == 0 && c < n) {
+        const float t = ((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx])) +
+                        ((red[4][cx] + red[5][cx]) + (red[6][cx] + red[7][cx]));
+        if (c < split) out0[c] = t; else out1[c - split] = t;
+    }
+}
+
+// Column sums, stage 1: grid (ceil(n / 512), S strips); wave w of a workgroup walks rows (4 s + w), + 4 S, ...; a lane
+// owns 8 columns.  part[s][n].
+template <int DT>
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ a, int64_t m, int n, int64_t ld,
+                                                     float* __restrict__ part) {
+    __shared__ float lds[4][512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = (blockIdx.x * 64 + lane) * 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (e < n)
+        for (int64_t row = (int64_t)blockIdx.y * 4 + wave; row < m; row += (int64_t)gridDim.y * 4) {
+            float v[8];
+            Vec8<DT>::load(a, row * ld + e, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += v[i];
+        }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lds[wave][lane * 8 + i] = acc[i];
+    __syncthreads();
+    for (int c = threadIdx.x; c < 512; c += 256) {
+        const int col = blockIdx.x * 512 + c;
+        if (col < n) part[(int64_t)blockIdx.y * n + col] = (lds[0][c] + lds[1][c]) + (lds[2][c] + lds[3][c]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// exact GELU (erf form)
+// ---------------------------------------------------------------------------------------------------------------
+BLK_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+BLK_DEV float dgelu_erf(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const void* __restrict__ x, void* __restrict__ y, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float v[8];
+        Vec8<DT>::load(x, i * 8, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = gelu_erf(v[k]);
+        Vec8<DT>::store(y, i * 8, v);
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ x,
+                                                       void* __restrict__ dx, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float v[8], g[8];
+        Vec8<DT>::load(x, i * 8, v);
+        Vec8<DT>::load(dy, i * 8, g);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g[k] *= dgelu_erf(v[k]);
+        Vec8<DT>::store(dx, i * 8, g);
+    }
+}
+
+inline bool dtype_ok(int dt) { return dt == GTA_DTYPE_F32 || dt == GTA_DTYPE_BF16; }
+inline int launch_status() { return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH; }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+constexpr int LN_BWD_MAX_WG = 1024;      // 4 workgroups of 4 waves per CU
+inline int ln_bwd_grid(int64_t rows) {
+    int64_t g = (rows + 3) / 4;
+    return (int)(g < LN_BWD_MAX_WG ? g : LN_BWD_MAX_WG);
+}
+constexpr int COLSUM_MAX_STRIPS = 512;
+inline int colsum_strips(int64_t m, int n) {
+    const int64_t per = (n + 511) / 512;                         // workgroups per strip
+    int64_t cap = COLSUM_MAX_STRIPS / per;
+    if (cap < 8) cap = 8;
+    int64_t s = (m + 63) / 64;                                   // at least 16 rows per wave
+    if (s > cap) s = cap;
+    return (int)(s < 1 ? 1 : s);
+}
+
+// dispatch over the chunks-per-lane count: d <= 512 * NJ
+template <class F> inline int by_nj(int d, F&& f) {
+    if (d <= 512) return f(std::integral_constant<int, 1>{});
+    if (d <= 1024) return f(std::integral_constant<int, 2>{});
+    if (d <= 2048) return f(std::integral_constant<int, 4>{});
+    return f(std::integral_constant<int, 8>{});
+}
+template <class F> inline int by_dtype(int dt, F&& f) {
+    return dt == GTA_DTYPE_F32 ? f(std::integral_constant<int, GTA_DTYPE_F32>{}) : f(std::integral_constant<int, GTA_DTYPE_BF16>{});
+}
+
+}  // namespace
+
+extern "C" {
+
+int gta_ln_fwd(const void* x, int32_t x_dtype, const float* gamma, const float* beta, float eps, int64_t rows, int32_t d,
+               void* y, int32_t y_dtype, float* mean, float* rstd, void* stream) {
+    if (!x || !gamma || !beta || !y || rows <= 0 || d <= 0 || !dtype_ok(x_dtype) || !dtype_ok(y_dtype)) return GTA_E_BADARG;
+    if (d % 8 != 0 || d > 4096) return GTA_E_UNSUPPORTED;
+    if (!aligned16(x) || !aligned16(y) || !aligned16(gamma) || !aligned16(beta)) return GTA_E_BADARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    return by_nj(d, [&](auto nj) {
+        return by_dtype(x_dtype, [&](auto xd) {
+            return by_dtype(y_dtype, [&](auto yd) {
+                hipLaunchKernelGGL((ln_fwd_kernel<decltype(xd)::value, decltype(yd)::value, decltype(nj)::value>), dim3(grid),
+                                   dim3(256), 0, s, x, gamma, beta, eps, rows, d, y, mean, rstd);
+                return launch_status();
+            });
+        });
+    });
+}
+
+int64_t gta_ln_bwd_workspace_bytes(int64_t rows, int32_t d) {
+    if (rows <= 0 || d <= 0) return 0;
+    return (int64_t)ln_bwd_grid(rows) * 2 * d * (int64_t)sizeof(float);
+}
+
+int gta_ln_bwd(const void* dy, int32_t dy_dtype, const void* x, int32_t x_dtype, const float* gamma, const float* mean,
+               const float* rstd, int64_t rows, int32_t d, const void* dres, void* dx, int32_t dx_dtype, float* dgamma,
+               float* dbeta, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace || rows <= 0 || d <= 0 ||
+        !dtype_ok(dy_dtype) || !dtype_ok(x_dtype))
+        return GTA_E_BADARG;
+    if (dx_dtype != x_dtype) return GTA_E_UNSUPPORTED;            // the skip connection keeps the stream's type
+    if (d % 8 != 0 || d > 4096) return GTA_E_UNSUPPORTED;
+    if (workspace_bytes < gta_ln_bwd_workspace_bytes(rows, d)) return GTA_E_BADARG;
+    if (!aligned16(dy) || !aligned16(x) || !aligned16(dx) || !aligned16(gamma) || (dres && !aligned16(dres))) return GTA_E_BADARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int grid = ln_bwd_grid(rows);
+    float* part = static_cast<float*>(workspace);
+    const size_t lds = (size_t)8 * d * sizeof(float);            // 128 KiB at d = 4096
+    int rc = by_nj(d, [&](auto nj) {
+        return by_dtype(dy_dtype, [&](auto gd) {
+            return by_dtype(x_dtype, [&](auto xd) {
+                auto kern = ln_bwd_kernel<decltype(gd)::value, decltype(xd)::value, decltype(nj)::value>;
+                if (lds > 64 * 1024 &&
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                    return GTA_E_LAUNCH;
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, rows, d, dres, dx, part);
+                return launch_status();
+            });
+        });
+    });
+    if (rc != GTA_OK) return rc;
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((2 * d + 31) / 32), dim3(256), 0, s, part, grid, 2 * d, dgamma, dbeta, d);
+    return launch_status();
+}
+
+int gta_gelu_fwd(const void* x, void* y, int32_t dtype, int64_t n, void* stream) {
+    if (!x || !y || n <= 0 || !dtype_ok(dtype) || !aligned16(x) || !aligned16(y)) return GTA_E_BADARG;
+    if (n % 8 != 0) return GTA_E_UNSUPPORTED;
+    const int64_t n8 = n / 8;
+    const int64_t want = (n8 + 255) / 256;
+    const unsigned grid = (unsigned)(want < 8192 ? want : 8192);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return by_dtype(dtype, [&](auto dt) {
+        hipLaunchKernelGGL((gelu_fwd_kernel<decltype(dt)::value>), dim3(grid), dim3(256), 0, s, x, y, n8);
+        return launch_status();
+    });
+}
+
+int gta_gelu_bwd(const void* dy, const void* x, void* dx, int32_t dtype, int64_t n, void* stream) {
+    if (!dy || !x || !dx || n <= 0 || !dtype_ok(dtype) || !aligned16(x) || !aligned16(dy) || !aligned16(dx)) return GTA_E_BADARG;
+    if (n % 8 != 0) return GTA_E_UNSUPPORTED;
+    const int64_t n8 = n / 8;
+    const int64_t want = (n8 + 255) / 256;
+    const unsigned grid = (unsigned)(want < 8192 ? want : 8192);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return by_dtype(dtype, [&](auto dt) {
+        hipLaunchKernelGGL((gelu_bwd_kernel<decltype(dt)::value>), dim3(grid), dim3(256), 0, s, dy, x, dx, n8);
+        return launch_status();
+    });
+}
+
+int64_t gta_colsum_workspace_bytes(int64_t m, int32_t n) {
+    if (m <= 0 || n <= 0) return 0;
+    return (int64_t)colsum_strips(m, n) * n * (int64_t)sizeof(float);
+}
+
+int gta_colsum(const void* a, int32_t dtype, int64_t m, int32_t n, int64_t ld, float* out, void* workspace,
+               int64_t workspace_bytes, void* stream) {
+    if (!a || !out || !workspace || m <= 0 || n <= 0 || ld < n || !dtype_ok(dtype) || !aligned16(a)) return GTA_E_BADARG;
+    if (n % 8 != 0 || ld % 8 != 0) return GTA_E_UNSUPPORTED;
+    if (workspace_bytes < gta_colsum_workspace_bytes(m, n)) return GTA_E_BADARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int strips = colsum_strips(m, n);
+    float* part = static_cast<float*>(workspace);
+    int rc = by_dtype(dtype, [&](auto dt) {
+        hipLaunchKernelGGL((colsum_kernel<decltype(dt)::value>), dim3((n + 511) / 512, strips), dim3(256), 0, s, a, m, n, ld, part);
+        return launch_status();
+    });
+    if (rc != GTA_OK) return rc;
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((n + 31) / 32), dim3(256), 0, s, part, strips, n, out, out, n);
+    return launch_status();
+}
+
+}  // extern "C"

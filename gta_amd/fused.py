@@ -1,0 +1,204 @@
+"""Fused pre-LN Transformer block around the GTA attention operator.
+
+What ``Transformer.forward`` (source/layers.py:475-488) does per layer, ``x = attn(norm(x)) + x; x = ff(norm(x)) + x``,
+as these launches (``gta_block.h``):
+
+    LayerNorm -> compute dtype        gta_ln_fwd           (PreNorm, layers.py:146-154, + autocast's cast kernel)
+    QKV / Q projection                gta_gemm             (to_qkv / to_q, layers.py:388-392)
+    rho, softmax(QK^T)V, rho^-1       gta_attn_fwd         (gta.py:92-279; unchanged)
+    out-proj + bias + skip            gta_gemm, epilogue   (to_out, layers.py:430, and `+ x`, :483-486)
+    LayerNorm -> compute dtype        gta_ln_fwd
+    Linear + bias (+ GELU)            gta_gemm, epilogue   (net[0], net[1], layers.py:161-162)
+    Linear + bias + skip              gta_gemm, epilogue   (net[3] and `+ x`, layers.py:164,487)
+
+and, in the backward, the LayerNorm gradient fused with the skip connection's (``gta_ln_bwd``), bias gradients as
+deterministic column sums, weight gradients written in fp32 straight from the bf16 GEMM.
+
+Arithmetic.  The compute dtype is autocast's (bf16) when autocast is on, else the dtype of ``x``.  The residual stream
+keeps the dtype of ``x`` (fp32 under autocast, as in the reference's mixed_prec runs), LayerNorm statistics and every
+accumulation are fp32.  GELU: nn.GELU() is the erf form.  hipBLASLt's GELU epilogue is the tanh form (max |difference|
+4.7e-4, below one bf16 ulp of the values it occurs at); it is used only in bf16 inference (``GELU_EPILOGUE``); training
+and fp32 use the exact kernels (``gta_gelu_fwd`` / ``gta_gelu_bwd``), so gradients match the forward they belong to.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import native_block as nb
+
+# bf16 inference only: fold the GELU into the GEMM epilogue (tanh form, see the module docstring)
+GELU_EPILOGUE = True
+
+
+def compute_dtype(x: torch.Tensor) -> Optional[torch.dtype]:
+    """The dtype the block's GEMMs run in for this input, or None when the fused path does not apply."""
+    if not x.is_cuda:
+        return None
+    if torch.is_autocast_enabled():
+        dt = torch.get_autocast_dtype("cuda")
+        return dt if dt == torch.bfloat16 else None
+    return x.dtype if x.dtype in (torch.float32, torch.bfloat16) else None
+
+
+def _cast_param(p: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
+    """p in the compute dtype; the copy is kept on the parameter until the parameter changes (an optimizer step)."""
+    if p.dtype == dt:
+        return p.detach()
+    tag = getattr(p, "_gta_cast", None)
+    if tag is not None and tag[0] == p._version and tag[1].dtype == dt and tag[1].device == p.device:
+        return tag[1]
+    c = p.detach().to(dt)
+    p._gta_cast = (p._version, c)
+    return c
+
+
+def _bias_for(b: Optional[torch.Tensor], out_dtype: torch.dtype) -> Optional[torch.Tensor]:
+    """hipBLASLt takes the bias in fp32 or in the output's dtype."""
+    if b is None:
+        return None
+    b = b.detach()
+    return b if b.dtype in (torch.float32, out_dtype) else b.float()
+
+
+def _rows(x: torch.Tensor) -> torch.Tensor:
+    return x.reshape(-1, x.shape[-1]) if x.is_contiguous() else x.contiguous().view(-1, x.shape[-1])
+
+
+class _LNLinear(torch.autograd.Function):
+    """(x W^T + b of LayerNorm(x), x): the second output is x itself, handed to the block's skip connection so that the
+    gradient arriving through the skip is added inside the LayerNorm backward kernel instead of by autograd."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, W, bias, eps, cdt, need):
+        x2 = _rows(x)
+        y, mean, rstd = nb.ln_fwd(x2, gamma.detach(), beta.detach(), eps, cdt, want_stats=need)
+        Wc = _cast_param(W, cdt)
+        b = _bias_for(bias, cdt)
+        out = nb.gemm(y, Wc, trans_b=True, epilogue=nb.EPI_BIAS if b is not None else nb.EPI_NONE, bias=b)
+        if need:
+            ctx.save_for_backward(x2, gamma, beta, mean, rstd, Wc)
+            ctx.eps, ctx.cdt, ctx.has_bias, ctx.wdtype = eps, cdt, bias is not None, W.dtype
+            ctx.xshape = x.shape
+        return out.view(*x.shape[:-1], W.shape[0]), x
+
+    @staticmethod
+    def backward(ctx, dout, dskip):
+        x2, gamma, beta, mean, rstd, Wc = ctx.saved_tensors
+        d2 = _rows(dout)
+        if d2.dtype != ctx.cdt:
+            d2 = d2.to(ctx.cdt)
+        y, _, _ = nb.ln_fwd(x2, gamma.detach(), beta.detach(), ctx.eps, ctx.cdt, want_stats=False)     # recomputed, not stored
+        dW = nb.gemm(d2, y, trans_a=True, out_dtype=ctx.wdtype) if ctx.needs_input_grad[3] else None
+        db = nb.colsum(d2) if ctx.has_bias and ctx.needs_input_grad[4] else None
+        dy = nb.gemm(d2, Wc)
+        dres = None
+        if dskip is not None:
+            dres = _rows(dskip)
+            if dres.dtype != x2.dtype:
+                dres = dres.to(x2.dtype)
+        dx, dgamma, dbeta = nb.ln_bwd(dy, x2, gamma.detach(), mean, rstd, dres)
+        return (dx.view(ctx.xshape), dgamma.to(gamma.dtype), dbeta.to(beta.dtype), dW,
+                db.to(ctx.wdtype) if db is not None else None, None, None, None)
+
+
+class _LinearSkip(torch.autograd.Function):
+    """skip + a W^T + b in one GEMM (bias epilogue, beta = 1 on the skip); output in the skip's dtype."""
+
+    @staticmethod
+    def forward(ctx, a, W, bias, skip, cdt, need):
+        a2 = _rows(a)
+        if a2.dtype != cdt:
+            a2 = a2.to(cdt)
+        s2 = _rows(skip)
+        Wc = _cast_param(W, cdt)
+        b = _bias_for(bias, s2.dtype)
+        out = nb.gemm(a2, Wc, trans_b=True, epilogue=nb.EPI_BIAS if b is not None else nb.EPI_NONE, bias=b, c=s2, beta=1.0,
+                      out_dtype=s2.dtype)
+        if need:
+            ctx.save_for_backward(a2, Wc)
+            ctx.cdt, ctx.has_bias, ctx.wdtype, ctx.ashape, ctx.adtype = cdt, bias is not None, W.dtype, a.shape, a.dtype
+        return out.view(skip.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        a2, Wc = ctx.saved_tensors
+        d2 = _rows(dout)
+        dc = d2 if d2.dtype == ctx.cdt else d2.to(ctx.cdt)
+        da = nb.gemm(dc, Wc).view(ctx.ashape) if ctx.needs_input_grad[0] else None
+        if da is not None and da.dtype != ctx.adtype:
+            da = da.to(ctx.adtype)
+        dW = nb.gemm(dc, a2, trans_a=True, out_dtype=ctx.wdtype) if ctx.needs_input_grad[1] else None
+        db = nb.colsum(dc).to(ctx.wdtype) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return da, dW, db, dout, None, None
+
+
+class _FeedForwardSkip(torch.autograd.Function):
+    """x + W2 gelu(W1 LayerNorm(x) + b1) + b2  (PreNorm(FeedForward) + skip, layers.py:146-169,487)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, W1, b1, W2, b2, eps, cdt, need):
+        x2 = _rows(x)
+        y, mean, rstd = nb.ln_fwd(x2, gamma.detach(), beta.detach(), eps, cdt, want_stats=need)
+        W1c, W2c = _cast_param(W1, cdt), _cast_param(W2, cdt)
+        bb1, bb2 = _bias_for(b1, cdt), _bias_for(b2, x2.dtype)
+        epi = nb.EPI_BIAS if bb1 is not None else nb.EPI_NONE
+        if not need and GELU_EPILOGUE and cdt == torch.bfloat16 and bb1 is not None:
+            pre = None
+            h = nb.gemm(y, W1c, trans_b=True, epilogue=nb.EPI_BIAS_GELU, bias=bb1)
+        else:
+            pre = nb.gemm(y, W1c, trans_b=True, epilogue=epi, bias=bb1)
+            h = nb.gelu_fwd(pre)
+        out = nb.gemm(h, W2c, trans_b=True, epilogue=nb.EPI_BIAS if bb2 is not None else nb.EPI_NONE, bias=bb2, c=x2, beta=1.0,
+                      out_dtype=x2.dtype)
+        if need:
+            ctx.save_for_backward(x2, gamma, beta, mean, rstd, W1c, W2c, pre, h)
+            ctx.eps, ctx.cdt, ctx.wdtype, ctx.xshape = eps, cdt, W1.dtype, x.shape
+            ctx.has_b1, ctx.has_b2 = b1 is not None, b2 is not None
+        return out.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, gamma, beta, mean, rstd, W1c, W2c, pre, h = ctx.saved_tensors
+        d2 = _rows(dout)
+        dc = d2 if d2.dtype == ctx.cdt else d2.to(ctx.cdt)
+        dW2 = nb.gemm(dc, h, trans_a=True, out_dtype=ctx.wdtype) if ctx.needs_input_grad[5] else None
+        db2 = nb.colsum(dc).to(ctx.wdtype) if ctx.has_b2 and ctx.needs_input_grad[6] else None
+        dh = nb.gemm(dc, W2c)
+        dpre = nb.gelu_bwd(dh, pre)
+        del dh
+        y, _, _ = nb.ln_fwd(x2, gamma.detach(), beta.detach(), ctx.eps, ctx.cdt, want_stats=False)
+        dW1 = nb.gemm(dpre, y, trans_a=True, out_dtype=ctx.wdtype) if ctx.needs_input_grad[3] else None
+        db1 = nb.colsum(dpre).to(ctx.wdtype) if ctx.has_b1 and ctx.needs_input_grad[4] else None
+        dy = nb.gemm(dpre, W1c)
+        dres = d2 if d2.dtype == x2.dtype else d2.to(x2.dtype)
+        dx, dgamma, dbeta = nb.ln_bwd(dy, x2, gamma.detach(), mean, rstd, dres)
+        return dx.view(ctx.xshape), dgamma.to(gamma.dtype), dbeta.to(beta.dtype), dW1, db1, dW2, db2, None, None, None
+
+
+def _need(*ts) -> bool:
+    """Will a backward run through this call?  (Inside Function.forward grad mode is always off, so it is decided here.)"""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+
+
+def ln_linear(x, norm: torch.nn.LayerNorm, lin: torch.nn.Linear, cdt):
+    """-> (lin(norm(x)) in the compute dtype, x for the skip connection)."""
+    args = (x, norm.weight, norm.bias, lin.weight, lin.bias)
+    return _LNLinear.apply(*args, norm.eps, cdt, _need(*args))
+
+
+def linear_skip(a, lin: torch.nn.Linear, skip, cdt):
+    args = (a, lin.weight, lin.bias, skip)
+    return _LinearSkip.apply(*args, cdt, _need(*args))
+
+
+def feed_forward_skip(x, norm: torch.nn.LayerNorm, lin1: torch.nn.Linear, lin2: torch.nn.Linear, cdt):
+    args = (x, norm.weight, norm.bias, lin1.weight, lin1.bias, lin2.weight, lin2.bias)
+    return _FeedForwardSkip.apply(*args, norm.eps, cdt, _need(*args))
+
+
+def norm_ok(norm) -> bool:
+    return (isinstance(norm, torch.nn.LayerNorm) and norm.elementwise_affine and norm.bias is not None
+            and len(norm.normalized_shape) == 1 and norm.normalized_shape[0] % 8 == 0 and norm.normalized_shape[0] <= 4096
+            and norm.weight.dtype == torch.float32)

@@ -4,20 +4,28 @@ Same constructor arguments, ``forward`` signatures, ``extras`` contract and stat
 the reference's ``Attention`` (layers.py:172-444), ``Transformer`` (:447-488), ``PreNorm``
 (:146-154), ``FeedForward`` (:157-169), ``JaxLinear`` (:14-25) and ``ViTLinear`` (:28-37), so a
 reference checkpoint loads with ``load_state_dict(strict=True)``.  The attention core is the
-fused HIP kernel; projections, LayerNorm and the MLP stay PyTorch-ROCm (rocBLAS/hipBLASLt).
+fused HIP kernel.  On an MI355X ``Transformer`` runs each layer as the fused block of ``gta_amd.fused`` (LayerNorm+cast
+kernel, hipBLASLt GEMMs with bias / skip / GELU epilogues, LayerNorm backward fused with the skip gradient; SURVEY.md
+section 8 row f1); ``FUSED_BLOCKS = False`` (or env ``GTA_FUSED_BLOCKS=0``) keeps the module-by-module path, which is
+also what ``Attention`` / ``PreNorm`` / ``FeedForward`` do when called on their own.
 Only ``method: gta`` is built -- the other positional-encoding baselines of the reference
 (repast/ape/mln/gbt/rpe/frustum) are out of scope.
 """
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn as nn
 from torch.nn import init
 
+from . import fused as _fused
 from . import gta as _gta
 from . import native
+
+# run Transformer layers as fused blocks (gta_amd.fused) where they qualify
+FUSED_BLOCKS = os.environ.get("GTA_FUSED_BLOCKS", "1") != "0"
 
 
 class JaxLinear(nn.Linear):
@@ -116,17 +124,17 @@ class Attention(nn.Module):
         self.to_out = nn.Sequential(linear_module(inner_dim, dim), nn.Dropout(dropout)) if project_out \
             else nn.Identity()
 
-    def forward(self, x, z=None, return_attmap=False, extras=None):
-        if extras is None:
-            raise ValueError("GTA attention needs `extras` (the reps dict)")
+    def project(self, x, z, extras, q_packed=None):
+        """(q, k, v) as [B,H,T,dh] strided views of the packed projections (layers.py:388-395) + the decode cache.
+        ``q_packed``: the query-side projection when the caller has already run it (fused LayerNorm + GEMM)."""
         B, Tq, _ = x.shape
         H, dh = self.heads, self.dim_head
         kv_cache = None
         if z is None:
-            qkv = self.to_qkv(x).view(B, Tq, 3, H, dh)                    # layers.py:389
+            qkv = (self.to_qkv(x) if q_packed is None else q_packed).view(B, Tq, 3, H, dh)      # layers.py:389
             q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))   # strided views, no copy
         else:
-            q = self.to_q(x).view(B, Tq, H, dh).permute(0, 2, 1, 3)      # layers.py:391-392
+            q = (self.to_q(x) if q_packed is None else q_packed).view(B, Tq, H, dh).permute(0, 2, 1, 3)   # layers.py:391-392
             # chunked decode (srt.render_image): the key side of a cross-attention layer does not change between
             # query chunks, so its projection and its K'/V' images are kept in the caller's cache
             if "gta_kv_cache" in extras and not torch.is_grad_enabled():
@@ -138,31 +146,43 @@ class Attention(nn.Module):
                 k, v = (kv[:, :, i].permute(0, 2, 1, 3) for i in range(2))
                 if kv_cache is not None:
                     kv_cache["kv"] = (k, v)
+        return q, k, v, kv_cache
+
+    def core(self, q, k, v, extras, kv_cache=None, return_attmap=False):
+        """rho, softmax(QK^T)V, rho^-1 (layers.py:409-428) -> [B,Tq,H*dh] (the input of ``to_out``), attmap or None."""
+        B, H, Tq, dh = q.shape
         tau = self.attend.tau if self.attend is not None else None
         if self.elementwise_mul:                                          # layers.py:410-419
             ex = dict(vecrep_q=self.rep_to_vec(extras["flattened_rep_q"]), vecrep_k=self.rep_to_vec(extras["flattened_rep_k"]),
                       vecinvrep_q=self.rep_to_vec(extras["flattened_invrep_q"]))
             out, _ = _gta.multihead_vecrep_attention(q, k, v, attn_fn=self, extras=ex, tau=tau)
             out = out.permute(0, 2, 1, 3).reshape(B, Tq, H * dh)
-            out = self.to_out(out)
+            attn = None
             if return_attmap:
-                return out, _gta.attention_map(ex["vecrep_q"][:, None] * q, ex["vecrep_k"][:, None] * k, {"triv": dh}, {},
-                                               tau=tau, scale=self.scale)
-            return out
+                attn = _gta.attention_map(ex["vecrep_q"][:, None] * q, ex["vecrep_k"][:, None] * k, {"triv": dh}, {},
+                                          tau=tau, scale=self.scale)
+            return out, attn
         packed = _gta.pack_reps(extras, self.f_dims)
         out = _gta.gta_attention(
             q, k, v, self.f_dims, packed,
             so3_degree=_gta._so3_degree(self.f_dims, packed, extras),
-            trans_coeff=self.trans_coeff, tau=self.attend.tau if self.attend is not None else None,
+            trans_coeff=self.trans_coeff, tau=tau,
             scale=self.scale, v_transform=self.method_args.get("v_transform", True), euclid=self.euclid,
             kv_cache=kv_cache)
         out = out.permute(0, 2, 1, 3).reshape(B, Tq, H * dh)              # free: out is [B,Tq,H,dh] in memory
-        out = self.to_out(out)
+        attn = None
         if return_attmap:                                                  # layers.py:441-442
             attn = _gta.attention_map(q, k, self.f_dims, packed, so3_degree=_gta._so3_degree(self.f_dims, packed, extras),
                                       trans_coeff=self.trans_coeff, tau=tau, scale=self.scale, euclid=self.euclid)
-            return out, attn
-        return out
+        return out, attn
+
+    def forward(self, x, z=None, return_attmap=False, extras=None):
+        if extras is None:
+            raise ValueError("GTA attention needs `extras` (the reps dict)")
+        q, k, v, kv_cache = self.project(x, z, extras)
+        out, attn = self.core(q, k, v, extras, kv_cache, return_attmap)
+        out = self.to_out(out)
+        return (out, attn) if return_attmap else out
 
 
 class Transformer(nn.Module):
@@ -181,10 +201,40 @@ class Transformer(nn.Module):
             self.layers.append(nn.ModuleList([attn, ff]))
         self.return_last_attmap = return_last_attmap
 
+    def _fused_dtype(self, x, attn, ff):
+        """Compute dtype of the fused block for this layer and input, or None -> module-by-module path."""
+        if not FUSED_BLOCKS or not isinstance(attn.fn, Attention):
+            return None
+        cdt = _fused.compute_dtype(x)
+        if cdt is None or x.dim() != 3:
+            return None
+        a, net = attn.fn, ff.fn.net
+        drop = [m for m in list(net) + ([a.to_out[1]] if isinstance(a.to_out, nn.Sequential) else []) if isinstance(m, nn.Dropout)]
+        if any(m.p > 0.0 and m.training for m in drop):
+            return None
+        if not (_fused.norm_ok(attn.norm) and _fused.norm_ok(ff.norm) and isinstance(a.to_out, nn.Sequential)):
+            return None
+        lins = [a.to_qkv if a.selfatt else a.to_q, a.to_out[0], net[0], net[3]]
+        if any(l.weight.dtype != torch.float32 or l.in_features % 8 or l.out_features % 8 for l in lins):
+            return None
+        return cdt
+
     def forward(self, x, z=None, extras=None):
         attmap = None
         for l, (attn, ff) in enumerate(self.layers):
-            if l == len(self.layers) - 1 and self.return_last_attmap:
+            want_map = l == len(self.layers) - 1 and self.return_last_attmap
+            cdt = self._fused_dtype(x, attn, ff) if extras is not None else None
+            if cdt is not None:
+                a = attn.fn
+                q_packed, skip = _fused.ln_linear(x, attn.norm, a.to_qkv if z is None else a.to_q, cdt)
+                q, k, v, kv_cache = a.project(x, z, extras, q_packed=q_packed)
+                out, amap = a.core(q, k, v, extras, kv_cache, return_attmap=want_map)
+                if want_map:
+                    attmap = amap
+                x = _fused.linear_skip(out, a.to_out[0], skip, cdt)                      # to_out + `+ x` (layers.py:483-486)
+                x = _fused.feed_forward_skip(x, ff.norm, ff.fn.net[0], ff.fn.net[3], cdt)  # ff(norm(x)) + x (layers.py:487)
+                continue
+            if want_map:
                 out, attmap = attn(x, z=z, return_attmap=True, extras=extras)
                 x = out + x
             else:

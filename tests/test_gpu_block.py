@@ -1,0 +1,206 @@
+"""GPU: the fused Transformer block (include/gta_block.h, gta_amd.fused).
+
+Row kernels and GEMM epilogues against plain PyTorch fp32 references of the same operations (nn.LayerNorm,
+nn.GELU, nn.Linear: source/layers.py:146-169,388-395,429-430), then the fused ``Transformer`` against the
+module-by-module path under identical weights, forward and every gradient.  The reference-generated module
+fixtures (tests/golden/mod_*.npz, srt_ms_tiny.npz) run through the fused path in test_gpu_modules.py.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import gta_amd
+from gta_amd import fused, layers, synth
+from gta_amd.native import GtaError
+from gta_amd import native_block as nb
+from tests import _hip_cases as C
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF = torch.bfloat16
+
+
+def _err(a, b):
+    return (a.float() - b.float()).abs().max().item()
+
+
+@pytest.mark.parametrize("rows,d", [(37, 768), (4, 8), (129, 512), (50, 1024), (33, 1536), (9, 2048), (5, 4096), (1, 264)])
+@pytest.mark.parametrize("xdt,ydt", [(torch.float32, BF), (torch.float32, torch.float32), (BF, BF)])
+def test_layernorm_forward_backward(rows, d, xdt, ydt):
+    g = torch.Generator(device=DEV).manual_seed(rows * 7 + d)
+    x = (torch.randn(rows, d, device=DEV, generator=g) * 1.7 + 0.4).to(xdt)
+    gam = torch.randn(d, device=DEV, generator=g) * 0.3 + 1.0
+    bet = torch.randn(d, device=DEV, generator=g) * 0.2
+    dy = torch.randn(rows, d, device=DEV, generator=g).to(ydt)
+    dres = torch.randn(rows, d, device=DEV, generator=g).to(xdt)
+    y, mean, rstd = nb.ln_fwd(x, gam, bet, 1e-5, ydt)
+    xr = x.double().requires_grad_(True)
+    gr, br = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    ref = F.layer_norm(xr, (d,), gr, br, 1e-5)
+    ref.backward(dy.double())
+    tol_y = 2.0 ** -8 * ref.abs().max().item() if ydt == BF else 2e-6 * max(1.0, ref.abs().max().item())
+    assert _err(y, ref) <= tol_y
+    assert _err(mean, xr.detach().mean(1)) < 1e-5 and _err(rstd * xr.detach().var(1, unbiased=False).add(1e-5).sqrt(), torch.ones(rows, device=DEV)) < 1e-5
+    dx, dgam, dbet = nb.ln_bwd(dy, x, gam, mean, rstd, dres)
+    want = xr.grad + dres.double()
+    tol_dx = 2.0 ** -8 * want.abs().max().item() if xdt == BF else 1e-5 * max(1.0, want.abs().max().item())
+    assert _err(dx, want) <= tol_dx
+    assert _err(dgam, gr.grad) <= 1e-5 * max(1.0, gr.grad.abs().max().item()) * rows ** 0.5
+    assert _err(dbet, br.grad) <= 1e-5 * max(1.0, br.grad.abs().max().item()) * rows ** 0.5
+    dx0, _, _ = nb.ln_bwd(dy, x, gam, mean, rstd, None)                       # no skip gradient
+    assert _err(dx0, xr.grad) <= tol_dx
+    a = nb.ln_bwd(dy, x, gam, mean, rstd, dres)                                # deterministic
+    assert torch.equal(a[1], dgam) and torch.equal(a[2], dbet) and torch.equal(a[0], dx)
+
+
+def test_layernorm_refuses_bad_shapes():
+    x = torch.randn(4, 12, device=DEV)
+    with pytest.raises(GtaError):
+        nb.ln_fwd(x, torch.ones(12, device=DEV), torch.zeros(12, device=DEV), 1e-5, BF)
+    with pytest.raises(GtaError):
+        nb.ln_fwd(torch.randn(4, 16), torch.ones(16), torch.zeros(16), 1e-5, BF)      # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize("dt", [torch.float32, BF])
+def test_gelu_and_colsum(dt):
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = (torch.randn(301, 1032, device=DEV, generator=g) * 2).to(dt)
+    dy = torch.randn(301, 1032, device=DEV, generator=g).to(dt)
+    xr = x.double().requires_grad_(True)
+    yr = F.gelu(xr)
+    yr.backward(dy.double())
+    tol = 2.0 ** -8 if dt == BF else 2e-6
+    assert _err(nb.gelu_fwd(x), yr) <= tol * yr.abs().max().item()
+    assert _err(nb.gelu_bwd(dy, x), xr.grad) <= tol * xr.grad.abs().max().item()
+    want = x.double().sum(0)
+    assert _err(nb.colsum(x), want) <= 1e-5 * x.double().abs().sum(0).max().item()
+    assert _err(nb.colsum(x[:, 8:520]), want[8:520]) <= 1e-5 * x.double().abs().sum(0).max().item()   # strided rows
+    big = torch.randn(5000, 3072, device=DEV, generator=g).to(dt)
+    assert _err(nb.colsum(big), big.double().sum(0)) <= 1e-5 * big.double().abs().sum(0).max().item()
+    assert torch.equal(nb.colsum(big), nb.colsum(big))
+
+
+@pytest.mark.parametrize("cdt", [BF, torch.float32])
+def test_gemm_epilogues(cdt):
+    """Every form the block uses, row-major, against fp64 matmul."""
+    g = torch.Generator(device=DEV).manual_seed(11)
+    M, K, N = 200, 72, 136
+    a = torch.randn(M, K, device=DEV, generator=g).to(cdt)
+    W = (torch.randn(N, K, device=DEV, generator=g) * K ** -0.5).to(cdt)
+    b = torch.randn(N, device=DEV, generator=g) * 0.3
+    skip = torch.randn(M, N, device=DEV, generator=g)
+    ref = a.double() @ W.double().t()
+    tol = (2.0 ** -8 if cdt == BF else 1e-5) * ref.abs().max().item()
+    assert _err(nb.gemm(a, W, trans_b=True), ref) <= tol                                             # x W^T
+    assert _err(nb.gemm(a, W, trans_b=True, epilogue=nb.EPI_BIAS, bias=b), ref + b) <= 1.5 * tol      # + bias
+    y = nb.gemm(a, W, trans_b=True, epilogue=nb.EPI_BIAS, bias=b, c=skip, beta=1.0, out_dtype=torch.float32)
+    assert y.dtype == torch.float32 and _err(y, ref + b + skip) <= 1e-5 * ref.abs().max().item() + 1e-5   # + skip, fp32 out
+    h = nb.gemm(a, W, trans_b=True, epilogue=nb.EPI_BIAS_GELU, bias=b)                                # tanh-form GELU
+    assert _err(h, F.gelu(ref + b, approximate="tanh")) <= 1.5 * tol
+    assert _err(h, F.gelu(ref + b)) <= 1.5 * tol + 5e-4
+    dout = torch.randn(M, N, device=DEV, generator=g).to(cdt)
+    assert _err(nb.gemm(dout, W), dout.double() @ W.double()) <= tol * 4                              # dgrad
+    dW = nb.gemm(dout, a, trans_a=True, out_dtype=torch.float32)                                      # wgrad, fp32 out
+    want = dout.double().t() @ a.double()
+    assert dW.dtype == torch.float32 and _err(dW, want) <= 1e-5 * want.abs().max().item() * (30 if cdt == BF else 1)
+    with pytest.raises(GtaError):
+        nb.gemm(a, W)                                                                                 # inner dimensions differ
+
+
+def _transformer(cross, seed=0):
+    torch.manual_seed(seed)
+    f_dims = {"triv": 0, "se3": 32, "so3": 0, "so2": 32}
+    ak = {"f_dims": f_dims, "so2": 8, "so3": 0, "max_freq_h": 1, "max_freq_w": 1}
+    tr = gta_amd.Transformer(128, 2, 2, 64, 256, 0.0, not cross, 96 if cross else None, False,
+                             {"method": {"name": "gta", "args": ak}}).to(DEV)
+    for n, p in tr.named_parameters():                      # biases and norms away from their trivial initial values
+        if n.endswith("bias") or "norm" in n:
+            with torch.no_grad():
+                p.add_(torch.randn_like(p) * 0.1)
+    B, V, hw = 2, 3, 6
+    gen = torch.Generator().manual_seed(3)
+    ex = {"input_transforms": synth.random_extrinsics(B, V, gen).to(DEV),
+          "input_coord": torch.rand(B, V, hw, hw, 2, generator=gen).to(DEV)}
+    gta_amd.pre_compute_reps_encoder(ak, ex)
+    if cross:
+        ex["target_transforms"] = synth.random_extrinsics(B, 1, gen).to(DEV)
+        ex["target_coord"] = torch.rand(B, 40, 2, generator=gen).to(DEV)
+        gta_amd.pre_compute_reps_decoder(ak, ex)
+    x = torch.randn(B, 40 if cross else V * hw * hw, 128, device=DEV)
+    z = torch.randn(B, V * hw * hw, 96, device=DEV) if cross else None
+    return tr, ex, x, z
+
+
+def _run(tr, ex, x, z, fused_on, autocast):
+    layers.FUSED_BLOCKS = fused_on
+    try:
+        for p in tr.parameters():
+            p.grad = None
+        x = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=BF, enabled=autocast):
+            y = tr(x, z, ex)
+        w = torch.randn(y.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+        (y.float() * w).sum().backward()
+        torch.cuda.synchronize()
+        return y.detach().float(), x.grad.clone(), {n: p.grad.clone() for n, p in tr.named_parameters()}
+    finally:
+        layers.FUSED_BLOCKS = True
+
+
+@pytest.mark.parametrize("cross", [False, True])
+@pytest.mark.parametrize("autocast", [False, True])
+def test_fused_transformer_matches_modulewise(cross, autocast):
+    """Same weights, same inputs: fused blocks vs LayerNorm / Linear / GELU modules + autograd, forward and all gradients."""
+    tr, ex, x, z = _transformer(cross)
+    y0, dx0, g0 = _run(tr, ex, x, z, False, False)                 # fp32 module-by-module: the yardstick
+    y1, dx1, g1 = _run(tr, ex, x, z, True, autocast)
+    rel = 3e-2 if autocast else 3e-3       # fp32: same arithmetic; only summation orders and the bf16 roundings they flip in the attention kernel differ
+    st = C.err_stats(y1.cpu(), y0.cpu())
+    assert st["finite"] and st["rel_rms"] < rel, st
+    st = C.err_stats(dx1.cpu(), dx0.cpu())
+    assert st["finite"] and st["rel_rms"] < 2 * rel, st
+    for n in g0:
+        st = C.err_stats(g1[n].float().cpu(), g0[n].cpu())
+        assert st["finite"], (n, st)
+        if n.endswith("trans_coeff"):
+            continue                                               # cancellation-dominated scalar (operator tests)
+        assert st["max_abs"] <= (8e-2 if autocast else 4e-2) * max(st["ref_max"], 1e-3) + 1e-5, (n, st)
+
+
+def test_fused_path_is_taken_and_launch_count():
+    """The fused layer issues 8 kernels beside the attention operator's; the module path under autocast many more."""
+    tr, ex, x, z = _transformer(False)
+    calls = []
+    orig = {n: getattr(nb, n) for n in ("ln_fwd", "gemm", "gelu_fwd")}
+    for n, f in orig.items():
+        setattr(nb, n, (lambda n_, f_: lambda *a, **k: (calls.append(n_), f_(*a, **k))[1])(n, f))
+    try:
+        with torch.no_grad(), torch.autocast("cuda", dtype=BF):
+            tr(x, z, ex)
+    finally:
+        for n, f in orig.items():
+            setattr(nb, n, f)
+    per_layer = ["ln_fwd", "gemm", "gemm", "ln_fwd", "gemm", "gemm"]     # bf16 inference: GELU in the epilogue
+    assert calls == per_layer * 2, calls
+
+
+def test_inference_gelu_epilogue_close_to_exact():
+    tr, ex, x, z = _transformer(False)
+    with torch.no_grad(), torch.autocast("cuda", dtype=BF):
+        y_epi = tr(x, z, ex).float()
+        fused.GELU_EPILOGUE = False
+        try:
+            y_exact = tr(x, z, ex).float()
+        finally:
+            fused.GELU_EPILOGUE = True
+    assert C.err_stats(y_epi.cpu(), y_exact.cpu())["rel_rms"] < 3e-3
+
+
+def test_weight_cast_cache_follows_updates():
+    tr, ex, x, z = _transformer(False)
+    with torch.no_grad(), torch.autocast("cuda", dtype=BF):
+        y0 = tr(x, z, ex).float()
+        w = tr.layers[0][1].fn.net[0].weight
+        w.mul_(1.5)                                   # in-place update bumps the version: the bf16 copy must be redone
+        y1 = tr(x, z, ex).float()
+    assert (y1 - y0).abs().max() > 1e-3

@@ -24,6 +24,35 @@ def test_library_exports_every_declared_symbol():
     assert lib.gta_sizeof_attn_desc() == ctypes.sizeof(native.GtaAttnDesc)
 
 
+def test_block_library_loads_and_exports_declared_symbols():
+    """include/gta_block.h <-> libgta_block.so <-> gta_amd/native_block.py (no compute without a GPU)."""
+    from gta_amd import native_block as nb
+    lib = nb.lib()
+    hdr = open(nb.LIB_PATH.replace("gta_amd/csrc/libgta_block.so", "include/gta_block.h")).read()
+    declared = set(re.findall(r"^(?:int|int64_t|void|const char\*)\s+(gta_[a-z0-9_]+)\s*\(", hdr, re.M))
+    assert declared == set(nb.ABI_SYMBOLS), declared ^ set(nb.ABI_SYMBOLS)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert lib.gta_block_abi_version() == nb.BLOCK_ABI_VERSION
+    assert lib.gta_sizeof_gemm_desc() == ctypes.sizeof(nb.GtaGemmDesc)
+    assert lib.gta_gemm_workspace_bytes() == 32 << 20
+    assert lib.gta_ln_bwd_workspace_bytes(40960, 768) == 1024 * 2 * 768 * 4
+    # argument checks run before anything touches a device
+    assert lib.gta_ln_fwd(None, 0, None, None, 1e-5, 4, 8, None, 0, None, None, None) == -1
+    d = nb.GtaGemmDesc()
+    assert lib.gta_gemm(ctypes.byref(d), None, None, None, None, None, None, None, 0, None) == -1
+    with pytest.raises(native.GtaError):
+        nb.ln_fwd(torch.zeros(4, 16), torch.ones(16), torch.zeros(16), 1e-5, torch.bfloat16)     # CPU tensors: no fallback
+
+
+def test_fused_blocks_do_not_engage_off_gpu():
+    """On CPU tensors the Transformer keeps the module-by-module path (and the attention operator then refuses)."""
+    from gta_amd import fused
+    assert fused.compute_dtype(torch.zeros(2, 3, 8)) is None
+    assert fused.norm_ok(torch.nn.LayerNorm(48)) and not fused.norm_ok(torch.nn.LayerNorm(20))
+    assert not fused.norm_ok(torch.nn.LayerNorm(48, elementwise_affine=False))
+
+
 def _desc(dh=96, f=None, L=2, **kw):
     f = f or {"se3": 48, "so3": 24, "so2": 24}
     q = torch.empty(2, 8, 1280, dh)
