@@ -160,6 +160,39 @@ def _check_tables(q, k, f_dims, Nq, Nk, vrep_q, vrep_k, cs_q, cs_k, coord_q, coo
     native.check_scalar("tau", ta, dev)
 
 
+class _SplitPacked(torch.autograd.Function):
+    """[B,T,n,H,dh] packed projection -> n strided [B,H,T,dh] views (layers.py:389,394-395), whose backward hands the
+    attention backward's packed gradient buffer straight through (``backward._grad_buffers``) instead of letting autograd
+    assemble it from three zero-filled scatters and two adds."""
+
+    @staticmethod
+    def forward(ctx, packed):
+        ctx.pshape = packed.shape
+        return tuple(packed[:, :, i].permute(0, 2, 1, 3) for i in range(packed.shape[2]))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        from .backward import packed_slices
+        base = getattr(grads[0], "_base", None) if grads[0] is not None else None
+        if (base is not None and all(g is not None and getattr(g, "_base", None) is base for g in grads)
+                and tuple(base.shape) == tuple(ctx.pshape) and base.is_contiguous() and packed_slices(grads)):
+            return base
+        B, T, n, H, dh = ctx.pshape
+        ref = next(g for g in grads if g is not None)
+        out = torch.empty(ctx.pshape, device=ref.device, dtype=ref.dtype)
+        for i, g in enumerate(grads):
+            if g is None:
+                out[:, :, i].zero_()
+            else:
+                out[:, :, i].copy_(g.permute(0, 2, 1, 3))
+        return out
+
+
+def split_packed(packed: torch.Tensor):
+    """``packed`` [B,T,n,H,dh] -> n views [B,H,T,dh] (no copy in either direction when the consumer is ``gta_attention``)."""
+    return _SplitPacked.apply(packed)
+
+
 class _GtaAttn(torch.autograd.Function):
     flash_events = None     # (start, end) torch.cuda.Event pair set by bench.py, else None
 

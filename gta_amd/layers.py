@@ -132,7 +132,7 @@ class Attention(nn.Module):
         kv_cache = None
         if z is None:
             qkv = (self.to_qkv(x) if q_packed is None else q_packed).view(B, Tq, 3, H, dh)      # layers.py:389
-            q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))   # strided views, no copy
+            q, k, v = _gta.split_packed(qkv)                                  # strided views, no copy (nor in the backward)
         else:
             q = (self.to_q(x) if q_packed is None else q_packed).view(B, Tq, H, dh).permute(0, 2, 1, 3)   # layers.py:391-392
             # chunked decode (srt.render_image): the key side of a cross-attention layer does not change between
@@ -143,7 +143,7 @@ class Attention(nn.Module):
                 k, v = kv_cache["kv"]
             else:
                 kv = self.to_kv(z).view(B, z.shape[1], 2, H, dh)
-                k, v = (kv[:, :, i].permute(0, 2, 1, 3) for i in range(2))
+                k, v = _gta.split_packed(kv)
                 if kv_cache is not None:
                     kv_cache["kv"] = (k, v)
         return q, k, v, kv_cache

@@ -204,3 +204,38 @@ def test_weight_cast_cache_follows_updates():
         w.mul_(1.5)                                   # in-place update bumps the version: the bf16 copy must be redone
         y1 = tr(x, z, ex).float()
     assert (y1 - y0).abs().max() > 1e-3
+
+
+def test_packed_projection_gradient_matches_separate_tensors():
+    """dq, dk, dv written by the attention backward as slices of one packed buffer (the gradient of ``to_qkv``'s output)
+    equal the gradients of separately stored q, k, v; same for the packed K/V projection of cross-attention."""
+    from gta_amd import gta as G
+    f_dims = {"triv": 0, "se3": 32, "so3": 0, "so2": 32}
+    q, k, v, ex, ak, cross = C.synth_inputs(2, 2, 3, 40, 3, 40, f_dims, 8, 0, torch.float32, seed=2)
+    ex = {n: t.to(DEV) for n, t in ex.items()}
+    gta_amd.pre_compute_reps_encoder(ak, ex)
+    packed_reps = G.pack_reps(ex, f_dims)
+    tc = torch.tensor([0.01], device=DEV)
+    B, H, T, dh = q.shape
+    w = torch.randn(B, H, T, dh, device=DEV)
+
+    def run(qq, kk, vv):
+        out = G.gta_attention(qq, kk, vv, f_dims, packed_reps, so3_degree=0, trans_coeff=tc, scale=dh ** -0.5)
+        (out.float() * w).sum().backward()
+
+    for dt in (torch.float32, BF):
+        leaves = [t.to(DEV).to(dt).clone().requires_grad_(True) for t in (q, k, v)]
+        run(*leaves)
+        qkv = torch.stack([t.detach().permute(0, 2, 1, 3) for t in leaves], dim=2).contiguous().requires_grad_(True)   # [B,T,3,H,dh]
+        run(*G.split_packed(qkv))
+        same = lambda a, b: C.err_stats(a.float(), b.float())["rel_rms"] < (2e-3 if dt == BF else 2e-5)   # the kernels pick
+        # their plan from the strides, so the two layouts may differ in summation order, not in values
+        for i, t in enumerate(leaves):
+            assert same(qkv.grad[:, :, i].permute(0, 2, 1, 3), t.grad), (dt, i)
+        # packed K/V only (cross-attention: layers.py:394-395)
+        ql = leaves[0].detach().clone().requires_grad_(True)
+        kv = torch.stack([t.detach().permute(0, 2, 1, 3) for t in leaves[1:]], dim=2).contiguous().requires_grad_(True)
+        run(ql, *G.split_packed(kv))
+        assert same(ql.grad, leaves[0].grad)
+        for i, t in enumerate(leaves[1:]):
+            assert same(kv.grad[:, :, i].permute(0, 2, 1, 3), t.grad), (dt, "kv", i)
