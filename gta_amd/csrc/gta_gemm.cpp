@@ -6,9 +6,16 @@
 // Bias vectors (length = rows of the column-major D = our n) therefore broadcast over our rows, as nn.Linear needs.
 //
 // State: one hipBLASLt handle and one descriptor set + algorithm per distinct GtaGemmDesc, per host thread.
+//
+// Algorithm choice: hipBLASLt's first heuristic answer is often not its fastest kernel for the long-K weight-gradient
+// shapes of this block (M = N ~ 768..2304, K = 40960 tokens: 270 us where another candidate takes 160).  The first call
+// of a shape therefore times the top TUNE_CANDIDATES answers on the caller's own buffers (two runs each, stream events)
+// and keeps the fastest; GTA_GEMM_TUNE=0 in the environment keeps the first answer.  Tuning is skipped for in-place
+// accumulation (C == D with beta != 0), where repeated runs would change the result.
 #include <hip/hip_runtime.h>
 #include <hipblaslt/hipblaslt.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <map>
 #include <string>
@@ -18,11 +25,15 @@
 namespace {
 
 constexpr int64_t WORKSPACE_BYTES = 32ll << 20;
+constexpr int TUNE_CANDIDATES = 16;
 
 struct Plan {
     hipblasLtMatmulDesc_t op = nullptr;
     hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, lc = nullptr, ld = nullptr;
     hipblasLtMatmulAlgo_t algo;
+    hipblasLtMatmulHeuristicResult_t cand[TUNE_CANDIDATES];
+    int n_cand = 0;
+    bool tuned = false;
     size_t ws = 0;
     bool ok = false;
     int status = 0;
@@ -106,17 +117,54 @@ void build_plan(Plan& p, hipblasLtHandle_t h, const GtaGemmDesc& g) {
     LT(hipblasLtMatmulPreferenceCreate(&pref));
     const uint64_t max_ws = WORKSPACE_BYTES;
     hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &max_ws, sizeof(max_ws));
-    hipblasLtMatmulHeuristicResult_t res[1];
     int found = 0;
-    hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(h, p.op, p.la, p.lb, p.lc, p.ld, pref, 1, res, &found);
+    hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(h, p.op, p.la, p.lb, p.lc, p.ld, pref, TUNE_CANDIDATES, p.cand, &found);
     hipblasLtMatmulPreferenceDestroy(pref);
     if (st != HIPBLAS_STATUS_SUCCESS || found < 1) {
         p.status = st != HIPBLAS_STATUS_SUCCESS ? (int)st : (int)HIPBLAS_STATUS_NOT_SUPPORTED;
         return;
     }
-    p.algo = res[0].algo;
-    p.ws = res[0].workspaceSize;
+    p.n_cand = found;
+    p.algo = p.cand[0].algo;
+    p.ws = p.cand[0].workspaceSize;
     p.ok = true;
+}
+
+bool tuning_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("GTA_GEMM_TUNE");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
+// times every candidate on the caller's buffers and keeps the fastest (see the file comment)
+void tune_plan(Plan& p, hipblasLtHandle_t h, const float* alpha, const float* beta, const void* a_lt, const void* b_lt,
+               const void* c, void* d, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    p.tuned = true;
+    if (p.n_cand < 2) return;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess) return;
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return; }
+    float best = 1e30f;
+    int best_i = 0;
+    for (int i = 0; i < p.n_cand; ++i) {
+        if (p.cand[i].workspaceSize > workspace_bytes) continue;
+        bool ok = true;
+        float ms = 1e30f;
+        for (int r = 0; r < 3 && ok; ++r) {                     // the first run of a kernel pays its code load
+            if (r == 1) ok = hipEventRecord(e0, stream) == hipSuccess;
+            ok = ok && hipblasLtMatmul(h, p.op, alpha, a_lt, p.la, b_lt, p.lb, beta, c, p.lc, d, p.ld, &p.cand[i].algo, workspace,
+                                 workspace_bytes, stream) == HIPBLAS_STATUS_SUCCESS;
+        }
+        if (!ok || hipEventRecord(e1, stream) != hipSuccess) continue;
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) continue;
+        if (ms < best) { best = ms; best_i = i; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    p.algo = p.cand[best_i].algo;
+    p.ws = p.cand[best_i].workspaceSize;
 }
 
 thread_local char g_msg[160];
@@ -170,6 +218,12 @@ int gta_gemm(const GtaGemmDesc* desc, const void* a, const void* b, const void* 
         if (hipblasLtMatmulDescSetAttribute(p.op, HIPBLASLT_MATMUL_DESC_EPILOGUE_AUX_POINTER, &ap, sizeof(ap)) != HIPBLAS_STATUS_SUCCESS) return GTA_E_LAUNCH;
     }
     const float alpha = g.alpha, beta = g.beta;
+    if (!p.tuned) {
+        if (tuning_enabled() && !(c == d && beta != 0.f))
+            tune_plan(p, ts.handle, &alpha, &beta, b, a, c ? c : d, d, workspace, (size_t)workspace_bytes, static_cast<hipStream_t>(stream));
+        else
+            p.tuned = true;
+    }
     hipblasStatus_t st = hipblasLtMatmul(ts.handle, p.op, &alpha, b, p.la, a, p.lb, &beta, c ? c : d, p.lc, d, p.ld, &p.algo,
                                          workspace, (size_t)workspace_bytes, static_cast<hipStream_t>(stream));
     if (st != HIPBLAS_STATUS_SUCCESS) { ts.last_status = (int)st; return GTA_E_LAUNCH; }

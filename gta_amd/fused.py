@@ -66,6 +66,20 @@ def _rows(x: torch.Tensor) -> torch.Tensor:
     return x.reshape(-1, x.shape[-1]) if x.is_contiguous() else x.contiguous().view(-1, x.shape[-1])
 
 
+def _weight_grads(g2: torch.Tensor, a2: torch.Tensor, want_w: bool, want_b: bool, wdtype: torch.dtype):
+    """(dW = g2^T a2, db = column sums of g2) for y = a2 W^T + b: the hand-written TN kernel where it applies (bf16
+    operands, fp32 master weights, tile-aligned shapes), else hipBLASLt's transposed GEMM + the column-sum kernel."""
+    dW = db = None
+    if want_w and wdtype == torch.float32 and nb.wgrad_supported(g2, a2):
+        dW, db = nb.wgrad(g2, a2, want_b)
+        return dW, db
+    if want_w:
+        dW = nb.gemm(g2, a2, trans_a=True, out_dtype=wdtype)
+    if want_b:
+        db = nb.colsum(g2).to(wdtype)
+    return dW, db
+
+
 class _LNLinear(torch.autograd.Function):
     """(x W^T + b of LayerNorm(x), x): the second output is x itself, handed to the block's skip connection so that the
     gradient arriving through the skip is added inside the LayerNorm backward kernel instead of by autograd."""
@@ -90,8 +104,7 @@ class _LNLinear(torch.autograd.Function):
         if d2.dtype != ctx.cdt:
             d2 = d2.to(ctx.cdt)
         y, _, _ = nb.ln_fwd(x2, gamma.detach(), beta.detach(), ctx.eps, ctx.cdt, want_stats=False)     # recomputed, not stored
-        dW = nb.gemm(d2, y, trans_a=True, out_dtype=ctx.wdtype) if ctx.needs_input_grad[3] else None
-        db = nb.colsum(d2) if ctx.has_bias and ctx.needs_input_grad[4] else None
+        dW, db = _weight_grads(d2, y, ctx.needs_input_grad[3], ctx.has_bias and ctx.needs_input_grad[4], ctx.wdtype)
         dy = nb.gemm(d2, Wc)
         dres = None
         if dskip is not None:
@@ -99,8 +112,7 @@ class _LNLinear(torch.autograd.Function):
             if dres.dtype != x2.dtype:
                 dres = dres.to(x2.dtype)
         dx, dgamma, dbeta = nb.ln_bwd(dy, x2, gamma.detach(), mean, rstd, dres)
-        return (dx.view(ctx.xshape), dgamma.to(gamma.dtype), dbeta.to(beta.dtype), dW,
-                db.to(ctx.wdtype) if db is not None else None, None, None, None)
+        return dx.view(ctx.xshape), dgamma.to(gamma.dtype), dbeta.to(beta.dtype), dW, db, None, None, None
 
 
 class _LinearSkip(torch.autograd.Function):
@@ -129,8 +141,7 @@ class _LinearSkip(torch.autograd.Function):
         da = nb.gemm(dc, Wc).view(ctx.ashape) if ctx.needs_input_grad[0] else None
         if da is not None and da.dtype != ctx.adtype:
             da = da.to(ctx.adtype)
-        dW = nb.gemm(dc, a2, trans_a=True, out_dtype=ctx.wdtype) if ctx.needs_input_grad[1] else None
-        db = nb.colsum(dc).to(ctx.wdtype) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        dW, db = _weight_grads(dc, a2, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2], ctx.wdtype)
         return da, dW, db, dout, None, None
 
 
@@ -163,14 +174,12 @@ class _FeedForwardSkip(torch.autograd.Function):
         x2, gamma, beta, mean, rstd, W1c, W2c, pre, h = ctx.saved_tensors
         d2 = _rows(dout)
         dc = d2 if d2.dtype == ctx.cdt else d2.to(ctx.cdt)
-        dW2 = nb.gemm(dc, h, trans_a=True, out_dtype=ctx.wdtype) if ctx.needs_input_grad[5] else None
-        db2 = nb.colsum(dc).to(ctx.wdtype) if ctx.has_b2 and ctx.needs_input_grad[6] else None
+        dW2, db2 = _weight_grads(dc, h, ctx.needs_input_grad[5], ctx.has_b2 and ctx.needs_input_grad[6], ctx.wdtype)
         dh = nb.gemm(dc, W2c)
         dpre = nb.gelu_bwd(dh, pre)
         del dh
         y, _, _ = nb.ln_fwd(x2, gamma.detach(), beta.detach(), ctx.eps, ctx.cdt, want_stats=False)
-        dW1 = nb.gemm(dpre, y, trans_a=True, out_dtype=ctx.wdtype) if ctx.needs_input_grad[3] else None
-        db1 = nb.colsum(dpre).to(ctx.wdtype) if ctx.has_b1 and ctx.needs_input_grad[4] else None
+        dW1, db1 = _weight_grads(dpre, y, ctx.needs_input_grad[3], ctx.has_b1 and ctx.needs_input_grad[4], ctx.wdtype)
         dy = nb.gemm(dpre, W1c)
         dres = d2 if d2.dtype == x2.dtype else d2.to(x2.dtype)
         dx, dgamma, dbeta = nb.ln_bwd(dy, x2, gamma.detach(), mean, rstd, dres)

@@ -24,7 +24,7 @@ EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_AUX, EPI_DGELU, EPI_DGELU_BGRAD
 ABI_SYMBOLS = (
     "gta_ln_fwd", "gta_ln_bwd", "gta_ln_bwd_workspace_bytes", "gta_gelu_fwd", "gta_gelu_bwd", "gta_colsum",
     "gta_colsum_workspace_bytes", "gta_gemm", "gta_gemm_workspace_bytes", "gta_block_release", "gta_block_strerror",
-    "gta_block_abi_version", "gta_sizeof_gemm_desc",
+    "gta_block_abi_version", "gta_sizeof_gemm_desc", "gta_wgrad", "gta_wgrad_supported", "gta_wgrad_workspace_bytes",
 )
 
 
@@ -70,6 +70,11 @@ def lib():
         L.gta_gemm_workspace_bytes.restype = c_int64
         L.gta_gemm.argtypes = [ctypes.POINTER(GtaGemmDesc)] + [c_void_p] * 7 + [c_int64, c_void_p]
         L.gta_block_release.restype = None
+        L.gta_wgrad_supported.argtypes = [c_int64, c_int64, c_int64]
+        L.gta_wgrad_workspace_bytes.argtypes = [c_int64, c_int64, c_int64]
+        L.gta_wgrad_workspace_bytes.restype = c_int64
+        L.gta_wgrad.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                c_int64, c_void_p]
         _lib = L
     return _lib
 
@@ -197,3 +202,25 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out_
     check(lib().gta_gemm(ctypes.byref(desc), _ptr(a), _ptr(b), _ptr(c), _ptr(out), _ptr(bias), _ptr(aux), _ptr(ws), ws.numel(),
                          _stream(a)), f"gta_gemm(m={m}, n={n}, k={k}, epilogue={epilogue})")
     return out
+
+
+def wgrad_supported(g: torch.Tensor, x: torch.Tensor) -> bool:
+    return (g.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and g.dim() == 2 and x.dim() == 2
+            and g.stride(1) == 1 and x.stride(1) == 1 and g.stride(0) % 8 == 0 and x.stride(0) % 8 == 0
+            and bool(lib().gta_wgrad_supported(g.shape[0], g.shape[1], x.shape[1])))
+
+
+def wgrad(g: torch.Tensor, x: torch.Tensor, want_bias: bool):
+    """g [m,n] bf16 (d out), x [m,k] bf16 (layer input) -> (dW [n,k] fp32 = g^T x, db [n] fp32 = column sums of g or None)."""
+    _need_cuda(g, x)
+    m, n = g.shape
+    k = x.shape[1]
+    if x.shape[0] != m:
+        raise GtaError(f"wgrad: {tuple(g.shape)} vs {tuple(x.shape)}")
+    dw = torch.empty(n, k, device=g.device, dtype=torch.float32)
+    db = torch.empty(n, device=g.device, dtype=torch.float32) if want_bias else None
+    nbytes = lib().gta_wgrad_workspace_bytes(m, n, k)
+    ws = torch.empty(max(nbytes, 16), device=g.device, dtype=torch.uint8)
+    check(lib().gta_wgrad(_ptr(g), g.stride(0), _ptr(x), x.stride(0), m, n, k, _ptr(dw), _ptr(db), _ptr(ws), nbytes, _stream(g)),
+          f"gta_wgrad(m={m}, n={n}, k={k})")
+    return dw, db

@@ -107,6 +107,19 @@ int64_t gta_gemm_workspace_bytes(void);      /* what gta_gemm wants for hipBLASL
 int gta_gemm(const GtaGemmDesc* desc, const void* a, const void* b, const void* c, void* d,
              void* bias, void* aux, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Weight gradient of a Linear, hand-written (gta_wgrad.hip):  dW[n,k] = sum_m G[m,n] X[m,k],  db[n] = sum_m G[m,n]
+ *   G = d(out) [m,n] bf16 (leading dimension ldg), X = the layer's input [m,k] bf16 (ldx); dW [n,k] fp32 contiguous,
+ *   dbias [n] fp32 or NULL.  The reduction index m (batch x tokens) is the slow index of both operands -- the shape
+ *   hipBLASLt is weakest at.  Split over m across the chip, partial tiles reduced in a fixed order (deterministic).
+ *   Supported when m % 64 == 0, n % 256 == 0, k % 256 == 0 (gta_wgrad_supported); else use gta_gemm(trans_a) + gta_colsum.
+ *   workspace: gta_wgrad_workspace_bytes(m, n, k).
+ * --------------------------------------------------------------------------------------------------------------- */
+int gta_wgrad_supported(int64_t m, int64_t n, int64_t k);
+int64_t gta_wgrad_workspace_bytes(int64_t m, int64_t n, int64_t k);
+int gta_wgrad(const void* g, int64_t ldg, const void* x, int64_t ldx, int64_t m, int64_t n, int64_t k,
+              float* dw, float* dbias, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* drops this thread's hipBLASLt handle and algorithm cache */
 void gta_block_release(void);
 

@@ -239,3 +239,22 @@ def test_packed_projection_gradient_matches_separate_tensors():
         assert same(ql.grad, leaves[0].grad)
         for i, t in enumerate(leaves[1:]):
             assert same(kv.grad[:, :, i].permute(0, 2, 1, 3), t.grad), (dt, "kv", i)
+
+
+@pytest.mark.parametrize("m,n,k", [(256, 256, 256), (1280, 512, 256), (4160, 768, 256), (64, 256, 512), (40960, 768, 768)])
+def test_wgrad_kernel(m, n, k):
+    """The hand-written TN weight-gradient kernel (gta_wgrad) against fp64, with and without the fused bias gradient,
+    on strided operands (slices of wider matrices, as the packed projections are)."""
+    g = torch.Generator(device=DEV).manual_seed(m + n + k)
+    G = torch.randn(m, n + 64, device=DEV, generator=g).to(BF)[:, 32:32 + n]
+    X = torch.randn(m, k + 8, device=DEV, generator=g).to(BF)[:, :k]
+    assert nb.wgrad_supported(G, X)
+    want = G.double().t() @ X.double()
+    wb = G.double().sum(0)
+    scale = (m ** 0.5)
+    dw, db = nb.wgrad(G, X, True)
+    assert dw.dtype == torch.float32 and _err(dw, want) <= 2e-5 * scale * 6
+    assert _err(db, wb) <= 2e-5 * scale * 6
+    dw2, none = nb.wgrad(G, X, False)
+    assert none is None and torch.equal(dw2, dw)                      # deterministic, bias leg changes nothing
+    assert not nb.wgrad_supported(G[:-1], X[:-1]) and not nb.wgrad_supported(G[:, :128], X)

@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--mlp", type=int, default=1536, help="MSN gta_so3: mlp_dim = attdim * 2 (encoder.py) = 1536")
     ap.add_argument("--layers", type=int, default=1)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--mode", default="both", choices=["both", "fused", "modules"])
+    ap.add_argument("--no-launch-count", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -72,10 +74,11 @@ def main():
             names[e.name] = names.get(e.name, 0) + 1
         return len(evs) / args.layers, names
 
-    for label, on in (("modules", False), ("fused", True), ("modules", False), ("fused", True)):
+    modes = [m for m in (("modules", False), ("fused", True)) if args.mode in ("both", m[0])]
+    for label, on in modes * 2:
         layers.FUSED_BLOCKS = on
         print(f"{label:8s} B={B} mlp={args.mlp}: forward {timeit(fwd):8.1f} us/layer   forward+backward {timeit(fwd_bwd):8.1f} us/layer")
-    for label, on in (("modules", False), ("fused", True)):
+    for label, on in ([] if args.no_launch_count else modes):
         layers.FUSED_BLOCKS = on
         for what, fn in (("forward", fwd), ("forward+backward", fwd_bwd)):
             try:
