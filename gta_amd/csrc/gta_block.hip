@@ -117,7 +117,7 @@ template <int GDT, int XDT, int NJ>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, int64_t rows, int d,
-                                                     const void* dres, void* dx, float* __restrict__ part) {
+                                                     const void* dres, void* dx, void* dx_bf16, float* __restrict__ part) {
     extern __shared__ float lds[];            // [4][2][d]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float ag[NJ][8], ab[NJ][8], gm[NJ][8];
@@ -166,6 +166,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
 #pragma unroll
                 for (int i = 0; i < 8; ++i) o[i] += rs * (g[j][i] - m1 - xh[j][i] * m2);
                 Vec8<XDT>::store(dx, base + e, o);
+                if (dx_bf16) Vec8<GTA_DTYPE_BF16>::store(dx_bf16, base + e, o);
             }
         }
     }
@@ -185,20 +186,31 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         part[(int64_t)blockIdx.x * 2 * d + c] = (lds[c] + lds[2 * d + c]) + (lds[4 * d + c] + lds[6 * d + c]);
 }
 
-// out[c] = sum_p part[p][c], p in a fixed order: 256 threads = 8 row groups x 32 columns, tree over the groups.
-__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int np, int n,
-                                                           float* __restrict__ out0, float* __restrict__ out1, int split) {
-    __shared__ float red[8][33];
+// out[c] = sum_p part[p][c], p in a fixed order: 1024 threads = 32 row groups x 32 columns, tree over the groups.
+__global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __restrict__ part, int np, int n,
+                                                            float* __restrict__ out0, float* __restrict__ out1, int split) {
+    __shared__ float red[32][33];
     const int cx = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cx;
-    float s = 0.f;
-    if (c < n)
-        for (int p = rg; p < np; p += 8) s += part[(int64_t)p * n + c];
-    red[rg][cx] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < n) {
+        int p = rg;
+        for (; p + 96 < np; p += 128) {                                   // four independent loads in flight
+            s0 += part[(int64_t)p * n + c];
+            s1 += part[(int64_t)(p + 32) * n + c];
+            s2 += part[(int64_t)(p + 64) * n + c];
+            s3 += part[(int64_t)(p + 96) * n + c];
+        }
+        for (; p < np; p += 32) s0 += part[(int64_t)p * n + c];
+    }
+    red[rg][cx] = (s0 + s1) + (s2 + s3);
     __syncthreads();
+    for (int w = 16; w >= 1; w >>= 1) {
+        if (rg < w) red[rg][cx] += red[rg + w][cx];
+        __syncthreads();
+    }
     if (rg == 0 && c < n) {
-        const float t = ((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx])) +
-                        ((red[4][cx] + red[5][cx]) + (red[6][cx] + red[7][cx]));
+        const float t = red[0][cx];
         if (c < split) out0[c] = t; else out1[c - split] = t;
     }
 }
@@ -320,15 +332,17 @@ int64_t gta_ln_bwd_workspace_bytes(int64_t rows, int32_t d) {
 }
 
 int gta_ln_bwd(const void* dy, int32_t dy_dtype, const void* x, int32_t x_dtype, const float* gamma, const float* mean,
-               const float* rstd, int64_t rows, int32_t d, const void* dres, void* dx, int32_t dx_dtype, float* dgamma,
-               float* dbeta, void* workspace, int64_t workspace_bytes, void* stream) {
+               const float* rstd, int64_t rows, int32_t d, const void* dres, void* dx, int32_t dx_dtype, void* dx_bf16,
+               float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace || rows <= 0 || d <= 0 ||
         !dtype_ok(dy_dtype) || !dtype_ok(x_dtype))
         return GTA_E_BADARG;
     if (dx_dtype != x_dtype) return GTA_E_UNSUPPORTED;            // the skip connection keeps the stream's type
     if (d % 8 != 0 || d > 4096) return GTA_E_UNSUPPORTED;
     if (workspace_bytes < gta_ln_bwd_workspace_bytes(rows, d)) return GTA_E_BADARG;
-    if (!aligned16(dy) || !aligned16(x) || !aligned16(dx) || !aligned16(gamma) || (dres && !aligned16(dres))) return GTA_E_BADARG;
+    if (!aligned16(dy) || !aligned16(x) || !aligned16(dx) || !aligned16(gamma) || (dres && !aligned16(dres)) ||
+        (dx_bf16 && !aligned16(dx_bf16)))
+        return GTA_E_BADARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int grid = ln_bwd_grid(rows);
     float* part = static_cast<float*>(workspace);
@@ -340,13 +354,13 @@ int gta_ln_bwd(const void* dy, int32_t dy_dtype, const void* x, int32_t x_dtype,
                 if (lds > 64 * 1024 &&
                     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                     return GTA_E_LAUNCH;
-                hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, rows, d, dres, dx, part);
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, rows, d, dres, dx, dx_bf16, part);
                 return launch_status();
             });
         });
     });
     if (rc != GTA_OK) return rc;
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((2 * d + 31) / 32), dim3(256), 0, s, part, grid, 2 * d, dgamma, dbeta, d);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((2 * d + 31) / 32), dim3(1024), 0, s, part, grid, 2 * d, dgamma, dbeta, d);
     return launch_status();
 }
 
@@ -394,7 +408,7 @@ int gta_colsum(const void* a, int32_t dtype, int64_t m, int32_t n, int64_t ld, f
         return launch_status();
     });
     if (rc != GTA_OK) return rc;
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((n + 31) / 32), dim3(256), 0, s, part, strips, n, out, out, n);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((n + 31) / 32), dim3(1024), 0, s, part, strips, n, out, out, n);
     return launch_status();
 }
 

@@ -62,8 +62,29 @@ def _bias_for(b: Optional[torch.Tensor], out_dtype: torch.dtype) -> Optional[tor
     return b if b.dtype in (torch.float32, out_dtype) else b.float()
 
 
+def _shaped(dx: torch.Tensor, shape) -> torch.Tensor:
+    """dx viewed in the input's shape, keeping the bf16 side copy attached (a view is a new Python object)."""
+    out = dx.view(shape)
+    side = getattr(dx, "_gta_bf16", None)
+    if side is not None:
+        out._gta_bf16 = (side[0].view(shape), side[1])      # a view shares its base's version counter
+    return out
+
+
 def _rows(x: torch.Tensor) -> torch.Tensor:
     return x.reshape(-1, x.shape[-1]) if x.is_contiguous() else x.contiguous().view(-1, x.shape[-1])
+
+
+def _in_compute_dtype(d2: torch.Tensor, dout: torch.Tensor, cdt: torch.dtype) -> torch.Tensor:
+    """The incoming gradient in the GEMMs' dtype: the bf16 copy the LayerNorm backward of the block downstream wrote
+    beside its fp32 result when there is one (``native_block.ln_bwd(bf16_copy=True)``), else a cast."""
+    if d2.dtype == cdt:
+        return d2
+    side = getattr(dout, "_gta_bf16", None)
+    if (side is not None and cdt == torch.bfloat16 and side[1] == dout._version and side[0].shape == dout.shape
+            and side[0].device == dout.device):
+        return side[0].view(d2.shape)
+    return d2.to(cdt)
 
 
 def _weight_grads(g2: torch.Tensor, a2: torch.Tensor, want_w: bool, want_b: bool, wdtype: torch.dtype):
@@ -92,18 +113,17 @@ class _LNLinear(torch.autograd.Function):
         b = _bias_for(bias, cdt)
         out = nb.gemm(y, Wc, trans_b=True, epilogue=nb.EPI_BIAS if b is not None else nb.EPI_NONE, bias=b)
         if need:
-            ctx.save_for_backward(x2, gamma, beta, mean, rstd, Wc)
+            ctx.save_for_backward(x2, gamma, beta, mean, rstd, Wc, y)       # y kept: 2 B per element against a 35 us recompute
             ctx.eps, ctx.cdt, ctx.has_bias, ctx.wdtype = eps, cdt, bias is not None, W.dtype
             ctx.xshape = x.shape
         return out.view(*x.shape[:-1], W.shape[0]), x
 
     @staticmethod
     def backward(ctx, dout, dskip):
-        x2, gamma, beta, mean, rstd, Wc = ctx.saved_tensors
+        x2, gamma, beta, mean, rstd, Wc, y = ctx.saved_tensors
         d2 = _rows(dout)
         if d2.dtype != ctx.cdt:
             d2 = d2.to(ctx.cdt)
-        y, _, _ = nb.ln_fwd(x2, gamma.detach(), beta.detach(), ctx.eps, ctx.cdt, want_stats=False)     # recomputed, not stored
         dW, db = _weight_grads(d2, y, ctx.needs_input_grad[3], ctx.has_bias and ctx.needs_input_grad[4], ctx.wdtype)
         dy = nb.gemm(d2, Wc)
         dres = None
@@ -111,8 +131,8 @@ class _LNLinear(torch.autograd.Function):
             dres = _rows(dskip)
             if dres.dtype != x2.dtype:
                 dres = dres.to(x2.dtype)
-        dx, dgamma, dbeta = nb.ln_bwd(dy, x2, gamma.detach(), mean, rstd, dres)
-        return dx.view(ctx.xshape), dgamma.to(gamma.dtype), dbeta.to(beta.dtype), dW, db, None, None, None
+        dx, dgamma, dbeta = nb.ln_bwd(dy, x2, gamma.detach(), mean, rstd, dres, bf16_copy=ctx.cdt == torch.bfloat16)
+        return _shaped(dx, ctx.xshape), dgamma.to(gamma.dtype), dbeta.to(beta.dtype), dW, db, None, None, None
 
 
 class _LinearSkip(torch.autograd.Function):
@@ -137,7 +157,7 @@ class _LinearSkip(torch.autograd.Function):
     def backward(ctx, dout):
         a2, Wc = ctx.saved_tensors
         d2 = _rows(dout)
-        dc = d2 if d2.dtype == ctx.cdt else d2.to(ctx.cdt)
+        dc = _in_compute_dtype(d2, dout, ctx.cdt)
         da = nb.gemm(dc, Wc).view(ctx.ashape) if ctx.needs_input_grad[0] else None
         if da is not None and da.dtype != ctx.adtype:
             da = da.to(ctx.adtype)
@@ -164,26 +184,25 @@ class _FeedForwardSkip(torch.autograd.Function):
         out = nb.gemm(h, W2c, trans_b=True, epilogue=nb.EPI_BIAS if bb2 is not None else nb.EPI_NONE, bias=bb2, c=x2, beta=1.0,
                       out_dtype=x2.dtype)
         if need:
-            ctx.save_for_backward(x2, gamma, beta, mean, rstd, W1c, W2c, pre, h)
+            ctx.save_for_backward(x2, gamma, beta, mean, rstd, W1c, W2c, pre, h, y)
             ctx.eps, ctx.cdt, ctx.wdtype, ctx.xshape = eps, cdt, W1.dtype, x.shape
             ctx.has_b1, ctx.has_b2 = b1 is not None, b2 is not None
         return out.view(x.shape)
 
     @staticmethod
     def backward(ctx, dout):
-        x2, gamma, beta, mean, rstd, W1c, W2c, pre, h = ctx.saved_tensors
+        x2, gamma, beta, mean, rstd, W1c, W2c, pre, h, y = ctx.saved_tensors
         d2 = _rows(dout)
-        dc = d2 if d2.dtype == ctx.cdt else d2.to(ctx.cdt)
+        dc = _in_compute_dtype(d2, dout, ctx.cdt)
         dW2, db2 = _weight_grads(dc, h, ctx.needs_input_grad[5], ctx.has_b2 and ctx.needs_input_grad[6], ctx.wdtype)
         dh = nb.gemm(dc, W2c)
         dpre = nb.gelu_bwd(dh, pre)
         del dh
-        y, _, _ = nb.ln_fwd(x2, gamma.detach(), beta.detach(), ctx.eps, ctx.cdt, want_stats=False)
         dW1, db1 = _weight_grads(dpre, y, ctx.needs_input_grad[3], ctx.has_b1 and ctx.needs_input_grad[4], ctx.wdtype)
         dy = nb.gemm(dpre, W1c)
         dres = d2 if d2.dtype == x2.dtype else d2.to(x2.dtype)
-        dx, dgamma, dbeta = nb.ln_bwd(dy, x2, gamma.detach(), mean, rstd, dres)
-        return dx.view(ctx.xshape), dgamma.to(gamma.dtype), dbeta.to(beta.dtype), dW1, db1, dW2, db2, None, None, None
+        dx, dgamma, dbeta = nb.ln_bwd(dy, x2, gamma.detach(), mean, rstd, dres, bf16_copy=ctx.cdt == torch.bfloat16)
+        return _shaped(dx, ctx.xshape), dgamma.to(gamma.dtype), dbeta.to(beta.dtype), dW1, db1, dW2, db2, None, None, None
 
 
 def _need(*ts) -> bool:

@@ -61,7 +61,7 @@ def lib():
         L.gta_ln_bwd_workspace_bytes.argtypes = [c_int64, c_int32]
         L.gta_ln_bwd_workspace_bytes.restype = c_int64
         L.gta_ln_bwd.argtypes = [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
-                                 c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]
+                                 c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]
         L.gta_gelu_fwd.argtypes = [c_void_p, c_void_p, c_int32, c_int64, c_void_p]
         L.gta_gelu_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p]
         L.gta_colsum_workspace_bytes.argtypes = [c_int64, c_int32]
@@ -129,19 +129,23 @@ def ln_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
 
 
 def ln_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor,
-           dres: Optional[torch.Tensor]):
-    """-> (dx like x [= dres + LayerNorm backward], dgamma [d] fp32, dbeta [d] fp32)."""
+           dres: Optional[torch.Tensor], bf16_copy: bool = False):
+    """-> (dx like x [= dres + LayerNorm backward], dgamma [d] fp32, dbeta [d] fp32); with ``bf16_copy`` (fp32 x) the
+    kernel also writes dx in bf16, returned as ``dx._gta_bf16`` for the block upstream (gta_amd.fused)."""
     _need_cuda(dy, x)
     d = x.shape[-1]
     rows = x.numel() // d
     dx = torch.empty_like(x)
+    dxb = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16) if (bf16_copy and x.dtype == torch.float32) else None
     dgamma = torch.empty(d, device=x.device, dtype=torch.float32)
     dbeta = torch.empty(d, device=x.device, dtype=torch.float32)
     nbytes = lib().gta_ln_bwd_workspace_bytes(rows, d)
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
     check(lib().gta_ln_bwd(_ptr(dy), dtype_code(dy.dtype), _ptr(x), dtype_code(x.dtype), _ptr(gamma), _ptr(mean), _ptr(rstd),
-                           rows, d, _ptr(dres), _ptr(dx), dtype_code(dx.dtype), _ptr(dgamma), _ptr(dbeta), _ptr(ws), nbytes,
-                           _stream(x)), "gta_ln_bwd")
+                           rows, d, _ptr(dres), _ptr(dx), dtype_code(dx.dtype), _ptr(dxb), _ptr(dgamma), _ptr(dbeta), _ptr(ws),
+                           nbytes, _stream(x)), "gta_ln_bwd")
+    if dxb is not None:
+        dx._gta_bf16 = (dxb, dx._version)     # the version pins the copy to this content (an in-place accumulate bumps it)
     return dx, dgamma, dbeta
 
 

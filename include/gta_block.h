@@ -48,11 +48,13 @@ int gta_ln_fwd(const void* x, int32_t x_dtype, const float* gamma, const float* 
  *   dx = (dres ? dres : 0) + rstd * (g - mean_d(g) - xhat * mean_d(g * xhat)),  g = dy * gamma, xhat = (x - mean) * rstd
  *   dgamma[d] = sum_rows dy * xhat, dbeta[d] = sum_rows dy   (fixed summation order: deterministic)
  *   dres: gradient arriving through the skip connection (`fn(norm(x)) + x`), dtype dx_dtype, or NULL; may alias dx.
+ *   dx_bf16: optional second copy of dx in bf16 (NULL = none): the block upstream feeds its GEMMs from it, which saves
+ *   the separate fp32 -> bf16 cast kernel autocast would run on the residual-stream gradient.
  *   workspace: gta_ln_bwd_workspace_bytes(rows, d) bytes. */
 int64_t gta_ln_bwd_workspace_bytes(int64_t rows, int32_t d);
 int gta_ln_bwd(const void* dy, int32_t dy_dtype, const void* x, int32_t x_dtype, const float* gamma,
                const float* mean, const float* rstd, int64_t rows, int32_t d,
-               const void* dres, void* dx, int32_t dx_dtype, float* dgamma, float* dbeta,
+               const void* dres, void* dx, int32_t dx_dtype, void* dx_bf16, float* dgamma, float* dbeta,
                void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------

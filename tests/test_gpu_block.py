@@ -258,3 +258,21 @@ def test_wgrad_kernel(m, n, k):
     dw2, none = nb.wgrad(G, X, False)
     assert none is None and torch.equal(dw2, dw)                      # deterministic, bias leg changes nothing
     assert not nb.wgrad_supported(G[:-1], X[:-1]) and not nb.wgrad_supported(G[:, :128], X)
+
+
+def test_bf16_side_copy_of_the_stream_gradient():
+    """gta_ln_bwd's second output: dx in bf16 beside the fp32 result, consumed by the block upstream instead of a cast;
+    a copy whose tensor was modified in place afterwards (autograd accumulating into it) must not be used."""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(64, 256, device=DEV, generator=g)
+    gam, bet = torch.ones(256, device=DEV), torch.zeros(256, device=DEV)
+    y, mean, rstd = nb.ln_fwd(x, gam, bet, 1e-5, BF)
+    dy = torch.randn(64, 256, device=DEV, generator=g).to(BF)
+    dx, _, _ = nb.ln_bwd(dy, x, gam, mean, rstd, None, bf16_copy=True)
+    side, ver = dx._gta_bf16
+    assert side.dtype == BF and torch.equal(side, dx.to(BF)) and ver == dx._version
+    shaped = fused._shaped(dx, (4, 16, 256))
+    assert fused._in_compute_dtype(shaped.reshape(-1, 256), shaped, BF).data_ptr() == side.data_ptr()
+    shaped.add_(1.0)                                              # what an in-place gradient accumulation does
+    fresh = fused._in_compute_dtype(shaped.reshape(-1, 256), shaped, BF)
+    assert fresh.data_ptr() != side.data_ptr() and torch.equal(fresh, shaped.reshape(-1, 256).to(BF))
