@@ -250,28 +250,115 @@ BLK_DEV float dgelu_erf(float x) {
     return cdf + x * pdf;
 }
 
-template <int DT>
-__global__ __launch_bounds__(256) void gelu_fwd_kernel(const void* __restrict__ x, void* __restrict__ y, int64_t n8) {
+// ---------------------------------------------------------------------------------------------------------------
+// Dropout (nn.Dropout of to_out / FeedForward.net, source/layers.py:163,165,289).  The keep mask is never stored: it is a
+// pure function of (seed, element index) -- Philox4x32-10 keyed by the call's seed, counter = index / 4 -- regenerated by
+// the backward.  keep <=> random word >= p * 2^32; kept values are scaled by 1 / (1 - p).
+// ---------------------------------------------------------------------------------------------------------------
+struct Drop {
+    uint32_t k0, k1, thr;
+    float scale;
+};
+
+BLK_DEV void philox4(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t (&r)[4]) {
+    uint32_t c2 = 0u, c3 = 0u;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        c0 = h1 ^ c1 ^ k0; c1 = l1; c2 = h0 ^ c3 ^ k1; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
+}
+
+// keep factors (0 or 1/(1-p)) of the eight elements 8*i8 .. 8*i8+7
+BLK_DEV void keep8(const Drop& d, int64_t i8, float (&m)[8]) {
+    uint32_t r[4];
+    philox4((uint32_t)(2 * i8), (uint32_t)((2 * i8) >> 32), d.k0, d.k1, r);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[j] = r[j] >= d.thr ? d.scale : 0.f;
+    philox4((uint32_t)(2 * i8 + 1), (uint32_t)((2 * i8 + 1) >> 32), d.k0, d.k1, r);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[4 + j] = r[j] >= d.thr ? d.scale : 0.f;
+}
+
+template <int DT, bool DROP>
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const void* __restrict__ x, void* __restrict__ y, int64_t n8, Drop d) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
         float v[8];
         Vec8<DT>::load(x, i * 8, v);
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = gelu_erf(v[k]);
+        if (DROP) {
+            float m[8];
+            keep8(d, i, m);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] *= m[k];
+        }
         Vec8<DT>::store(y, i * 8, v);
     }
 }
 
-template <int DT>
+template <int DT, bool DROP>
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ x,
-                                                       void* __restrict__ dx, int64_t n8) {
+                                                       void* __restrict__ dx, int64_t n8, Drop d) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
         float v[8], g[8];
         Vec8<DT>::load(x, i * 8, v);
         Vec8<DT>::load(dy, i * 8, g);
 #pragma unroll
         for (int k = 0; k < 8; ++k) g[k] *= dgelu_erf(v[k]);
+        if (DROP) {
+            float m[8];
+            keep8(d, i, m);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g[k] *= m[k];
+        }
         Vec8<DT>::store(dx, i * 8, g);
     }
+}
+
+// out = skip + keep * z / (1 - p)      (z: the GEMM output with its bias; out, skip: the residual stream)
+template <int ZDT, int SDT>
+__global__ __launch_bounds__(256) void dropout_add_kernel(const void* __restrict__ z, const void* __restrict__ skip,
+                                                          void* __restrict__ out, int64_t n8, Drop d) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float v[8], s[8], m[8];
+        Vec8<ZDT>::load(z, i * 8, v);
+        Vec8<SDT>::load(skip, i * 8, s);
+        keep8(d, i, m);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] += v[k] * m[k];
+        Vec8<SDT>::store(out, i * 8, s);
+    }
+}
+
+// dz = keep * dout / (1 - p), written in the GEMMs' dtype
+template <int GDT, int ZDT>
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const void* __restrict__ dout, void* __restrict__ dz, int64_t n8, Drop d) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float g[8], m[8];
+        Vec8<GDT>::load(dout, i * 8, g);
+        keep8(d, i, m);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g[k] *= m[k];
+        Vec8<ZDT>::store(dz, i * 8, g);
+    }
+}
+
+inline bool make_drop(float p, uint64_t seed, Drop* d) {
+    if (!(p >= 0.f) || p >= 1.f) return false;
+    d->k0 = (uint32_t)seed;
+    d->k1 = (uint32_t)(seed >> 32);
+    const double t = (double)p * 4294967296.0;
+    d->thr = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+    d->scale = 1.0f / (1.0f - p);
+    return true;
+}
+inline unsigned ew_grid(int64_t n8) {
+    const int64_t want = (n8 + 255) / 256;
+    return (unsigned)(want < 8192 ? want : 8192);
 }
 
 inline bool dtype_ok(int dt) { return dt == GTA_DTYPE_F32 || dt == GTA_DTYPE_BF16; }
@@ -364,29 +451,65 @@ int gta_ln_bwd(const void* dy, int32_t dy_dtype, const void* x, int32_t x_dtype,
     return launch_status();
 }
 
-int gta_gelu_fwd(const void* x, void* y, int32_t dtype, int64_t n, void* stream) {
+int gta_gelu_fwd(const void* x, void* y, int32_t dtype, int64_t n, float p, uint64_t seed, void* stream) {
     if (!x || !y || n <= 0 || !dtype_ok(dtype) || !aligned16(x) || !aligned16(y)) return GTA_E_BADARG;
     if (n % 8 != 0) return GTA_E_UNSUPPORTED;
+    Drop d;
+    if (!make_drop(p, seed, &d)) return GTA_E_BADARG;
     const int64_t n8 = n / 8;
-    const int64_t want = (n8 + 255) / 256;
-    const unsigned grid = (unsigned)(want < 8192 ? want : 8192);
     hipStream_t s = static_cast<hipStream_t>(stream);
     return by_dtype(dtype, [&](auto dt) {
-        hipLaunchKernelGGL((gelu_fwd_kernel<decltype(dt)::value>), dim3(grid), dim3(256), 0, s, x, y, n8);
+        if (p > 0.f) hipLaunchKernelGGL((gelu_fwd_kernel<decltype(dt)::value, true>), dim3(ew_grid(n8)), dim3(256), 0, s, x, y, n8, d);
+        else         hipLaunchKernelGGL((gelu_fwd_kernel<decltype(dt)::value, false>), dim3(ew_grid(n8)), dim3(256), 0, s, x, y, n8, d);
         return launch_status();
     });
 }
 
-int gta_gelu_bwd(const void* dy, const void* x, void* dx, int32_t dtype, int64_t n, void* stream) {
+int gta_gelu_bwd(const void* dy, const void* x, void* dx, int32_t dtype, int64_t n, float p, uint64_t seed, void* stream) {
     if (!dy || !x || !dx || n <= 0 || !dtype_ok(dtype) || !aligned16(x) || !aligned16(dy) || !aligned16(dx)) return GTA_E_BADARG;
     if (n % 8 != 0) return GTA_E_UNSUPPORTED;
+    Drop d;
+    if (!make_drop(p, seed, &d)) return GTA_E_BADARG;
     const int64_t n8 = n / 8;
-    const int64_t want = (n8 + 255) / 256;
-    const unsigned grid = (unsigned)(want < 8192 ? want : 8192);
     hipStream_t s = static_cast<hipStream_t>(stream);
     return by_dtype(dtype, [&](auto dt) {
-        hipLaunchKernelGGL((gelu_bwd_kernel<decltype(dt)::value>), dim3(grid), dim3(256), 0, s, dy, x, dx, n8);
+        if (p > 0.f) hipLaunchKernelGGL((gelu_bwd_kernel<decltype(dt)::value, true>), dim3(ew_grid(n8)), dim3(256), 0, s, dy, x, dx, n8, d);
+        else         hipLaunchKernelGGL((gelu_bwd_kernel<decltype(dt)::value, false>), dim3(ew_grid(n8)), dim3(256), 0, s, dy, x, dx, n8, d);
         return launch_status();
+    });
+}
+
+int gta_dropout_add(const void* z, int32_t z_dtype, const void* skip, void* out, int32_t skip_dtype, int64_t n, float p,
+                    uint64_t seed, void* stream) {
+    if (!z || !skip || !out || n <= 0 || !dtype_ok(z_dtype) || !dtype_ok(skip_dtype) || !aligned16(z) || !aligned16(skip) || !aligned16(out))
+        return GTA_E_BADARG;
+    if (n % 8 != 0) return GTA_E_UNSUPPORTED;
+    Drop d;
+    if (!make_drop(p, seed, &d)) return GTA_E_BADARG;
+    const int64_t n8 = n / 8;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return by_dtype(z_dtype, [&](auto zd) {
+        return by_dtype(skip_dtype, [&](auto sd) {
+            hipLaunchKernelGGL((dropout_add_kernel<decltype(zd)::value, decltype(sd)::value>), dim3(ew_grid(n8)), dim3(256), 0, s, z,
+                               skip, out, n8, d);
+            return launch_status();
+        });
+    });
+}
+
+int gta_dropout_bwd(const void* dout, int32_t dout_dtype, void* dz, int32_t dz_dtype, int64_t n, float p, uint64_t seed, void* stream) {
+    if (!dout || !dz || n <= 0 || !dtype_ok(dout_dtype) || !dtype_ok(dz_dtype) || !aligned16(dout) || !aligned16(dz)) return GTA_E_BADARG;
+    if (n % 8 != 0) return GTA_E_UNSUPPORTED;
+    Drop d;
+    if (!make_drop(p, seed, &d)) return GTA_E_BADARG;
+    const int64_t n8 = n / 8;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return by_dtype(dout_dtype, [&](auto gd) {
+        return by_dtype(dz_dtype, [&](auto zd) {
+            hipLaunchKernelGGL((dropout_bwd_kernel<decltype(gd)::value, decltype(zd)::value>), dim3(ew_grid(n8)), dim3(256), 0, s, dout, dz,
+                               n8, d);
+            return launch_status();
+        });
     });
 }
 

@@ -11,8 +11,14 @@ as these launches (``gta_block.h``):
     Linear + bias (+ GELU)            gta_gemm, epilogue   (net[0], net[1], layers.py:161-162)
     Linear + bias + skip              gta_gemm, epilogue   (net[3] and `+ x`, layers.py:164,487)
 
-and, in the backward, the LayerNorm gradient fused with the skip connection's (``gta_ln_bwd``), bias gradients as
-deterministic column sums, weight gradients written in fp32 straight from the bf16 GEMM.
+and, in the backward, the LayerNorm gradient fused with the skip connection's (``gta_ln_bwd``), weight and bias
+gradients from the hand-written TN kernel (``gta_wgrad``) in fp32 straight from the bf16 operands.
+
+Dropout (both reference configs train with ``dropout: 0.01``; layers.py:163,165,289): the three nn.Dropout of a layer run
+inside the block's own kernels -- after the GELU in the GELU kernel, in front of the two skip additions in
+``gta_dropout_add`` (the skip epilogue of the GEMM is then not used) -- with masks that are a pure function of a per-call
+seed (drawn from torch's CPU generator, so ``torch.manual_seed`` fixes them) and the element index; the backward
+regenerates them.  The masks are NOT torch's Philox stream: runs are reproducible, not bit-identical to nn.Dropout's.
 
 Arithmetic.  The compute dtype is autocast's (bf16) when autocast is on, else the dtype of ``x``.  The residual stream
 keeps the dtype of ``x`` (fp32 under autocast, as in the reference's mixed_prec runs), LayerNorm statistics and every
@@ -73,6 +79,11 @@ def _shaped(dx: torch.Tensor, shape) -> torch.Tensor:
 
 def _rows(x: torch.Tensor) -> torch.Tensor:
     return x.reshape(-1, x.shape[-1]) if x.is_contiguous() else x.contiguous().view(-1, x.shape[-1])
+
+
+def next_seed() -> int:
+    """A fresh dropout seed from torch's default CPU generator (reproducible under torch.manual_seed)."""
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
 
 
 def _in_compute_dtype(d2: torch.Tensor, dout: torch.Tensor, cdt: torch.dtype) -> torch.Tensor:
@@ -136,21 +147,28 @@ class _LNLinear(torch.autograd.Function):
 
 
 class _LinearSkip(torch.autograd.Function):
-    """skip + a W^T + b in one GEMM (bias epilogue, beta = 1 on the skip); output in the skip's dtype."""
+    """skip + dropout_p(a W^T + b).  p = 0: one GEMM (bias epilogue, beta = 1 on the skip); p > 0: GEMM with bias, then
+    ``gta_dropout_add``.  Output in the skip's dtype."""
 
     @staticmethod
-    def forward(ctx, a, W, bias, skip, cdt, need):
+    def forward(ctx, a, W, bias, skip, cdt, need, p, seed):
         a2 = _rows(a)
         if a2.dtype != cdt:
             a2 = a2.to(cdt)
         s2 = _rows(skip)
         Wc = _cast_param(W, cdt)
-        b = _bias_for(bias, s2.dtype)
-        out = nb.gemm(a2, Wc, trans_b=True, epilogue=nb.EPI_BIAS if b is not None else nb.EPI_NONE, bias=b, c=s2, beta=1.0,
-                      out_dtype=s2.dtype)
+        if p > 0.0:
+            b = _bias_for(bias, cdt)
+            z = nb.gemm(a2, Wc, trans_b=True, epilogue=nb.EPI_BIAS if b is not None else nb.EPI_NONE, bias=b)
+            out = nb.dropout_add(z, s2, p, seed)
+        else:
+            b = _bias_for(bias, s2.dtype)
+            out = nb.gemm(a2, Wc, trans_b=True, epilogue=nb.EPI_BIAS if b is not None else nb.EPI_NONE, bias=b, c=s2, beta=1.0,
+                          out_dtype=s2.dtype)
         if need:
             ctx.save_for_backward(a2, Wc)
             ctx.cdt, ctx.has_bias, ctx.wdtype, ctx.ashape, ctx.adtype = cdt, bias is not None, W.dtype, a.shape, a.dtype
+            ctx.p, ctx.seed = p, seed
         return out.view(skip.shape)
 
     @staticmethod
@@ -158,35 +176,44 @@ class _LinearSkip(torch.autograd.Function):
         a2, Wc = ctx.saved_tensors
         d2 = _rows(dout)
         dc = _in_compute_dtype(d2, dout, ctx.cdt)
+        if ctx.p > 0.0:
+            dc = nb.dropout_bwd(dc, ctx.cdt, ctx.p, ctx.seed)
         da = nb.gemm(dc, Wc).view(ctx.ashape) if ctx.needs_input_grad[0] else None
         if da is not None and da.dtype != ctx.adtype:
             da = da.to(ctx.adtype)
         dW, db = _weight_grads(dc, a2, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2], ctx.wdtype)
-        return da, dW, db, dout, None, None
+        return da, dW, db, dout, None, None, None, None
 
 
 class _FeedForwardSkip(torch.autograd.Function):
-    """x + W2 gelu(W1 LayerNorm(x) + b1) + b2  (PreNorm(FeedForward) + skip, layers.py:146-169,487)."""
+    """x + drop(W2 drop(gelu(W1 LayerNorm(x) + b1)) + b2)  (PreNorm(FeedForward) + skip, layers.py:146-169,487)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, W1, b1, W2, b2, eps, cdt, need):
+    def forward(ctx, x, gamma, beta, W1, b1, W2, b2, eps, cdt, need, p_mid, p_out, seed):
         x2 = _rows(x)
         y, mean, rstd = nb.ln_fwd(x2, gamma.detach(), beta.detach(), eps, cdt, want_stats=need)
         W1c, W2c = _cast_param(W1, cdt), _cast_param(W2, cdt)
-        bb1, bb2 = _bias_for(b1, cdt), _bias_for(b2, x2.dtype)
+        bb1 = _bias_for(b1, cdt)
         epi = nb.EPI_BIAS if bb1 is not None else nb.EPI_NONE
-        if not need and GELU_EPILOGUE and cdt == torch.bfloat16 and bb1 is not None:
+        if not need and p_mid == 0.0 and GELU_EPILOGUE and cdt == torch.bfloat16 and bb1 is not None:
             pre = None
             h = nb.gemm(y, W1c, trans_b=True, epilogue=nb.EPI_BIAS_GELU, bias=bb1)
         else:
             pre = nb.gemm(y, W1c, trans_b=True, epilogue=epi, bias=bb1)
-            h = nb.gelu_fwd(pre)
-        out = nb.gemm(h, W2c, trans_b=True, epilogue=nb.EPI_BIAS if bb2 is not None else nb.EPI_NONE, bias=bb2, c=x2, beta=1.0,
-                      out_dtype=x2.dtype)
+            h = nb.gelu_fwd(pre, p_mid, seed)
+        if p_out > 0.0:
+            bb2 = _bias_for(b2, cdt)
+            z = nb.gemm(h, W2c, trans_b=True, epilogue=nb.EPI_BIAS if bb2 is not None else nb.EPI_NONE, bias=bb2)
+            out = nb.dropout_add(z, x2, p_out, seed + 1)
+        else:
+            bb2 = _bias_for(b2, x2.dtype)
+            out = nb.gemm(h, W2c, trans_b=True, epilogue=nb.EPI_BIAS if bb2 is not None else nb.EPI_NONE, bias=bb2, c=x2, beta=1.0,
+                          out_dtype=x2.dtype)
         if need:
             ctx.save_for_backward(x2, gamma, beta, mean, rstd, W1c, W2c, pre, h, y)
             ctx.eps, ctx.cdt, ctx.wdtype, ctx.xshape = eps, cdt, W1.dtype, x.shape
             ctx.has_b1, ctx.has_b2 = b1 is not None, b2 is not None
+            ctx.p_mid, ctx.p_out, ctx.seed = p_mid, p_out, seed
         return out.view(x.shape)
 
     @staticmethod
@@ -194,15 +221,18 @@ class _FeedForwardSkip(torch.autograd.Function):
         x2, gamma, beta, mean, rstd, W1c, W2c, pre, h, y = ctx.saved_tensors
         d2 = _rows(dout)
         dc = _in_compute_dtype(d2, dout, ctx.cdt)
+        if ctx.p_out > 0.0:
+            dc = nb.dropout_bwd(dc, ctx.cdt, ctx.p_out, ctx.seed + 1)
         dW2, db2 = _weight_grads(dc, h, ctx.needs_input_grad[5], ctx.has_b2 and ctx.needs_input_grad[6], ctx.wdtype)
         dh = nb.gemm(dc, W2c)
-        dpre = nb.gelu_bwd(dh, pre)
+        dpre = nb.gelu_bwd(dh, pre, ctx.p_mid, ctx.seed)
         del dh
         dW1, db1 = _weight_grads(dpre, y, ctx.needs_input_grad[3], ctx.has_b1 and ctx.needs_input_grad[4], ctx.wdtype)
         dy = nb.gemm(dpre, W1c)
         dres = d2 if d2.dtype == x2.dtype else d2.to(x2.dtype)
         dx, dgamma, dbeta = nb.ln_bwd(dy, x2, gamma.detach(), mean, rstd, dres, bf16_copy=ctx.cdt == torch.bfloat16)
-        return _shaped(dx, ctx.xshape), dgamma.to(gamma.dtype), dbeta.to(beta.dtype), dW1, db1, dW2, db2, None, None, None
+        return (_shaped(dx, ctx.xshape), dgamma.to(gamma.dtype), dbeta.to(beta.dtype), dW1, db1, dW2, db2, None, None, None,
+                None, None, None)
 
 
 def _need(*ts) -> bool:
@@ -216,14 +246,25 @@ def ln_linear(x, norm: torch.nn.LayerNorm, lin: torch.nn.Linear, cdt):
     return _LNLinear.apply(*args, norm.eps, cdt, _need(*args))
 
 
-def linear_skip(a, lin: torch.nn.Linear, skip, cdt):
+def linear_skip(a, lin: torch.nn.Linear, skip, cdt, p: float = 0.0, seed=None):
+    """skip + dropout_p(lin(a)); ``seed`` None draws one (``next_seed``)."""
     args = (a, lin.weight, lin.bias, skip)
-    return _LinearSkip.apply(*args, cdt, _need(*args))
+    p = float(p)
+    return _LinearSkip.apply(*args, cdt, _need(*args), p, (next_seed() if seed is None else seed) if p > 0.0 else 0)
 
 
-def feed_forward_skip(x, norm: torch.nn.LayerNorm, lin1: torch.nn.Linear, lin2: torch.nn.Linear, cdt):
+def feed_forward_skip(x, norm: torch.nn.LayerNorm, lin1: torch.nn.Linear, lin2: torch.nn.Linear, cdt, p_mid: float = 0.0,
+                      p_out: float = 0.0, seed=None):
+    """x + dropout_{p_out}(lin2(dropout_{p_mid}(gelu(lin1(norm(x))))))."""
     args = (x, norm.weight, norm.bias, lin1.weight, lin1.bias, lin2.weight, lin2.bias)
-    return _FeedForwardSkip.apply(*args, norm.eps, cdt, _need(*args))
+    p_mid, p_out = float(p_mid), float(p_out)
+    seed = (next_seed() if seed is None else seed) if (p_mid > 0.0 or p_out > 0.0) else 0
+    return _FeedForwardSkip.apply(*args, norm.eps, cdt, _need(*args), p_mid, p_out, seed)
+
+
+def active_p(m) -> float:
+    """Dropout probability a module applies right now (0 for nn.Identity and in eval mode)."""
+    return float(m.p) if isinstance(m, torch.nn.Dropout) and m.training else 0.0
 
 
 def norm_ok(norm) -> bool:

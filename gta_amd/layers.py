@@ -209,9 +209,6 @@ class Transformer(nn.Module):
         if cdt is None or x.dim() != 3:
             return None
         a, net = attn.fn, ff.fn.net
-        drop = [m for m in list(net) + ([a.to_out[1]] if isinstance(a.to_out, nn.Sequential) else []) if isinstance(m, nn.Dropout)]
-        if any(m.p > 0.0 and m.training for m in drop):
-            return None
         if not (_fused.norm_ok(attn.norm) and _fused.norm_ok(ff.norm) and isinstance(a.to_out, nn.Sequential)):
             return None
         lins = [a.to_qkv if a.selfatt else a.to_q, a.to_out[0], net[0], net[3]]
@@ -231,8 +228,10 @@ class Transformer(nn.Module):
                 out, amap = a.core(q, k, v, extras, kv_cache, return_attmap=want_map)
                 if want_map:
                     attmap = amap
-                x = _fused.linear_skip(out, a.to_out[0], skip, cdt)                      # to_out + `+ x` (layers.py:483-486)
-                x = _fused.feed_forward_skip(x, ff.norm, ff.fn.net[0], ff.fn.net[3], cdt)  # ff(norm(x)) + x (layers.py:487)
+                net = ff.fn.net
+                x = _fused.linear_skip(out, a.to_out[0], skip, cdt, p=_fused.active_p(a.to_out[1]))   # to_out + `+ x` (:483-486)
+                x = _fused.feed_forward_skip(x, ff.norm, net[0], net[3], cdt, p_mid=_fused.active_p(net[2]),
+                                             p_out=_fused.active_p(net[4]))                            # ff(norm(x)) + x (:487)
                 continue
             if want_map:
                 out, attmap = attn(x, z=z, return_attmap=True, extras=extras)

@@ -25,6 +25,7 @@ ABI_SYMBOLS = (
     "gta_ln_fwd", "gta_ln_bwd", "gta_ln_bwd_workspace_bytes", "gta_gelu_fwd", "gta_gelu_bwd", "gta_colsum",
     "gta_colsum_workspace_bytes", "gta_gemm", "gta_gemm_workspace_bytes", "gta_block_release", "gta_block_strerror",
     "gta_block_abi_version", "gta_sizeof_gemm_desc", "gta_wgrad", "gta_wgrad_supported", "gta_wgrad_workspace_bytes",
+    "gta_dropout_add", "gta_dropout_bwd",
 )
 
 
@@ -62,8 +63,10 @@ def lib():
         L.gta_ln_bwd_workspace_bytes.restype = c_int64
         L.gta_ln_bwd.argtypes = [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                                  c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]
-        L.gta_gelu_fwd.argtypes = [c_void_p, c_void_p, c_int32, c_int64, c_void_p]
-        L.gta_gelu_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p]
+        L.gta_gelu_fwd.argtypes = [c_void_p, c_void_p, c_int32, c_int64, c_float, ctypes.c_uint64, c_void_p]
+        L.gta_gelu_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_float, ctypes.c_uint64, c_void_p]
+        L.gta_dropout_add.argtypes = [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int64, c_float, ctypes.c_uint64, c_void_p]
+        L.gta_dropout_bwd.argtypes = [c_void_p, c_int32, c_void_p, c_int32, c_int64, c_float, ctypes.c_uint64, c_void_p]
         L.gta_colsum_workspace_bytes.argtypes = [c_int64, c_int32]
         L.gta_colsum_workspace_bytes.restype = c_int64
         L.gta_colsum.argtypes = [c_void_p, c_int32, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_int64, c_void_p]
@@ -149,18 +152,42 @@ def ln_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: torch.T
     return dx, dgamma, dbeta
 
 
-def gelu_fwd(x: torch.Tensor) -> torch.Tensor:
+def gelu_fwd(x: torch.Tensor, p: float = 0.0, seed: int = 0) -> torch.Tensor:
+    """gelu(x), followed by dropout(p) with the mask of ``seed`` when p > 0 (x contiguous)."""
     _need_cuda(x)
     y = torch.empty_like(x)
-    check(lib().gta_gelu_fwd(_ptr(x), _ptr(y), dtype_code(x.dtype), x.numel(), _stream(x)), "gta_gelu_fwd")
+    check(lib().gta_gelu_fwd(_ptr(x), _ptr(y), dtype_code(x.dtype), x.numel(), float(p), int(seed), _stream(x)), "gta_gelu_fwd")
     return y
 
 
-def gelu_bwd(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+def gelu_bwd(dy: torch.Tensor, x: torch.Tensor, p: float = 0.0, seed: int = 0) -> torch.Tensor:
     _need_cuda(x, dy)
     dx = torch.empty_like(x)
-    check(lib().gta_gelu_bwd(_ptr(dy), _ptr(x), _ptr(dx), dtype_code(x.dtype), x.numel(), _stream(x)), "gta_gelu_bwd")
+    check(lib().gta_gelu_bwd(_ptr(dy), _ptr(x), _ptr(dx), dtype_code(x.dtype), x.numel(), float(p), int(seed), _stream(x)),
+          "gta_gelu_bwd")
     return dx
+
+
+def dropout_add(z: torch.Tensor, skip: torch.Tensor, p: float, seed: int) -> torch.Tensor:
+    """skip + dropout_p(z) (mask of ``seed``), in skip's dtype; z, skip contiguous and equally shaped."""
+    _need_cuda(z, skip)
+    if z.shape != skip.shape or not z.is_contiguous() or not skip.is_contiguous():
+        raise GtaError("dropout_add: contiguous operands of one shape")
+    out = torch.empty_like(skip)
+    check(lib().gta_dropout_add(_ptr(z), dtype_code(z.dtype), _ptr(skip), _ptr(out), dtype_code(skip.dtype), z.numel(), float(p),
+                                int(seed), _stream(z)), "gta_dropout_add")
+    return out
+
+
+def dropout_bwd(dout: torch.Tensor, out_dtype: torch.dtype, p: float, seed: int) -> torch.Tensor:
+    """keep * dout / (1 - p) in ``out_dtype`` (the same mask as the forward call with this seed)."""
+    _need_cuda(dout)
+    if not dout.is_contiguous():
+        raise GtaError("dropout_bwd: contiguous gradient")
+    dz = torch.empty(dout.shape, device=dout.device, dtype=out_dtype)
+    check(lib().gta_dropout_bwd(_ptr(dout), dtype_code(dout.dtype), _ptr(dz), dtype_code(out_dtype), dout.numel(), float(p), int(seed),
+                                _stream(dout)), "gta_dropout_bwd")
+    return dz
 
 
 def colsum(a: torch.Tensor) -> torch.Tensor:

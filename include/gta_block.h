@@ -58,11 +58,24 @@ int gta_ln_bwd(const void* dy, int32_t dy_dtype, const void* x, int32_t x_dtype,
                void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
- * GELU, exact erf form (nn.GELU(), layers.py:162), for the configurations that run in fp32 (mixed_prec: False), where
- * hipBLASLt's tanh-form epilogue would be a parity break.  y = gelu(x);  dx = dy * gelu'(x).  n elements, n % 8 == 0.
+ * GELU, exact erf form (nn.GELU(), layers.py:162) -- hipBLASLt's epilogue is the tanh form, a parity break in fp32 and
+ * not available with the pre-activation output training needs -- fused with the Dropout that follows it in
+ * FeedForward.net (layers.py:163):  y = keep * gelu(x) / (1 - p);  dx = dy * keep / (1 - p) * gelu'(x).
+ * p = 0: plain GELU.  n elements, n % 8 == 0.
+ *
+ * Dropout masks are never stored: keep(i) is a pure function of (seed, element index) -- Philox4x32-10 keyed by `seed`,
+ * counter = i / 4, keep <=> word >= p * 2^32 -- so the backward regenerates the forward's mask from the same seed.
  * --------------------------------------------------------------------------------------------------------------- */
-int gta_gelu_fwd(const void* x, void* y, int32_t dtype, int64_t n, void* stream);
-int gta_gelu_bwd(const void* dy, const void* x, void* dx, int32_t dtype, int64_t n, void* stream);
+int gta_gelu_fwd(const void* x, void* y, int32_t dtype, int64_t n, float p, uint64_t seed, void* stream);
+int gta_gelu_bwd(const void* dy, const void* x, void* dx, int32_t dtype, int64_t n, float p, uint64_t seed, void* stream);
+
+/* Dropout + skip connection, forward (to_out's / net's trailing nn.Dropout and the `+ x`, layers.py:165,289,483-487):
+ *   out = skip + keep * z / (1 - p);  z [n] (z_dtype): the GEMM output incl. bias; skip, out [n] (skip_dtype).
+ * Backward of the dropout:  dz = keep * dout / (1 - p), written in the GEMMs' dtype. */
+int gta_dropout_add(const void* z, int32_t z_dtype, const void* skip, void* out, int32_t skip_dtype, int64_t n,
+                    float p, uint64_t seed, void* stream);
+int gta_dropout_bwd(const void* dout, int32_t dout_dtype, void* dz, int32_t dz_dtype, int64_t n, float p, uint64_t seed,
+                    void* stream);
 
 /* Column sums: out[n] (fp32) = sum over the m rows of a [m, n] (ld elements between rows); the bias gradient of a
  * Linear.  Deterministic.  workspace: gta_colsum_workspace_bytes(m, n).  n % 8 == 0. */

@@ -276,3 +276,108 @@ def test_bf16_side_copy_of_the_stream_gradient():
     shaped.add_(1.0)                                              # what an in-place gradient accumulation does
     fresh = fused._in_compute_dtype(shaped.reshape(-1, 256), shaped, BF)
     assert fresh.data_ptr() != side.data_ptr() and torch.equal(fresh, shaped.reshape(-1, 256).to(BF))
+
+
+def _mask(shape, p, seed, dt=torch.float32):
+    """The keep factors (0 or 1/(1-p)) of a dropout call, recovered through the kernel itself."""
+    return nb.dropout_add(torch.ones(shape, device=DEV, dtype=dt), torch.zeros(shape, device=DEV, dtype=dt), p, seed)
+
+
+def test_dropout_kernels():
+    n = (1 << 20)
+    for p in (0.01, 0.3):
+        m = _mask((n,), p, 1234)
+        kept = (m > 0).float().mean().item()
+        assert abs(kept - (1 - p)) < 4 * (p * (1 - p) / n) ** 0.5 + 1e-4, (p, kept)
+        assert torch.all((m == 0) | ((m - 1 / (1 - p)).abs() < 1e-6))
+        assert torch.equal(m, _mask((n,), p, 1234)) and not torch.equal(m, _mask((n,), p, 1235))
+        x = torch.randn(n, device=DEV)
+        assert torch.allclose(nb.dropout_bwd(x, torch.float32, p, 1234), x * m)
+        assert torch.equal(nb.dropout_bwd(x, BF, p, 1234), (x * m).to(BF))
+        assert torch.allclose(nb.gelu_fwd(x, p, 1234), F.gelu(x) * m, atol=1e-6)
+        xr = x.clone().requires_grad_(True)
+        (F.gelu(xr) * m).backward(torch.ones_like(x) * 0.5)
+        assert torch.allclose(nb.gelu_bwd(torch.full_like(x, 0.5), x, p, 1234), xr.grad, atol=1e-6)
+        skip = torch.randn(n, device=DEV)
+        assert torch.allclose(nb.dropout_add(x.to(BF), skip, p, 1234), skip + x.to(BF).float() * m, atol=1e-6)
+    assert torch.equal(nb.gelu_fwd(x), nb.gelu_fwd(x, 0.0, 99))                 # p = 0: no mask, the seed is irrelevant
+    # adjacent masks are unrelated (counter-based generator: no visible structure at stride 8)
+    m = _mask((n,), 0.5, 7).view(-1, 8)
+    assert abs(((m[:-1] > 0) == (m[1:] > 0)).float().mean().item() - 0.5) < 0.01
+
+
+@pytest.mark.parametrize("autocast", [False, True])
+def test_fused_functions_with_dropout_match_masked_reference(autocast):
+    """to_out + Dropout + skip and PreNorm(FeedForward with its two Dropouts) + skip with fixed seeds against plain PyTorch
+    using the same masks (recovered from the kernels), forward and all gradients."""
+    torch.manual_seed(0)
+    cdt = BF if autocast else torch.float32
+    M, D, Fh, p, seed = 192, 128, 256, 0.25, 4242
+    x = torch.randn(2, M // 2, D, device=DEV)
+    norm = torch.nn.LayerNorm(D).to(DEV)
+    l1, l2, lo = layers.ViTLinear(D, Fh).to(DEV), layers.ViTLinear(Fh, D).to(DEV), layers.JaxLinear(D, D).to(DEV)
+    with torch.no_grad():
+        for m in (norm, l1, l2, lo):
+            for q in m.parameters():
+                q.add_(torch.randn_like(q) * 0.05)
+    a = torch.randn(2, M // 2, D, device=DEV).to(cdt)
+    w = torch.randn(2, M // 2, D, device=DEV)
+    params = [q for m in (norm, l1, l2, lo) for q in m.parameters()]
+
+    def grads(out, xin):
+        for q in params:
+            q.grad = None
+        (out.float() * w).sum().backward()
+        return [xin.grad.clone()] + [None if q.grad is None else q.grad.clone() for q in params]
+
+    # fused
+    xf = x.clone().requires_grad_(True)
+    y1 = fused.linear_skip(a, lo, xf, cdt, p=p, seed=seed)
+    y2 = fused.feed_forward_skip(y1, norm, l1, l2, cdt, p_mid=p, p_out=p, seed=seed + 10)
+    gf = grads(y2, xf)
+    # reference with the same masks
+    m_out = _mask((M, D), p, seed).view(2, M // 2, D)
+    m_mid = _mask((M, Fh), p, seed + 10).view(2, M // 2, Fh)
+    m_ff = _mask((M, D), p, seed + 11).view(2, M // 2, D)
+    xr = x.clone().requires_grad_(True)
+    r1 = xr + lo(a.float()) * m_out
+    r2 = r1 + l2(F.gelu(l1(norm(r1))) * m_mid) * m_ff
+    gr = grads(r2, xr)
+    tol = 3e-2 if autocast else 2e-4
+    assert C.err_stats(y2.float().cpu(), r2.detach().cpu())["rel_rms"] < tol
+    for g1, g0 in zip(gf, gr):
+        assert (g1 is None) == (g0 is None)
+        if g0 is not None:
+            assert C.err_stats(g1.float().cpu(), g0.cpu())["rel_rms"] < 2 * tol
+
+
+def test_transformer_training_with_dropout_takes_fused_path():
+    """dropout: 0.01 as in both reference configs: training mode keeps the fused blocks (mask kernels run), eval mode has
+    no dropout, and torch.manual_seed makes the training forward reproducible."""
+    torch.manual_seed(0)
+    f_dims = {"triv": 0, "se3": 32, "so3": 0, "so2": 32}
+    ak = {"f_dims": f_dims, "so2": 8, "so3": 0, "max_freq_h": 1, "max_freq_w": 1}
+    tr = gta_amd.Transformer(128, 2, 2, 64, 256, 0.01, True, None, False, {"method": {"name": "gta", "args": ak}}).to(DEV)
+    _, ex, x, z = _transformer(False)
+    calls = []
+    orig = nb.dropout_add
+    nb.dropout_add = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        tr.train()
+        torch.manual_seed(5)
+        y_a = tr(x, None, ex)
+        torch.manual_seed(5)
+        y_b = tr(x, None, ex)
+        torch.manual_seed(6)
+        y_c = tr(x, None, ex)
+        assert len(calls) == 3 * 4                                   # two per layer
+        y_a.sum().backward()
+        assert all(q.grad is not None and torch.isfinite(q.grad).all() for q in tr.parameters())
+        tr.eval()
+        with torch.no_grad():
+            y_e = tr(x, None, ex)
+        assert len(calls) == 12
+    finally:
+        nb.dropout_add = orig
+    assert torch.equal(y_a, y_b) and not torch.equal(y_a, y_c)
+    assert C.err_stats(y_a.detach().cpu(), y_e.cpu())["rel_rms"] < 0.3      # p = 0.01 perturbs, it does not change the answer
