@@ -155,6 +155,56 @@ def dry_run(args):
         dist.destroy_process_group()
 
 
+def block_layer_leg(B, steps, device):
+    """one MSN encoder layer (d = 768 = 8 x 96, mlp 1536, 5 views x 256 tokens, bf16 autocast, dropout off) run
+    as the fused block and module by module -- microseconds per layer, forward and forward + backward."""
+    import gta_amd
+    from gta_amd import layers, synth
+    torch.manual_seed(0)
+    ak = {"f_dims": {"triv": 0, "se3": 48, "so3": 24, "so2": 24}, "so2": 6, "so3": 2, "max_freq_h": 1, "max_freq_w": 1}
+    tr = gta_amd.Transformer(768, 1, 8, 96, 1536, 0.0, True, None, False, {"method": {"name": "gta", "args": ak}}).to(device)
+    gen = torch.Generator().manual_seed(1)
+    ex = {"input_transforms": synth.random_extrinsics(B, 5, gen).to(device), "input_coord": torch.rand(B, 5, 16, 16, 2, generator=gen).to(device)}
+    gta_amd.pre_compute_reps_encoder(ak, ex)
+    x0 = torch.randn(B, 1280, 768, device=device)
+
+    def fwd():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            tr(x0, None, ex)
+
+    def fwd_bwd():
+        x = x0.requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = tr(x, None, ex)
+        y.backward(x0)
+        for p in tr.parameters():
+            p.grad = None
+        x0.grad = None
+
+    def timeit(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(steps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / steps * 1e3
+
+    res = {}
+    try:
+        for label, on in (("modules", False), ("fused", True)):
+            layers.FUSED_BLOCKS = on
+            res[label] = {"forward_us": timeit(fwd), "forward_backward_us": timeit(fwd_bwd)}
+    finally:
+        layers.FUSED_BLOCKS = True
+    res["config"] = f"one pre-LN layer of the MSN gta_so3 encoder: d=768 (8 x 96), mlp 1536, B={B}, 1280 tokens, bf16 autocast"
+    res["note"] = "fused = libgta_block.so (DESIGN.md section 8); modules = nn.LayerNorm / nn.Linear / nn.GELU + autograd; not part of `value`"
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,6 +221,10 @@ def main():
     ap.add_argument("--model-batch", type=int, default=8, help="per-GPU scenes for --model-train-steps")
     ap.add_argument("--train-steps", type=int, default=10,
                     help="extra (untimed-for-`value`) forward+backward steps reported as fwd_bwd_* fields; 0 = skip")
+    ap.add_argument("--block-steps", type=int, default=5,
+                    help="also time one whole pre-LN layer around the operator (SURVEY 8 f1: the fused block of libgta_block.so "
+                         "against the module-by-module path), forward and forward+backward; reported as `block_layer`, not "
+                         "part of `value`; 0 = skip")
     ap.add_argument("--kv-mode", dest="kv_mode", default="prepass", choices=["prepass", "fused"],
                     help="execution plan of gta_attn_fwd (see include/gta_hip.h)")
     ap.add_argument("--dry-run", action="store_true",
@@ -301,6 +355,9 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         fwd_bwd_ms = e0.elapsed_time(e1) / args.train_steps
+    block_layer = None
+    if args.block_steps > 0 and rank == 0 and args.workload == "ms-enc" and not args.dry_run:
+        block_layer = block_layer_leg(B, args.block_steps, device)
     srt_train = None
     if args.model_train_steps > 0:
         # whole-model optimizer step (conv stem, 5 + 2 Transformer blocks on the HIP attention path,
@@ -385,6 +442,8 @@ def main():
                                "tflops": 3.5 * flops / (fwd_bwd_ms * 1e-3) / 1e12,
                                "note": "operator forward + backward (5 GEMMs + 2 recomputed = 3.5x forward flops), "
                                        "not part of `value`"}
+        if block_layer is not None:
+            line["block_layer"] = block_layer
         if srt_train is not None:
             line["srt_train"] = srt_train
         if not args.no_cpu_baseline and n == 1:
