@@ -109,6 +109,22 @@ if __name__ == "__main__":
             flops = 4.0 * B * H_ * Nq_ * Pq_ * Nk_ * Pk_ * dh_
             msg = "  ".join(f"{n}: median {sorted(r)[3]*1e3:7.1f} us min {min(r)*1e3:7.1f} ({flops/sorted(r)[3]/1e9:6.1f} TF)" for n, r in res.items())
             print(f"{name:8s} {msg}", flush=True)
+    if which == "plans":
+        # whole forward call, both execution plans, at the BASELINE shapes (what gta_attn_fwd's plan choice should follow)
+        shapes = {"MS-enc": (8, 5, 256, 5, 256, MS, 6, 2), "MS-dec": (8, 5, 512, 5, 256, MS, 6, 2), "CL-enc": (6, 2, 300, 2, 300, CL, 8, 0),
+                  "CL-dec": (6, 3, 853, 2, 300, CL, 8, 0), "DT": (16, 1, 1024, 1, 1024, {"so2": 64}, 16, 0),
+                  "CL-enc-1v": (6, 1, 300, 1, 300, CL, 8, 0), "MS-3v": (8, 3, 256, 3, 256, MS, 6, 2)}
+        VT = native.FLAG_V_TRANSFORM
+        for name, (H_, Nq_, Pq_, Nk_, Pk_, FD, so2_, so3_) in shapes.items():
+            q, k, v, packed, L = setup(B, H_, Nq_, Pq_, Nk_, Pk_, FD, so2_, so3_, torch.bfloat16)
+            fns = {"two-stage": raw_call(q, k, v, packed, FD, L, VT, True)[0],
+                   "two-stage persistent": raw_call(q, k, v, packed, FD, L, VT | native.FLAG_PERSIST, True)[0],
+                   "single-kernel": raw_call(q, k, v, packed, FD, L, VT | native.FLAG_FUSED_KV, None)[0]}
+            res = {n: [] for n in fns}
+            for _ in range(5):
+                for n, fn in fns.items():
+                    res[n].append(time_call(fn, n=10, warm=2))
+            print(f"{name:10s} Tq={Nq_*Pq_:5d} Tk={Nk_*Pk_:5d} " + "  ".join(f"{n}: {sorted(r)[2]*1e3:7.1f} us" for n, r in res.items()), flush=True)
     if which == "prep":
         # the K/V pre-pass alone (FLAG_PREP_ONLY) at the BASELINE shapes: time and effective bandwidth on algorithmic bytes
         shapes = {"MS-enc": (8, 5, 256, 5, 256, MS, 6, 2), "CL-enc": (6, 2, 300, 2, 300, CL, 8, 0), "DT": (16, 1, 1024, 1, 1024, {"so2": 64}, 16, 0)}
