@@ -7,16 +7,25 @@
 // reduction runs over the M = batch x tokens rows, the SLOW index of both row-major operands, and the outputs are small
 // (768..2304 squared).  hipBLASLt's best kernel for it reaches 370-540 TFLOP/s at the MSN shapes (profiles/r02/README.md).
 //
-// Structure.  One workgroup (4 waves, 256 threads, one per CU) owns a 256 x 256 tile of dW over a slice of the tokens
-// (split-M, partial tiles reduced in a fixed order by wgrad_finish_kernel: deterministic).  Per step of 64 tokens the two
-// operand tiles [64][256] are brought in by LDS-DMA (global_load_lds, 16 B per lane) as [16 token][32 column] sub-tiles of
-// 1 KiB -- one DMA instruction each: lane l fetches 16 B of row l/4 at column chunk l%4, i.e. 64-B row segments, and the
-// lane-linear LDS image of that instruction IS the row-major sub-tile with 64-B rows.  MFMA operands need 8 consecutive
-// TOKENS of one column per lane; ds_read_b64_tr_b16 delivers 4 (a 16-lane group reads a [4 token][16 column] block and
-// transposes it), so an operand of v_mfma_f32_32x32x16_bf16 is two such reads.  With 64-B rows the 32 lanes serviced
-// together read 4 rows x 64 B = 256 contiguous bytes: conflict-free.  Two LDS stages of 64 KiB: the DMA of step t+1 runs
-// under the MFMAs of step t (one barrier per step).  Each wave owns 128 x 128 of the tile: 16 accumulators of 32 x 32
-// (256 accumulator registers), 64 MFMAs against 64 transpose-reads per step.
+// Structure.  One workgroup (8 waves, 512 threads, one per CU) owns a 256 x 256 tile of dW over a slice of the tokens
+// (split-M, partial tiles reduced in a fixed order by wgrad_finish_kernel: deterministic).  Per step of 32 tokens the two
+// operand tiles [32][256] are brought in by LDS-DMA (global_load_lds, 16 B per lane) as [8 token][64 column] sub-tiles of
+// 1 KiB -- one DMA instruction each: eight lanes fetch one whole 128-B line of a row, and the lane-linear LDS image of
+// the instruction IS the row-major sub-tile with 128-B rows (16-B chunks XOR-swizzled by the row through the SOURCE
+// addresses).  MFMA operands need 8 consecutive TOKENS of one column per lane; ds_read_b64_tr_b16 delivers 4 (a 16-lane
+// group reads a [4 token][16 column] block and transposes it), so an operand of v_mfma_f32_32x32x16_bf16 is two such
+// reads.  With the swizzle the 32 lanes serviced together cover all 64 banks once: conflict-free (SQ_LDS_BANK_CONFLICT 0).
+// A ring of four 32-KiB stages keeps three steps of DMA in flight under the MFMAs; the ring turns in the MIDDLE of a step,
+// between its two 16-token MFMA blocks, so every fragment read flies under an MFMA block.  Each wave owns 128 x 64 of the
+// tile: 8 accumulators of 32 x 32, 16 MFMAs against 24 transpose-reads and 4 DMA instructions per step.
+//
+// What bounds it (profiles/r02/README.md): 600-760 TFLOP/s = ~10 B per clock and CU into the LDS, whatever the shape of the
+// loop -- one wave per SIMD with 128 x 128 per wave and a two-stage ring of 64-token steps, 64-B or 128-B row segments per
+// DMA lane group, two to four stages, four or eight waves all land within 2 % of each other; HBM traffic is 1.7x the
+// algorithmic bytes (FETCH_SIZE), LDS conflicts are zero, the matrix pipe is busy 40 % of the time.  The rate is that of
+// the LDS-DMA path itself (a 1-KiB global_load_lds costs ~100 cycles of the CU's address unit): 32 of them per 32-token
+// step.  A tile with more flops per loaded byte does not fit the accumulator registers (256 x 256 fp32 = half the CU's
+// register file).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "gta_common.h"
@@ -26,9 +35,16 @@
 namespace {
 
 constexpr int WG_TILE = 256;                       // dW tile edge (both ways)
-constexpr int WG_BT = 64;                          // tokens per step
-constexpr int WG_STAGE = 2 * WG_BT * WG_TILE * 2;  // G tile + X tile, bytes (64 KiB)
-constexpr int WG_LDS = 2 * WG_STAGE;
+constexpr int WG_BT = 32;                          // tokens per step (two 16-token groups)
+constexpr int WG_OPER = WG_BT * WG_TILE * 2;       // one operand tile [32][256] bf16, bytes (16 KiB)
+constexpr int WG_STAGE = 2 * WG_OPER;              // G tile + X tile (32 KiB)
+#ifndef GTA_WGRAD_STAGES
+#define GTA_WGRAD_STAGES 4
+#endif
+constexpr int WG_NSTAGE = GTA_WGRAD_STAGES;        // ring depth: NSTAGE - 1 steps of DMA in flight under the MFMAs
+constexpr int WG_LDS = WG_NSTAGE * WG_STAGE;
+constexpr int WG_WAVES = 8;                        // 2 (n) x 4 (k): 128 x 64 of the tile per wave, two waves per SIMD
+constexpr int WG_DMA_PER_WAVE = 4;                 // 1-KiB sub-tiles a wave brings per step
 
 struct WgradParams {
     const char* g;       // [M][ldg] bf16
@@ -39,7 +55,7 @@ struct WgradParams {
     int M, N, K;
     int tiles_k;         // K / 256
     int n_tiles;         // (N / 256) * tiles_k
-    int steps_per_split; // 64-token steps per split (the last split may have fewer)
+    int steps_per_split; // 32-token steps per split (the last split may have fewer)
 };
 
 template <int IMM>
@@ -53,10 +69,10 @@ GTA_DEV float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
 GTA_DEV float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
 template <bool BIAS>
-__global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradParams p) {
+__global__ __launch_bounds__(64 * WG_WAVES) void wgrad_kernel(WgradParams p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave >> 1, wk = wave & 1;
+    const int wn = wave >> 2, wk = wave & 3;
     // XCD-aware work map: workgroup L runs on XCD L % 8.  Workgroups of one token split share their operand tiles (the G
     // tile of a row of dW tiles, the X tile of a column), so each XCD takes a CONTIGUOUS run of the (split, tile) list and
     // its L2 serves the re-reads (measured: the kernel is bound by the fabric otherwise, 4.8 TB/s into the LDS).
@@ -66,89 +82,130 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradParams p) {
     const int tile = v % p.n_tiles, split = v / p.n_tiles;
     const int n0 = (tile / p.tiles_k) * WG_TILE, k0 = (tile % p.tiles_k) * WG_TILE;
     const int step0 = split * p.steps_per_split;
-    int n_steps = p.M / WG_BT - step0;
+    int n_steps = p.M / WG_BT - step0;                                     // 32-token steps of this split
     if (n_steps > p.steps_per_split) n_steps = p.steps_per_split;
 
-    // ---- DMA plan: 64 sub-tiles of 1 KiB per stage; waves 0,1 bring G (32 sub-tiles), waves 2,3 bring X ----
-    const bool is_x = wave >= 2;
+    // ---- DMA plan: 32 sub-tiles of 1 KiB per step; waves 0,1 bring G (16 sub-tiles), waves 2,3 bring X ----
+    // A sub-tile is [8 tokens][64 columns]: lane l fetches 16 B of row l/8 -- eight lanes cover one whole 128-B line (the
+    // vector-memory path works per line: 64-B row segments cost twice the address work for the same bytes).  Which of
+    // the row's eight 16-B chunks a lane fetches is swizzled, chunk = (l % 8) ^ 4*((row >> 1) & 1), so that in the
+    // lane-linear LDS image (128-B rows) rows 0..3 of a 64-B column band land in four different bank quarters.
+    const bool is_x = wave >= 4;
     const char* src = is_x ? p.x : p.g;
     const long ld = is_x ? p.ldx : p.ldg;
     const int c0 = is_x ? k0 : n0;
-    const int piece0 = (wave & 1) * 16;                                   // this wave's 16 sub-tiles of its operand
-    // lane's byte offset inside a sub-tile's source: row lane/4, 16-B chunk lane%4
-    const long lane_src = ((long)(lane >> 2) * ld + (lane & 3) * 8) * 2;
+    const int piece0 = (wave & 3) * WG_DMA_PER_WAVE;                       // this wave's 4 sub-tiles of its operand
+    const int drow = lane >> 3, dchunk = (lane & 7) ^ (((drow >> 1) & 1) << 2);
+    const long lane_src = ((long)drow * ld + dchunk * 8) * 2;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)smem;
 
     auto stage_dma = [&](int step, int stage) {
         const long m0 = (long)(step0 + step) * WG_BT;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int pc = piece0 + q, tg = pc >> 3, cg = pc & 7;
-            const char* gp = src + ((m0 + tg * 16) * ld + c0 + cg * 32) * 2 + lane_src;
-            char* lp = smem + stage * WG_STAGE + (is_x ? WG_BT * WG_TILE * 2 : 0) + pc * 1024;
+        for (int q = 0; q < WG_DMA_PER_WAVE; ++q) {
+            const int pc = piece0 + q, t8 = pc >> 2, cg = pc & 3;           // [token group of 8][column group of 64]
+            const char* gp = src + ((m0 + t8 * 8) * ld + c0 + cg * 64) * 2 + lane_src;
+            char* lp = smem + stage * WG_STAGE + (is_x ? WG_OPER : 0) + pc * 1024;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
                                              (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
         }
     };
+    // wait until at most `groups` of my DMA groups (WG_DMA_PER_WAVE instructions each) are still in flight
+    auto dma_wait = [&](int groups) {
+        if (groups >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * WG_DMA_PER_WAVE) : "memory");
+        else if (groups == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WG_DMA_PER_WAVE) : "memory");
+        else if (groups == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WG_DMA_PER_WAVE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    static_assert(WG_NSTAGE >= 2 && WG_NSTAGE <= 5, "ring depth (dma_wait counts up to three groups in flight beside the awaited one)");
 
-    // ---- operand addresses: lane -> its [4 token][16 column] block inside a sub-tile (64-B rows) ----
-    const uint32_t la = (uint32_t)(((lane >> 5) * 8 + ((lane & 15) >> 2)) * 64 + (((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2);
-    const uint32_t a_base = lds0 + wn * 4096 + la;                         // G sub-tiles wn*4 .. wn*4+3 of a token group
-    const uint32_t b_base = lds0 + WG_BT * WG_TILE * 2 + wk * 4096 + la;   // X sub-tiles wk*4 ..
+    // ---- operand addresses.  An MFMA operand is [32 columns][16 tokens]: lanes 0-31 hold tokens 0-7 (sub-tile row group
+    // t8 = 2u), lanes 32-63 tokens 8-15 (t8 = 2u + 1, 4 KiB further); a 16-lane group reads the [4 token][16 column] block
+    // of rows 0-3 (first read) or 4-7 (second, +512 B) of its 16 columns: lane p of the group points at row p/4, columns
+    // 4(p%4)..+3, i.e. 16-B chunk (16-column block)*2 + (p%4)/2 of the 64-column band, un-swizzled as it was stored.
+    // The two 32-column halves of a band differ in chunk bit 2, which the swizzle XORs: two lane bases, ^64 B apart. ----
+    const int grp = lane >> 4, pl = lane & 15, rrow = pl >> 2;
+    const int chunk0 = ((grp & 1) * 2 + ((pl & 3) >> 1)) ^ (((rrow >> 1) & 1) << 2);
+    const uint32_t la0 = (uint32_t)((lane >> 5) * 4096 + rrow * 128 + chunk0 * 16 + (pl & 1) * 8);
+    const uint32_t la1 = la0 ^ 64u;
+    const uint32_t a_base0 = lds0 + wn * 2048 + la0, a_base1 = lds0 + wn * 2048 + la1;                 // G bands wn*2, wn*2+1
+    const uint32_t b_base0 = lds0 + WG_OPER + wk * 1024 + la0, b_base1 = lds0 + WG_OPER + wk * 1024 + la1;     // X band wk
 
-    f32x16_t acc[4][4];
+    f32x16_t acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     float dbs[4] = {0.f, 0.f, 0.f, 0.f};
 
-    if (n_steps > 0) stage_dma(0, 0);
-
-    for (int t = 0; t < n_steps; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // my pieces of step t have landed
-        __builtin_amdgcn_s_barrier();                                       // everyone's have; stage (t+1)&1 is free again
-        if (t + 1 < n_steps) stage_dma(t + 1, (t + 1) & 1);
-        const uint32_t ab = a_base + (t & 1) * WG_STAGE, bb = b_base + (t & 1) * WG_STAGE;
-
-        u32x2_t af[2][4][2], bf[2][4][2];                                   // [buffer][32-column group][token half]
-        auto load_frags = [&](auto TG, int buf) {
-            constexpr int tg = decltype(TG)::value;
-            gta_static_for<4>([&](auto I) {
-                constexpr int i = decltype(I)::value;
-                af[buf][i][0] = tr16<(tg * 8 + i) * 1024>(ab);
-                af[buf][i][1] = tr16<(tg * 8 + i) * 1024 + 256>(ab);
-            });
-            gta_static_for<4>([&](auto J) {
-                constexpr int j = decltype(J)::value;
-                bf[buf][j][0] = tr16<(tg * 8 + j) * 1024>(bb);
-                bf[buf][j][1] = tr16<(tg * 8 + j) * 1024 + 256>(bb);
-            });
-        };
-        load_frags(std::integral_constant<int, 0>{}, 0);
-        gta_static_for<4>([&](auto TG) {
-            constexpr int tg = decltype(TG)::value, cur = tg & 1;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (tg < 3) load_frags(std::integral_constant<int, tg + 1>{}, cur ^ 1);
-            bf16x8_t a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const u32x4_t av = {af[cur][i][0].x, af[cur][i][0].y, af[cur][i][1].x, af[cur][i][1].y};
-                const u32x4_t bv = {bf[cur][i][0].x, bf[cur][i][0].y, bf[cur][i][1].x, bf[cur][i][1].y};
-                a[i] = __builtin_bit_cast(bf16x8_t, av);
-                b[i] = __builtin_bit_cast(bf16x8_t, bv);
-                if (BIAS && wk == 0 && k0 == 0)
-                    dbs[i] += ((bf16_lo(av.x) + bf16_hi(av.x)) + (bf16_lo(av.y) + bf16_hi(av.y))) +
-                              ((bf16_lo(av.z) + bf16_hi(av.z)) + (bf16_lo(av.w) + bf16_hi(av.w)));
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    u32x2_t af[2][4][2], bf[2][2][2];                                       // [buffer][32-column group][token half]
+    // fragments of the 16-token group u (sub-tile row groups 2u, 2u+1) of the stage at byte offset `so`
+    auto load_frags = [&](uint32_t so, auto U, int buf) {
+        constexpr int u = decltype(U)::value;
+        gta_static_for<4>([&](auto I) {
+            constexpr int i = decltype(I)::value, off = (2 * u * 4 + (i >> 1)) * 1024;
+            const uint32_t ab = ((i & 1) ? a_base1 : a_base0) + so;
+            af[buf][i][0] = tr16<off>(ab);
+            af[buf][i][1] = tr16<off + 512>(ab);
         });
+        gta_static_for<2>([&](auto J) {
+            constexpr int j = decltype(J)::value, off = 2 * u * 4 * 1024;
+            const uint32_t bb = (j ? b_base1 : b_base0) + so;
+            bf[buf][j][0] = tr16<off>(bb);
+            bf[buf][j][1] = tr16<off + 512>(bb);
+        });
+    };
+    auto mfma_block = [&](int cur) {
+        bf16x8_t a[4], b[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32x4_t av = {af[cur][i][0].x, af[cur][i][0].y, af[cur][i][1].x, af[cur][i][1].y};
+            a[i] = __builtin_bit_cast(bf16x8_t, av);
+            if (BIAS && wk == 0 && k0 == 0)
+                dbs[i] += ((bf16_lo(av.x) + bf16_hi(av.x)) + (bf16_lo(av.y) + bf16_hi(av.y))) +
+                          ((bf16_lo(av.z) + bf16_hi(av.z)) + (bf16_lo(av.w) + bf16_hi(av.w)));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const u32x4_t bv = {bf[cur][j][0].x, bf[cur][j][0].y, bf[cur][j][1].x, bf[cur][j][1].y};
+            b[j] = __builtin_bit_cast(bf16x8_t, bv);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    };
+
+    // prologue: the ring's first NSTAGE steps are requested; step 0 is awaited
+    const int pre = n_steps < WG_NSTAGE ? n_steps : WG_NSTAGE;
+    for (int s0 = 0; s0 < pre; ++s0) stage_dma(s0, s0);
+    dma_wait(pre - 1);
+    __builtin_amdgcn_s_barrier();
+    load_frags(0u, std::integral_constant<int, 0>{}, 0);
+
+    int st = 0;                                                             // ring stage of step t
+    for (int t = 0; t < n_steps; ++t) {
+        // A: token group 0 of step t; group 1's fragments fly under its MFMAs
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags((uint32_t)(st * WG_STAGE), std::integral_constant<int, 1>{}, 1);
+        mfma_block(0);
+        // B: token group 1; before its MFMAs the ring turns: step t's stage is read out by everyone (barrier) and takes
+        // step t + NSTAGE, and the first fragments of step t + 1 fly under these MFMAs
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const int st1 = st + 1 == WG_NSTAGE ? 0 : st + 1;
+        if (t + 1 < n_steps) {
+            const int last_issued = t + WG_NSTAGE - 1 < n_steps - 1 ? t + WG_NSTAGE - 1 : n_steps - 1;
+            dma_wait(last_issued - (t + 1));                                // step t + 1 has landed (my share of it)
+            __builtin_amdgcn_s_barrier();                                    // ... and everyone's; stage st is free
+            if (t + WG_NSTAGE < n_steps) stage_dma(t + WG_NSTAGE, st);
+            load_frags((uint32_t)(st1 * WG_STAGE), std::integral_constant<int, 0>{}, 0);
+        }
+        mfma_block(1);
+        st = st1;
     }
 
     // ---- epilogue: accumulators -> this split's partial tile (rows n, 128-B segments along k) ----
@@ -156,11 +213,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradParams p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wn * 128 + i * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
-                const int k = k0 + wk * 128 + j * 32 + (lane & 31);
+                const int k = k0 + wk * 64 + j * 32 + (lane & 31);
                 out[(long)n * p.ldo + k] = acc[i][j][r];
             }
     if (BIAS && wk == 0 && k0 == 0) {
@@ -198,7 +255,7 @@ inline Split choose_split(long m, long n, long k) {
     const int total = (int)(m / WG_BT);
     int want = 256 / tiles;                     // one workgroup per CU
     if (want < 1) want = 1;
-    if (want > total / 4) want = total / 4 > 0 ? total / 4 : 1;            // at least four steps per workgroup
+    if (want > total / 8) want = total / 8 > 0 ? total / 8 : 1;            // at least eight 32-token steps per workgroup
     const int steps = (total + want - 1) / want;
     return {(total + steps - 1) / steps, steps};
 }
@@ -239,8 +296,8 @@ int gta_wgrad(const void* g, int64_t ldg, const void* x, int64_t ldx, int64_t m,
     hipStream_t s = static_cast<hipStream_t>(stream);
     int rc = dbias ? gta_lds_optin<&wgrad_kernel<true>>(WG_LDS) : gta_lds_optin<&wgrad_kernel<false>>(WG_LDS);
     if (rc != 0) return rc;
-    if (dbias) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(p.n_tiles * sp.S), dim3(256), WG_LDS, s, p);
-    else       hipLaunchKernelGGL(wgrad_kernel<false>, dim3(p.n_tiles * sp.S), dim3(256), WG_LDS, s, p);
+    if (dbias) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(p.n_tiles * sp.S), dim3(64 * WG_WAVES), WG_LDS, s, p);
+    else       hipLaunchKernelGGL(wgrad_kernel<false>, dim3(p.n_tiles * sp.S), dim3(64 * WG_WAVES), WG_LDS, s, p);
     if (hipGetLastError() != hipSuccess) return GTA_E_LAUNCH;
     const long n4 = n * k / 4;
     hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p.part, sp.S, (long)n * k, n4, dw,

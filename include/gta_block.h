@@ -127,7 +127,7 @@ int gta_gemm(const GtaGemmDesc* desc, const void* a, const void* b, const void* 
  *   G = d(out) [m,n] bf16 (leading dimension ldg), X = the layer's input [m,k] bf16 (ldx); dW [n,k] fp32 contiguous,
  *   dbias [n] fp32 or NULL.  The reduction index m (batch x tokens) is the slow index of both operands -- the shape
  *   hipBLASLt is weakest at.  Split over m across the chip, partial tiles reduced in a fixed order (deterministic).
- *   Supported when m % 64 == 0, n % 256 == 0, k % 256 == 0 (gta_wgrad_supported); else use gta_gemm(trans_a) + gta_colsum.
+ *   Supported when m % 32 == 0, n % 256 == 0, k % 256 == 0 (gta_wgrad_supported); else use gta_gemm(trans_a) + gta_colsum.
  *   workspace: gta_wgrad_workspace_bytes(m, n, k).
  * --------------------------------------------------------------------------------------------------------------- */
 int gta_wgrad_supported(int64_t m, int64_t n, int64_t k);
