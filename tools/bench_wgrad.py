@@ -1,3 +1,4 @@
+"""Time gta_wgrad (with the fused bias gradient) at the MSN layer shapes, 40 960 tokens: python tools/bench_wgrad.py (on an MI355X)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gta_amd import native_block as nb
