@@ -221,6 +221,11 @@ def main():
     ap.add_argument("--model-batch", type=int, default=8, help="per-GPU scenes for --model-train-steps")
     ap.add_argument("--train-steps", type=int, default=10,
                     help="extra (untimed-for-`value`) forward+backward steps reported as fwd_bwd_* fields; 0 = skip")
+    ap.add_argument("--kernel-samples", type=int, default=10,
+                    help="how many of the K timed steps carry the dispatch events that time the attention kernel (evenly "
+                         "spaced over the timed region).  The events cost ~7 us of launch gap in front of the kernel they "
+                         "bracket (profiles/r02/final_step_gaps.txt), so bracketing every step would slow the metric it "
+                         "sits in; 0 = every step")
     ap.add_argument("--block-steps", type=int, default=5,
                     help="also time one whole pre-LN layer around the operator (SURVEY 8 f1: the fused block of libgta_block.so "
                          "against the module-by-module path), forward and forward+backward; reported as `block_layer`, not "
@@ -270,7 +275,10 @@ def main():
     reps_q = plan.RepPlan(B, Nq, Pq, so3_deg, so2, device=device) if (reps_k is not None and cross) else None
     fwd = plan.ForwardPlan(q, k, v, f_dims, so3_degree=so3_deg, Nq=Nq if need_view else 1, Nk=Nk if need_view else 1,
                            flags=native.FLAG_FUSED_KV if fused else 0)
-    ev = [(L.gta_debug_event_create(), L.gta_debug_event_create()) for _ in range(args.steps)]
+    n_samp = args.steps if args.kernel_samples <= 0 else min(args.kernel_samples, args.steps)
+    stride = max(1, args.steps // n_samp)
+    sampled = {i: len(range(stride // 2, i, stride)) for i in range(stride // 2, args.steps, stride)}   # step -> event slot
+    ev = [(L.gta_debug_event_create(), L.gta_debug_event_create()) for _ in sampled]
 
     def build_reps():
         if reps_k is not None:
@@ -287,8 +295,9 @@ def main():
 
     def step(i=None):
         vq, vk, cq, ck = build_reps()                      # reps are rebuilt every step (timed)
-        if i is not None and not fused:
-            L.gta_debug_time_next_attention_kernel(ctypes.c_void_p(ev[i][0]), ctypes.c_void_p(ev[i][1]))
+        if i in sampled and not fused:
+            e = ev[sampled[i]]
+            L.gta_debug_time_next_attention_kernel(ctypes.c_void_p(e[0]), ctypes.c_void_p(e[1]))
         return fwd(q, k, v, vq, vk, cq, ck, tc)
 
     for _ in range(args.warmup):
@@ -432,7 +441,7 @@ def main():
             line["roofline"] = {"bound": "mfma", "kernel": "gta_fwd2_kernel", "achieved": achieved,
                                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
                                 "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                                "kernel_ms": kern_ms, "algorithmic_flops": flops, "algorithmic_bytes": alg_bytes,
+                                "kernel_ms": kern_ms, "kernel_samples": len(ev), "algorithmic_flops": flops, "algorithmic_bytes": alg_bytes,
                                 "hbm_frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                 "step_frac": flops / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS}
         if parity is not None:

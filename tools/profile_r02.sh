@@ -5,13 +5,15 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_r02
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $OUT
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity --train-steps 10 > $OUT/bench_stats.log 2>&1
-timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-parity --train-steps 2 > $OUT/bench_fetch.log 2>&1
-timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-parity --train-steps 2 > $OUT/bench_write.log 2>&1
-timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace --output-format csv -d $OUT/pmc_sq -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-parity --train-steps 0 > $OUT/bench_sq.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity --block-steps 0 --train-steps 10 > $OUT/bench_stats.log 2>&1
+timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-parity --block-steps 0 --train-steps 2 > $OUT/bench_fetch.log 2>&1
+timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-parity --block-steps 0 --train-steps 2 > $OUT/bench_write.log 2>&1
+timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace --output-format csv -d $OUT/pmc_sq -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-parity --block-steps 0 --train-steps 0 > $OUT/bench_sq.log 2>&1
 cd $R
 python tools/step_gaps.py gpurun_out/prof_r02/stats > $OUT/step_gaps.txt 2>&1; cat $OUT/step_gaps.txt
 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err; tail -c 1500 $OUT/bench_line.json
+if [ -n "$GTA_PROFILE_FULL" ]; then   # per-item timeline (instrumented build), A/B of the grids, pre-pass timings
 GTA_HIP_LIB=$R/gta_amd/csrc/libgta_hip_ablate.so GTA_TL_DEFAULT_ONLY= python tools/bench_kernels.py timeline > $OUT/timeline.txt 2>&1
 python tools/bench_kernels.py ab > $OUT/ab.txt 2>&1; cat $OUT/ab.txt
 python tools/bench_kernels.py prep > $OUT/prep.txt 2>&1; cat $OUT/prep.txt
+fi
