@@ -700,20 +700,33 @@ int launch_fwd2(const GtaFwdParams& p, hipStream_t stream) {
     const void* kfn = reinterpret_cast<const void*>(&gta_fwd2_kernel<DHP, ESZ, LAYOUT>);
     if (int rc = gta_lds_optin<&gta_fwd2_kernel<DHP, ESZ, LAYOUT>>(S::total(GTA_MAX_VIEWS))) return rc;
     int lds = S::total(p.vrep_q ? p.nrec : 0);
-    // Default: one workgroup per item.  GTA_FLAG_PERSIST: a persistent grid of as many workgroups as are resident at once
+    // One workgroup per item, or (GTA_FLAG_PERSIST / the few-rounds rule below) a persistent grid of as many workgroups as are resident at once
     // (registers and LDS: two per CU at dh = 96, three at dh = 64), a multiple of 8 so that the virtual ids of a workgroup
     // stay on its XCD.
     GtaFwdParams pl = p;
     long grid = p.n_items;
     pl.per_cu = 0;
-    if (p.flags & GTA_FLAG_PERSIST) {
-        int dev = 0, cus = 0, per_cu = 0;
+    {
+        // resident workgroups of this instance on this device (queried once per device and LDS size)
+        static int slots_dev[64], slots_lds[64], slots_percu[64];
+        int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) return GTA_E_NODEVICE;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-        long g = (long)cus * per_cu;
-        g -= g % 8;
-        if (g >= 8 && g < grid) { grid = g; pl.per_cu = per_cu; }
+        int cus = 0, per_cu = 0;
+        long g = 0;
+        if (dev >= 0 && dev < 64 && slots_dev[dev] > 0 && slots_lds[dev] == lds) { g = slots_dev[dev]; per_cu = slots_percu[dev]; }
+        else {
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+            g = (long)cus * per_cu;
+            g -= g % 8;
+            if (dev >= 0 && dev < 64) { slots_dev[dev] = (int)g; slots_lds[dev] = lds; slots_percu[dev] = per_cu; }
+        }
+        // Persistent grid on request, and by default for launches of more than one but at most two rounds of resident
+        // workgroups (the 600-token CLEVR-TR encoder: 960 items on 768 slots): there the second round runs a quarter
+        // full, and walking the items with the ring running on is the faster form (35.9 against 39.3 us); at every
+        // shape of five and more rounds it is the slower one (profiles/r02/README.md).
+        const bool few_rounds = p.n_items > g && p.n_items <= 2 * g;
+        if (((p.flags & GTA_FLAG_PERSIST) || few_rounds) && g >= 8 && g < grid) { grid = g; pl.per_cu = per_cu; }
     }
 #ifdef GTA_ABLATE
     if (const char* e = getenv("GTA_LDS_PAD")) {        // occupancy experiment: inflate LDS so fewer workgroups share a CU

@@ -39,7 +39,8 @@ extern "C" {
 #define GTA_FLAG_PREP_ONLY     (1u << 5) /* two-stage plan: run only the K/V pre-pass (fills workspace) */
 #define GTA_FLAG_KV_READY      (1u << 4) /* workspace already holds K'/V' for these k,v,reps:     */
                                          /* skip the pre-pass (several query sets, one key set)   */
-#define GTA_FLAG_PERSIST       (1u << 9) /* tuning: persistent grid (resident workgroups walk the query tiles) instead of one workgroup per tile */
+#define GTA_FLAG_PERSIST       (1u << 9) /* tuning: persistent grid (resident workgroups walk the query tiles) instead of one workgroup per tile; */
+                                         /* chosen automatically for launches of 1..2 rounds of resident workgroups (short sequences) */
 #define GTA_FLAG_FP32_PRODUCTS (1u << 10) /* fp32 inputs: split-bf16 (hi+lo) operands, three MFMAs per product: fp32-class */
                                          /* results for the reference's mixed_prec: False configs, single-kernel plan, 3x the MFMAs */
 #define GTA_FLAG_NO_DMA        (1u << 8) /* debug: stage K/V tiles through VGPRs, not LDS-DMA  */
