@@ -109,8 +109,9 @@ _ws_cache: dict = {}
 
 
 def gemm_workspace(device) -> torch.Tensor:
-    """One hipBLASLt workspace per device, reused by every call (calls on one stream are ordered)."""
-    key = (device.type, device.index)
+    """One hipBLASLt workspace per (device, stream): calls on one stream are ordered, calls on different streams may
+    overlap and must not share scratch memory."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _ws_cache.get(key)
     if ws is None:
         ws = torch.empty(lib().gta_gemm_workspace_bytes(), device=device, dtype=torch.uint8)
