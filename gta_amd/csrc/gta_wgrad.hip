@@ -19,13 +19,16 @@
 // between its two 16-token MFMA blocks, so every fragment read flies under an MFMA block.  Each wave owns 128 x 64 of the
 // tile: 8 accumulators of 32 x 32, 16 MFMAs against 24 transpose-reads and 4 DMA instructions per step.
 //
-// What bounds it (profiles/r02/README.md): 600-760 TFLOP/s = ~10 B per clock and CU into the LDS, whatever the shape of the
-// loop -- one wave per SIMD with 128 x 128 per wave and a two-stage ring of 64-token steps, 64-B or 128-B row segments per
-// DMA lane group, two to four stages, four or eight waves all land within 2 % of each other; HBM traffic is 1.7x the
-// algorithmic bytes (FETCH_SIZE), LDS conflicts are zero, the matrix pipe is busy 40 % of the time.  The rate is that of
-// the LDS-DMA path itself (a 1-KiB global_load_lds costs ~100 cycles of the CU's address unit): 32 of them per 32-token
-// step.  A tile with more flops per loaded byte does not fit the accumulator registers (256 x 256 fp32 = half the CU's
-// register file).
+// What bounds it (profiles/r02/README.md): the transpose-reads.  ds_read_b64_tr_b16 occupies the LDS for 8 cycles per
+// wave-instruction (SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS), i.e. 64 B per clock and CU, half the rate of ds_read_b128, and a
+// TN product needs them for BOTH operands: 192 reads = 1 536 LDS cycles per 32-token step against 1 024 cycles of MFMA per
+// SIMD.  Measured on dW[2304,768]: 231 us as is, 191 us with the DMA switched off (compute on stale LDS), 114 us with the
+// MFMAs and fragment reads switched off (DMA alone: 11 TB/s into the LDS) -- so neither HBM (FETCH_SIZE 1.7x the
+// algorithmic bytes) nor the DMA path is the limit, and four structurally different loops (one or two waves per SIMD,
+// 128 x 128 or 128 x 64 per wave, two to four stages, 64-B or 128-B row segments per DMA lane group) land within 2 % of
+// each other at 600-760 TFLOP/s.  Fewer reads per MFMA would need a larger tile per wave than the accumulator registers
+// allow; the way out is an operand the PRODUCER already wrote token-major (as the K/V pre-pass does for the attention
+// kernel), which none of this block's producers do yet.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "gta_common.h"
