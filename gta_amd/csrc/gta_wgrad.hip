@@ -19,16 +19,17 @@
 // between its two 16-token MFMA blocks, so every fragment read flies under an MFMA block.  Each wave owns 128 x 64 of the
 // tile: 8 accumulators of 32 x 32, 16 MFMAs against 24 transpose-reads and 4 DMA instructions per step.
 //
-// What bounds it (profiles/r02/README.md): the transpose-reads.  ds_read_b64_tr_b16 occupies the LDS for 8 cycles per
-// wave-instruction (SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS), i.e. 64 B per clock and CU, half the rate of ds_read_b128, and a
-// TN product needs them for BOTH operands: 192 reads = 1 536 LDS cycles per 32-token step against 1 024 cycles of MFMA per
-// SIMD.  Measured on dW[2304,768]: 231 us as is, 191 us with the DMA switched off (compute on stale LDS), 114 us with the
-// MFMAs and fragment reads switched off (DMA alone: 11 TB/s into the LDS) -- so neither HBM (FETCH_SIZE 1.7x the
-// algorithmic bytes) nor the DMA path is the limit, and four structurally different loops (one or two waves per SIMD,
-// 128 x 128 or 128 x 64 per wave, two to four stages, 64-B or 128-B row segments per DMA lane group) land within 2 % of
-// each other at 600-760 TFLOP/s.  Fewer reads per MFMA would need a larger tile per wave than the accumulator registers
-// allow; the way out is an operand the PRODUCER already wrote token-major (as the K/V pre-pass does for the attention
-// kernel), which none of this block's producers do yet.
+// What bounds it (profiles/r02/README.md).  Switch experiment on dW[2304,768]: 231 us as is, 191 us with the DMA switched
+// off (compute on stale LDS), 114 us with the MFMAs and fragment reads switched off (the DMA alone: 11 TB/s into the LDS)
+// -- so neither HBM (FETCH_SIZE 1.7x the algorithmic bytes) nor the DMA path is the limit; it is the wave's own stream of
+// fragment reads and MFMAs.  The LDS array is not saturated (SQ_LDS_IDX_ACTIVE: 2 cycles per ds_read_b64_tr_b16, 384 per
+// 32-token step against 1 024 cycles of MFMA per SIMD, zero bank conflicts), but 8-byte-per-lane reads reach the array's
+// rate only from about four waves per SIMD (MI355X_MICROARCH.md, LDS table: one wave alone gets a fifth), and a TN
+// product needs two of them per operand fragment for BOTH operands: 1 to 1.5 reads per MFMA with one or two waves per
+// SIMD.  Four structurally different loops (128 x 128 or 128 x 64 per wave, two to four stages, 64-B or 128-B row segments
+// per DMA lane group) land within 2 % of each other at 600-760 TFLOP/s.  The way out is an operand the PRODUCER already
+// wrote token-major, so that fragments are one ds_read_b128 each (as the K/V pre-pass does for the attention kernel's
+// K'); none of this block's producers do that yet.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "gta_common.h"
