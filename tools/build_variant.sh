@@ -10,6 +10,6 @@ BASEFLAGS="-fno-slp-vectorize"
 [ "$FILE" != "gta_fwd2.hip" ] && BASEFLAGS=""
 mkdir -p build_var
 /opt/rocm/bin/hipcc -DGTA_ABLATE -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $BASEFLAGS $@ -c $FILE -o build_var/${FILE%.hip}_$NAME.o
-OBJS=$(ls build_ablate/*.o | grep -v ${FILE%.hip})
+OBJS=$(ls build_ablate/*.o | grep -v ${FILE%.hip} | grep -v "gta_block\|gta_wgrad\|gta_gemm")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libgta_var_$NAME.so build_var/${FILE%.hip}_$NAME.o $OBJS
 echo built libgta_var_$NAME.so
