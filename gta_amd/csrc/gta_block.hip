@@ -49,6 +49,33 @@ template <> struct Vec8<GTA_DTYPE_BF16> {
     }
 };
 
+// VW consecutive elements of a row <-> VW floats: VW = 8 (16-byte accesses of bf16, rows that are multiples of 8 elements) or
+// VW = 4 (8-byte accesses of bf16 / 16-byte of fp32, rows that are multiples of 4: the MSN decoder's d = 180)
+template <int DT, int VW> struct VecN;
+template <int DT> struct VecN<DT, 8> {
+    static BLK_DEV void load(const void* p, int64_t e, float (&v)[8]) { Vec8<DT>::load(p, e, v); }
+    static BLK_DEV void store(void* p, int64_t e, const float (&v)[8]) { Vec8<DT>::store(p, e, v); }
+};
+template <> struct VecN<GTA_DTYPE_F32, 4> {
+    static BLK_DEV void load(const void* p, int64_t e, float (&v)[4]) {
+        const float4 a = *reinterpret_cast<const float4*>(static_cast<const float*>(p) + e);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    }
+    static BLK_DEV void store(void* p, int64_t e, const float (&v)[4]) {
+        *reinterpret_cast<float4*>(static_cast<float*>(p) + e) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <> struct VecN<GTA_DTYPE_BF16, 4> {
+    static BLK_DEV void load(const void* p, int64_t e, float (&v)[4]) {
+        const uint2 a = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(p) + e);
+        v[0] = bf16_to_f(a.x & 0xffffu); v[1] = bf16_to_f(a.x >> 16); v[2] = bf16_to_f(a.y & 0xffffu); v[3] = bf16_to_f(a.y >> 16);
+    }
+    static BLK_DEV void store(void* p, int64_t e, const float (&v)[4]) {
+        *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p) + e) =
+            make_uint2(f_to_bf16(v[0]) | (f_to_bf16(v[1]) << 16), f_to_bf16(v[2]) | (f_to_bf16(v[3]) << 16));
+    }
+};
+
 BLK_DEV float wave_sum(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
@@ -58,7 +85,7 @@ BLK_DEV float wave_sum(float v) {
 // ---------------------------------------------------------------------------------------------------------------
 // LayerNorm forward: one 64-lane wave per row, the row held in registers (NJ chunks of 8 elements per lane, d <= 512 NJ).
 // ---------------------------------------------------------------------------------------------------------------
-template <int XDT, int YDT, int NJ>
+template <int XDT, int YDT, int NJ, int VW>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps, int64_t rows, int d,
                                                      void* __restrict__ y, float* __restrict__ mean_out,
@@ -67,15 +94,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int64_t base = row * d;
-    float v[NJ][8];
+    float v[NJ][VW];
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int e = (lane + 64 * j) * 8;
+        const int e = (lane + 64 * j) * VW;
         if (e < d) {
-            Vec8<XDT>::load(x, base + e, v[j]);
+            VecN<XDT, VW>::load(x, base + e, v[j]);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) s += v[j][i];
+            for (int i = 0; i < VW; ++i) s += v[j][i];
         }
     }
     const float inv_d = 1.0f / (float)d;
@@ -83,23 +110,23 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
     float q = 0.f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int e = (lane + 64 * j) * 8;
+        const int e = (lane + 64 * j) * VW;
         if (e < d) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { const float c = v[j][i] - mean; q += c * c; }
+            for (int i = 0; i < VW; ++i) { const float c = v[j][i] - mean; q += c * c; }
         }
     }
     const float rstd = rsqrtf(wave_sum(q) * inv_d + eps);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int e = (lane + 64 * j) * 8;
+        const int e = (lane + 64 * j) * VW;
         if (e < d) {
-            float g[8], b[8], o[8];
-            Vec8<GTA_DTYPE_F32>::load(gamma, e, g);
-            Vec8<GTA_DTYPE_F32>::load(beta, e, b);
+            float g[VW], b[VW], o[VW];
+            VecN<GTA_DTYPE_F32, VW>::load(gamma, e, g);
+            VecN<GTA_DTYPE_F32, VW>::load(beta, e, b);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) o[i] = (v[j][i] - mean) * rstd * g[i] + b[i];
-            Vec8<YDT>::store(y, base + e, o);
+            for (int i = 0; i < VW; ++i) o[i] = (v[j][i] - mean) * rstd * g[i] + b[i];
+            VecN<YDT, VW>::store(y, base + e, o);
         }
     }
     if (lane == 0) {
@@ -113,36 +140,36 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
 // dgamma / dbeta partial sums live in registers across the walk, are reduced over the 4 waves through LDS and written
 // to part[g][2][d]; colsum_finish_kernel adds the G partials in a fixed order.
 // ---------------------------------------------------------------------------------------------------------------
-template <int GDT, int XDT, int NJ>
+template <int GDT, int XDT, int NJ, int VW>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, int64_t rows, int d,
                                                      const void* dres, void* dx, void* dx_bf16, float* __restrict__ part) {
     extern __shared__ float lds[];            // [4][2][d]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float ag[NJ][8], ab[NJ][8], gm[NJ][8];
+    float ag[NJ][VW], ab[NJ][VW], gm[NJ][VW];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int e = (lane + 64 * j) * 8;
-        if (e < d) Vec8<GTA_DTYPE_F32>::load(gamma, e, gm[j]);
+        const int e = (lane + 64 * j) * VW;
+        if (e < d) VecN<GTA_DTYPE_F32, VW>::load(gamma, e, gm[j]);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { ag[j][i] = 0.f; ab[j][i] = 0.f; }
+        for (int i = 0; i < VW; ++i) { ag[j][i] = 0.f; ab[j][i] = 0.f; }
     }
     const float inv_d = 1.0f / (float)d;
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
         const int64_t base = row * d;
         const float mu = mean[row], rs = rstd[row];
-        float g[NJ][8], xh[NJ][8];
+        float g[NJ][VW], xh[NJ][VW];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int e = (lane + 64 * j) * 8;
+            const int e = (lane + 64 * j) * VW;
             if (e < d) {
-                float dyv[8], xv[8];
-                Vec8<GDT>::load(dy, base + e, dyv);
-                Vec8<XDT>::load(x, base + e, xv);
+                float dyv[VW], xv[VW];
+                VecN<GDT, VW>::load(dy, base + e, dyv);
+                VecN<XDT, VW>::load(x, base + e, xv);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < VW; ++i) {
                     xh[j][i] = (xv[i] - mu) * rs;
                     g[j][i] = dyv[i] * gm[j][i];
                     s1 += g[j][i];
@@ -155,27 +182,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         const float m1 = wave_sum(s1) * inv_d, m2 = wave_sum(s2) * inv_d;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int e = (lane + 64 * j) * 8;
+            const int e = (lane + 64 * j) * VW;
             if (e < d) {
-                float o[8];
-                if (dres) Vec8<XDT>::load(dres, base + e, o);
+                float o[VW];
+                if (dres) VecN<XDT, VW>::load(dres, base + e, o);
                 else {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) o[i] = 0.f;
+                    for (int i = 0; i < VW; ++i) o[i] = 0.f;
                 }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) o[i] += rs * (g[j][i] - m1 - xh[j][i] * m2);
-                Vec8<XDT>::store(dx, base + e, o);
-                if (dx_bf16) Vec8<GTA_DTYPE_BF16>::store(dx_bf16, base + e, o);
+                for (int i = 0; i < VW; ++i) o[i] += rs * (g[j][i] - m1 - xh[j][i] * m2);
+                VecN<XDT, VW>::store(dx, base + e, o);
+                if (dx_bf16) VecN<GTA_DTYPE_BF16, VW>::store(dx_bf16, base + e, o);
             }
         }
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int e = (lane + 64 * j) * 8;
+        const int e = (lane + 64 * j) * VW;
         if (e < d) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < VW; ++i) {
                 lds[(wave * 2 + 0) * d + e + i] = ag[j][i];
                 lds[(wave * 2 + 1) * d + e + i] = ab[j][i];
             }
@@ -217,25 +244,27 @@ __global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __rest
 
 // Column sums, stage 1: grid (ceil(n / 512), S strips); wave w of a workgroup walks rows (4 s + w), + 4 S, ...; a lane
 // owns 8 columns.  part[s][n].
-template <int DT>
+template <int DT, int VW>
 __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ a, int64_t m, int n, int64_t ld,
                                                      float* __restrict__ part) {
-    __shared__ float lds[4][512];
+    __shared__ float lds[4][64 * VW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int e = (blockIdx.x * 64 + lane) * 8;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int e = (blockIdx.x * 64 + lane) * VW;
+    float acc[VW];
+#pragma unroll
+    for (int i = 0; i < VW; ++i) acc[i] = 0.f;
     if (e < n)
         for (int64_t row = (int64_t)blockIdx.y * 4 + wave; row < m; row += (int64_t)gridDim.y * 4) {
-            float v[8];
-            Vec8<DT>::load(a, row * ld + e, v);
+            float v[VW];
+            VecN<DT, VW>::load(a, row * ld + e, v);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] += v[i];
+            for (int i = 0; i < VW; ++i) acc[i] += v[i];
         }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) lds[wave][lane * 8 + i] = acc[i];
+    for (int i = 0; i < VW; ++i) lds[wave][lane * VW + i] = acc[i];
     __syncthreads();
-    for (int c = threadIdx.x; c < 512; c += 256) {
-        const int col = blockIdx.x * 512 + c;
+    for (int c = threadIdx.x; c < 64 * VW; c += 256) {
+        const int col = blockIdx.x * 64 * VW + c;
         if (col < n) part[(int64_t)blockIdx.y * n + col] = (lds[0][c] + lds[1][c]) + (lds[2][c] + lds[3][c]);
     }
 }
@@ -380,12 +409,24 @@ inline int colsum_strips(int64_t m, int n) {
     return (int)(s < 1 ? 1 : s);
 }
 
-// dispatch over the chunks-per-lane count: d <= 512 * NJ
-template <class F> inline int by_nj(int d, F&& f) {
-    if (d <= 512) return f(std::integral_constant<int, 1>{});
-    if (d <= 1024) return f(std::integral_constant<int, 2>{});
-    if (d <= 2048) return f(std::integral_constant<int, 4>{});
-    return f(std::integral_constant<int, 8>{});
+// dispatch over the vector width (8 elements per lane and chunk when the row length allows, else 4) and the
+// chunks-per-lane count: d <= 64 * VW * NJ
+template <class F> inline int by_row(int d, F&& f) {
+    if (d % 8 == 0) {
+        if (d <= 512) return f(std::integral_constant<int, 1>{}, std::integral_constant<int, 8>{});
+        if (d <= 1024) return f(std::integral_constant<int, 2>{}, std::integral_constant<int, 8>{});
+        if (d <= 2048) return f(std::integral_constant<int, 4>{}, std::integral_constant<int, 8>{});
+        return f(std::integral_constant<int, 8>{}, std::integral_constant<int, 8>{});
+    }
+    if (d <= 256) return f(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{});
+    if (d <= 512) return f(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
+    if (d <= 1024) return f(std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});
+    return f(std::integral_constant<int, 8>{}, std::integral_constant<int, 4>{});
+}
+inline bool row_ok(int d) { return d > 0 && d % 4 == 0 && (d % 8 == 0 ? d <= 4096 : d <= 2048); }
+inline bool aligned_for(const void* p, int d, int dtype) {       // base alignment the row accesses need
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    return (d % 8 == 0 || dtype == GTA_DTYPE_F32) ? (a & 15u) == 0 : (a & 7u) == 0;
 }
 template <class F> inline int by_dtype(int dt, F&& f) {
     return dt == GTA_DTYPE_F32 ? f(std::integral_constant<int, GTA_DTYPE_F32>{}) : f(std::integral_constant<int, GTA_DTYPE_BF16>{});
@@ -398,15 +439,15 @@ extern "C" {
 int gta_ln_fwd(const void* x, int32_t x_dtype, const float* gamma, const float* beta, float eps, int64_t rows, int32_t d,
                void* y, int32_t y_dtype, float* mean, float* rstd, void* stream) {
     if (!x || !gamma || !beta || !y || rows <= 0 || d <= 0 || !dtype_ok(x_dtype) || !dtype_ok(y_dtype)) return GTA_E_BADARG;
-    if (d % 8 != 0 || d > 4096) return GTA_E_UNSUPPORTED;
-    if (!aligned16(x) || !aligned16(y) || !aligned16(gamma) || !aligned16(beta)) return GTA_E_BADARG;
+    if (!row_ok(d)) return GTA_E_UNSUPPORTED;
+    if (!aligned_for(x, d, x_dtype) || !aligned_for(y, d, y_dtype) || !aligned16(gamma) || !aligned16(beta)) return GTA_E_BADARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const unsigned grid = (unsigned)((rows + 3) / 4);
-    return by_nj(d, [&](auto nj) {
+    return by_row(d, [&](auto nj, auto vw) {
         return by_dtype(x_dtype, [&](auto xd) {
             return by_dtype(y_dtype, [&](auto yd) {
-                hipLaunchKernelGGL((ln_fwd_kernel<decltype(xd)::value, decltype(yd)::value, decltype(nj)::value>), dim3(grid),
-                                   dim3(256), 0, s, x, gamma, beta, eps, rows, d, y, mean, rstd);
+                hipLaunchKernelGGL((ln_fwd_kernel<decltype(xd)::value, decltype(yd)::value, decltype(nj)::value, decltype(vw)::value>),
+                                   dim3(grid), dim3(256), 0, s, x, gamma, beta, eps, rows, d, y, mean, rstd);
                 return launch_status();
             });
         });
@@ -425,19 +466,19 @@ int gta_ln_bwd(const void* dy, int32_t dy_dtype, const void* x, int32_t x_dtype,
         !dtype_ok(dy_dtype) || !dtype_ok(x_dtype))
         return GTA_E_BADARG;
     if (dx_dtype != x_dtype) return GTA_E_UNSUPPORTED;            // the skip connection keeps the stream's type
-    if (d % 8 != 0 || d > 4096) return GTA_E_UNSUPPORTED;
+    if (!row_ok(d)) return GTA_E_UNSUPPORTED;
     if (workspace_bytes < gta_ln_bwd_workspace_bytes(rows, d)) return GTA_E_BADARG;
-    if (!aligned16(dy) || !aligned16(x) || !aligned16(dx) || !aligned16(gamma) || (dres && !aligned16(dres)) ||
-        (dx_bf16 && !aligned16(dx_bf16)))
+    if (!aligned_for(dy, d, dy_dtype) || !aligned_for(x, d, x_dtype) || !aligned_for(dx, d, x_dtype) || !aligned16(gamma) ||
+        (dres && !aligned_for(dres, d, x_dtype)) || (dx_bf16 && !aligned_for(dx_bf16, d, GTA_DTYPE_BF16)))
         return GTA_E_BADARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int grid = ln_bwd_grid(rows);
     float* part = static_cast<float*>(workspace);
     const size_t lds = (size_t)8 * d * sizeof(float);            // 128 KiB at d = 4096
-    int rc = by_nj(d, [&](auto nj) {
+    int rc = by_row(d, [&](auto nj, auto vw) {
         return by_dtype(dy_dtype, [&](auto gd) {
             return by_dtype(x_dtype, [&](auto xd) {
-                auto kern = ln_bwd_kernel<decltype(gd)::value, decltype(xd)::value, decltype(nj)::value>;
+                auto kern = ln_bwd_kernel<decltype(gd)::value, decltype(xd)::value, decltype(nj)::value, decltype(vw)::value>;
                 if (lds > 64 * 1024 &&
                     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                     return GTA_E_LAUNCH;
@@ -520,14 +561,17 @@ int64_t gta_colsum_workspace_bytes(int64_t m, int32_t n) {
 
 int gta_colsum(const void* a, int32_t dtype, int64_t m, int32_t n, int64_t ld, float* out, void* workspace,
                int64_t workspace_bytes, void* stream) {
-    if (!a || !out || !workspace || m <= 0 || n <= 0 || ld < n || !dtype_ok(dtype) || !aligned16(a)) return GTA_E_BADARG;
-    if (n % 8 != 0 || ld % 8 != 0) return GTA_E_UNSUPPORTED;
+    if (!a || !out || !workspace || m <= 0 || n <= 0 || ld < n || !dtype_ok(dtype)) return GTA_E_BADARG;
+    if (n % 4 != 0 || ld % 4 != 0) return GTA_E_UNSUPPORTED;
+    const bool wide = n % 8 == 0 && ld % 8 == 0;
+    if (!aligned_for(a, wide ? 8 : 4, dtype)) return GTA_E_BADARG;
     if (workspace_bytes < gta_colsum_workspace_bytes(m, n)) return GTA_E_BADARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int strips = colsum_strips(m, n);
     float* part = static_cast<float*>(workspace);
     int rc = by_dtype(dtype, [&](auto dt) {
-        hipLaunchKernelGGL((colsum_kernel<decltype(dt)::value>), dim3((n + 511) / 512, strips), dim3(256), 0, s, a, m, n, ld, part);
+        if (wide) hipLaunchKernelGGL((colsum_kernel<decltype(dt)::value, 8>), dim3((n + 511) / 512, strips), dim3(256), 0, s, a, m, n, ld, part);
+        else      hipLaunchKernelGGL((colsum_kernel<decltype(dt)::value, 4>), dim3((n + 255) / 256, strips), dim3(256), 0, s, a, m, n, ld, part);
         return launch_status();
     });
     if (rc != GTA_OK) return rc;

@@ -268,6 +268,8 @@ def active_p(m) -> float:
 
 
 def norm_ok(norm) -> bool:
-    return (isinstance(norm, torch.nn.LayerNorm) and norm.elementwise_affine and norm.bias is not None
-            and len(norm.normalized_shape) == 1 and norm.normalized_shape[0] % 8 == 0 and norm.normalized_shape[0] <= 4096
-            and norm.weight.dtype == torch.float32)
+    if not (isinstance(norm, torch.nn.LayerNorm) and norm.elementwise_affine and norm.bias is not None
+            and len(norm.normalized_shape) == 1 and norm.weight.dtype == torch.float32):
+        return False
+    d = norm.normalized_shape[0]
+    return (d % 8 == 0 and d <= 4096) or (d % 4 == 0 and d <= 2048)       # gta_ln_fwd's row shapes (gta_block.h)

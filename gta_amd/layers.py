@@ -212,7 +212,9 @@ class Transformer(nn.Module):
         if not (_fused.norm_ok(attn.norm) and _fused.norm_ok(ff.norm) and isinstance(a.to_out, nn.Sequential)):
             return None
         lins = [a.to_qkv if a.selfatt else a.to_q, a.to_out[0], net[0], net[3]]
-        if any(l.weight.dtype != torch.float32 or l.in_features % 8 or l.out_features % 8 for l in lins):
+        if any(l.weight.dtype != torch.float32 or l.in_features % 4 or l.out_features % 4 for l in lins):
+            return None
+        if (x.shape[0] * x.shape[1]) % 2:                  # the elementwise kernels work on multiples of 8 elements
             return None
         return cdt
 

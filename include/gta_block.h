@@ -38,7 +38,8 @@ extern "C" {
 /* ---------------------------------------------------------------------------------------------------------------
  * LayerNorm over the last dimension (nn.LayerNorm(dim), layers.py:149; elementwise affine, biased variance).
  *   x [rows, d] (x_dtype) -> y [rows, d] (y_dtype) = (x - mean) * rstd * gamma + beta, statistics and arithmetic in
- *   fp32; mean, rstd [rows] fp32 out (needed by the backward) or NULL.  d % 8 == 0, d <= 4096.
+ *   fp32; mean, rstd [rows] fp32 out (needed by the backward) or NULL.  d % 8 == 0 and d <= 4096, or d % 4 == 0 and d <= 2048
+ *   (8-byte row accesses: the MSN decoder's d = 180).
  *   Writing y as bf16 is the "cast for the GEMM" that autocast does in a separate kernel.
  * --------------------------------------------------------------------------------------------------------------- */
 int gta_ln_fwd(const void* x, int32_t x_dtype, const float* gamma, const float* beta, float eps,
@@ -78,7 +79,7 @@ int gta_dropout_bwd(const void* dout, int32_t dout_dtype, void* dz, int32_t dz_d
                     void* stream);
 
 /* Column sums: out[n] (fp32) = sum over the m rows of a [m, n] (ld elements between rows); the bias gradient of a
- * Linear.  Deterministic.  workspace: gta_colsum_workspace_bytes(m, n).  n % 8 == 0. */
+ * Linear.  Deterministic.  workspace: gta_colsum_workspace_bytes(m, n).  n % 4 == 0, ld % 4 == 0. */
 int64_t gta_colsum_workspace_bytes(int64_t m, int32_t n);
 int gta_colsum(const void* a, int32_t dtype, int64_t m, int32_t n, int64_t ld, float* out,
                void* workspace, int64_t workspace_bytes, void* stream);

@@ -24,7 +24,8 @@ def _err(a, b):
     return (a.float() - b.float()).abs().max().item()
 
 
-@pytest.mark.parametrize("rows,d", [(37, 768), (4, 8), (129, 512), (50, 1024), (33, 1536), (9, 2048), (5, 4096), (1, 264)])
+@pytest.mark.parametrize("rows,d", [(37, 768), (4, 8), (129, 512), (50, 1024), (33, 1536), (9, 2048), (5, 4096), (1, 264),
+                                    (41, 180), (6, 4), (17, 1020), (3, 2044)])
 @pytest.mark.parametrize("xdt,ydt", [(torch.float32, BF), (torch.float32, torch.float32), (BF, BF)])
 def test_layernorm_forward_backward(rows, d, xdt, ydt):
     g = torch.Generator(device=DEV).manual_seed(rows * 7 + d)
@@ -54,9 +55,11 @@ def test_layernorm_forward_backward(rows, d, xdt, ydt):
 
 
 def test_layernorm_refuses_bad_shapes():
-    x = torch.randn(4, 12, device=DEV)
+    x = torch.randn(4, 10, device=DEV)
     with pytest.raises(GtaError):
-        nb.ln_fwd(x, torch.ones(12, device=DEV), torch.zeros(12, device=DEV), 1e-5, BF)
+        nb.ln_fwd(x, torch.ones(10, device=DEV), torch.zeros(10, device=DEV), 1e-5, BF)
+    with pytest.raises(GtaError):
+        nb.ln_fwd(torch.randn(2, 2052, device=DEV), torch.ones(2052, device=DEV), torch.zeros(2052, device=DEV), 1e-5, BF)
     with pytest.raises(GtaError):
         nb.ln_fwd(torch.randn(4, 16), torch.ones(16), torch.zeros(16), 1e-5, BF)      # CPU tensors: no fallback
 
@@ -75,6 +78,8 @@ def test_gelu_and_colsum(dt):
     want = x.double().sum(0)
     assert _err(nb.colsum(x), want) <= 1e-5 * x.double().abs().sum(0).max().item()
     assert _err(nb.colsum(x[:, 8:520]), want[8:520]) <= 1e-5 * x.double().abs().sum(0).max().item()   # strided rows
+    odd = torch.randn(333, 180, device=DEV, generator=g).to(dt)                  # rows of 4k elements: 8-byte accesses
+    assert _err(nb.colsum(odd), odd.double().sum(0)) <= 1e-5 * odd.double().abs().sum(0).max().item()
     big = torch.randn(5000, 3072, device=DEV, generator=g).to(dt)
     assert _err(nb.colsum(big), big.double().sum(0)) <= 1e-5 * big.double().abs().sum(0).max().item()
     assert torch.equal(nb.colsum(big), nb.colsum(big))
@@ -107,11 +112,11 @@ def test_gemm_epilogues(cdt):
         nb.gemm(a, W)                                                                                 # inner dimensions differ
 
 
-def _transformer(cross, seed=0):
+def _transformer(cross, seed=0, dim=128):
     torch.manual_seed(seed)
     f_dims = {"triv": 0, "se3": 32, "so3": 0, "so2": 32}
     ak = {"f_dims": f_dims, "so2": 8, "so3": 0, "max_freq_h": 1, "max_freq_w": 1}
-    tr = gta_amd.Transformer(128, 2, 2, 64, 256, 0.0, not cross, 96 if cross else None, False,
+    tr = gta_amd.Transformer(dim, 2, 2, 64, 2 * dim, 0.0, not cross, 96 if cross else None, False,
                              {"method": {"name": "gta", "args": ak}}).to(DEV)
     for n, p in tr.named_parameters():                      # biases and norms away from their trivial initial values
         if n.endswith("bias") or "norm" in n:
@@ -126,7 +131,7 @@ def _transformer(cross, seed=0):
         ex["target_transforms"] = synth.random_extrinsics(B, 1, gen).to(DEV)
         ex["target_coord"] = torch.rand(B, 40, 2, generator=gen).to(DEV)
         gta_amd.pre_compute_reps_decoder(ak, ex)
-    x = torch.randn(B, 40 if cross else V * hw * hw, 128, device=DEV)
+    x = torch.randn(B, 40 if cross else V * hw * hw, dim, device=DEV)
     z = torch.randn(B, V * hw * hw, 96, device=DEV) if cross else None
     return tr, ex, x, z
 
@@ -147,13 +152,22 @@ def _run(tr, ex, x, z, fused_on, autocast):
         layers.FUSED_BLOCKS = True
 
 
-@pytest.mark.parametrize("cross", [False, True])
+@pytest.mark.parametrize("cross,dim", [(False, 128), (True, 128), (True, 180), (False, 180)])
 @pytest.mark.parametrize("autocast", [False, True])
-def test_fused_transformer_matches_modulewise(cross, autocast):
-    """Same weights, same inputs: fused blocks vs LayerNorm / Linear / GELU modules + autograd, forward and all gradients."""
-    tr, ex, x, z = _transformer(cross)
+def test_fused_transformer_matches_modulewise(cross, dim, autocast):
+    """Same weights, same inputs: fused blocks vs LayerNorm / Linear / GELU modules + autograd, forward and all gradients.
+    dim = 180: the MSN decoder's width (rows of 4k elements: the 8-byte-access forms of the row kernels, hipBLASLt on
+    leading dimensions that are not 16-byte multiples, transposed-GEMM weight gradients)."""
+    tr, ex, x, z = _transformer(cross, dim=dim)
+    spy = []
+    orig_ln = nb.ln_fwd
+    nb.ln_fwd = lambda *a, **k: (spy.append(1), orig_ln(*a, **k))[1]
     y0, dx0, g0 = _run(tr, ex, x, z, False, False)                 # fp32 module-by-module: the yardstick
-    y1, dx1, g1 = _run(tr, ex, x, z, True, autocast)
+    try:
+        y1, dx1, g1 = _run(tr, ex, x, z, True, autocast)
+    finally:
+        nb.ln_fwd = orig_ln
+    assert len(spy) == 4                                           # the fused path ran (two LayerNorm kernels per layer)
     rel = 3e-2 if autocast else 3e-3       # fp32: same arithmetic; only summation orders and the bf16 roundings they flip in the attention kernel differ
     st = C.err_stats(y1.cpu(), y0.cpu())
     assert st["finite"] and st["rel_rms"] < rel, st
