@@ -49,14 +49,16 @@ def compute_dtype(x: torch.Tensor) -> Optional[torch.dtype]:
 
 
 def _cast_param(p: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
-    """p in the compute dtype; the copy is kept on the parameter until the parameter changes (an optimizer step)."""
+    """p in the compute dtype; the copy is kept on the parameter until the parameter changes -- an in-place update (an
+    optimizer step, load_state_dict) bumps its version counter, an assignment to ``.data`` moves its storage."""
     if p.dtype == dt:
         return p.detach()
+    key = (p._version, p.data_ptr())
     tag = getattr(p, "_gta_cast", None)
-    if tag is not None and tag[0] == p._version and tag[1].dtype == dt and tag[1].device == p.device:
+    if tag is not None and tag[0] == key and tag[1].dtype == dt and tag[1].device == p.device:
         return tag[1]
     c = p.detach().to(dt)
-    p._gta_cast = (p._version, c)
+    p._gta_cast = (key, c)
     return c
 
 
