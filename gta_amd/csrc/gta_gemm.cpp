@@ -7,14 +7,19 @@
 //
 // State: one hipBLASLt handle and one descriptor set + algorithm per distinct GtaGemmDesc, per host thread.
 //
-// Algorithm choice: hipBLASLt's first heuristic answer is often not its fastest kernel for the long-K weight-gradient
-// shapes of this block (M = N ~ 768..2304, K = 40960 tokens: 270 us where another candidate takes 160).  The first call
-// of a shape therefore times the top TUNE_CANDIDATES answers on the caller's own buffers (two runs each, stream events)
-// and keeps the fastest; GTA_GEMM_TUNE=0 in the environment keeps the first answer.  Tuning is skipped for in-place
-// accumulation (C == D with beta != 0), where repeated runs would change the result.
+// Algorithm choice: hipBLASLt's first heuristic answer is often not its fastest kernel for this block's shapes (the long-K
+// weight-gradient shapes: 270 us where another candidate takes 160).  The first call of a shape therefore times the top
+// TUNE_CANDIDATES answers on the caller's own buffers (two runs each after a warm-up, stream events) and keeps the fastest
+// (GTA_GEMM_TUNE=1, default); =0 keeps the first answer; =2 times every kernel of the library that accepts the problem
+// (~220 per shape) -- measured on the fused MSN layer in one process pair on one box: 2742 us (=1) vs 2733 us (=2)
+// forward+backward, i.e. the heuristic's top 16 already contain the winners.
+// Tuning is skipped for in-place accumulation (C == D with beta != 0), where repeated runs would change the result.
 #include <hip/hip_runtime.h>
 #include <hipblaslt/hipblaslt.h>
+#include <hipblaslt/hipblaslt-ext.hpp>
+#include <vector>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <map>
@@ -130,31 +135,52 @@ void build_plan(Plan& p, hipblasLtHandle_t h, const GtaGemmDesc& g) {
     p.ok = true;
 }
 
-bool tuning_enabled() {
-    static const bool on = [] {
+// GTA_GEMM_TUNE: 0 = hipBLASLt's first answer, 1 (default) = fastest of its top TUNE_CANDIDATES answers, 2 = fastest of
+// EVERY kernel the library has for the problem type that accepts this problem (hipblaslt_ext::getAllAlgos +
+// matmulIsAlgoSupported: ~220 candidates, ~0.1 s per shape at the MSN sizes)
+int tuning_mode() {
+    static const int mode = [] {
         const char* e = getenv("GTA_GEMM_TUNE");
-        return !(e && e[0] == '0');
+        return e ? atoi(e) : 1;
     }();
-    return on;
+    return mode;
 }
+bool tuning_enabled() { return tuning_mode() > 0; }
 
 // times every candidate on the caller's buffers and keeps the fastest (see the file comment)
-void tune_plan(Plan& p, hipblasLtHandle_t h, const float* alpha, const float* beta, const void* a_lt, const void* b_lt,
-               const void* c, void* d, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+void tune_plan(Plan& p, hipblasLtHandle_t h, const GtaGemmDesc& g, const float* alpha, const float* beta, const void* a_lt,
+               const void* b_lt, const void* c, void* d, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     p.tuned = true;
-    if (p.n_cand < 2) return;
+    std::vector<hipblasLtMatmulHeuristicResult_t> all;
+    if (tuning_mode() >= 2) {
+        std::vector<hipblasLtMatmulHeuristicResult_t> every;
+        const hipblasOperation_t ta = g.trans_b ? HIPBLAS_OP_T : HIPBLAS_OP_N, tb = g.trans_a ? HIPBLAS_OP_T : HIPBLAS_OP_N;
+        if (hipblaslt_ext::getAllAlgos(h, hipblaslt_ext::GemmType::HIPBLASLT_GEMM, ta, tb, hip_type(g.b_dtype), hip_type(g.a_dtype),
+                                       hip_type(g.d_dtype), hip_type(g.d_dtype), HIPBLAS_COMPUTE_32F, every) == HIPBLAS_STATUS_SUCCESS) {
+            for (auto& r : every) {
+                size_t ws = 0;
+                if (hipblaslt_ext::matmulIsAlgoSupported(h, p.op, alpha, p.la, p.lb, beta, p.lc, p.ld, r.algo, ws) == HIPBLAS_STATUS_SUCCESS &&
+                    ws <= workspace_bytes) {
+                    r.workspaceSize = ws;
+                    all.push_back(r);
+                }
+            }
+        }
+    }
+    for (int i = 0; i < p.n_cand; ++i) all.push_back(p.cand[i]);
+    if (all.size() < 2) return;
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess) return;
     if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return; }
     float best = 1e30f;
-    int best_i = 0;
-    for (int i = 0; i < p.n_cand; ++i) {
-        if (p.cand[i].workspaceSize > workspace_bytes) continue;
+    int best_i = -1;
+    for (int i = 0; i < (int)all.size(); ++i) {
+        if (all[i].workspaceSize > workspace_bytes) continue;
         bool ok = true;
         float ms = 1e30f;
         for (int r = 0; r < 3 && ok; ++r) {                     // the first run of a kernel pays its code load
             if (r == 1) ok = hipEventRecord(e0, stream) == hipSuccess;
-            ok = ok && hipblasLtMatmul(h, p.op, alpha, a_lt, p.la, b_lt, p.lb, beta, c, p.lc, d, p.ld, &p.cand[i].algo, workspace,
+            ok = ok && hipblasLtMatmul(h, p.op, alpha, a_lt, p.la, b_lt, p.lb, beta, c, p.lc, d, p.ld, &all[i].algo, workspace,
                                  workspace_bytes, stream) == HIPBLAS_STATUS_SUCCESS;
         }
         if (!ok || hipEventRecord(e1, stream) != hipSuccess) continue;
@@ -163,8 +189,13 @@ void tune_plan(Plan& p, hipblasLtHandle_t h, const float* alpha, const float* be
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    p.algo = p.cand[best_i].algo;
-    p.ws = p.cand[best_i].workspaceSize;
+    if (best_i >= 0) {
+        p.algo = all[best_i].algo;
+        p.ws = all[best_i].workspaceSize;
+    }
+    if (getenv("GTA_GEMM_TUNE_LOG"))
+        fprintf(stderr, "gta_gemm tune m=%ld n=%ld k=%ld ta=%d tb=%d epi=%d: %zu candidates, best %.1f us (first heuristic answer is #%zu)\n",
+                (long)g.m, (long)g.n, (long)g.k, g.trans_a, g.trans_b, g.epilogue, all.size(), best * 500.0f, all.size() - p.n_cand);
 }
 
 thread_local char g_msg[160];
@@ -220,7 +251,7 @@ int gta_gemm(const GtaGemmDesc* desc, const void* a, const void* b, const void* 
     const float alpha = g.alpha, beta = g.beta;
     if (!p.tuned) {
         if (tuning_enabled() && !(c == d && beta != 0.f))
-            tune_plan(p, ts.handle, &alpha, &beta, b, a, c ? c : d, d, workspace, (size_t)workspace_bytes, static_cast<hipStream_t>(stream));
+            tune_plan(p, ts.handle, g, &alpha, &beta, b, a, c ? c : d, d, workspace, (size_t)workspace_bytes, static_cast<hipStream_t>(stream));
         else
             p.tuned = true;
     }
