@@ -143,3 +143,19 @@ def test_lazy_softmax_full_path(pattern, kv_mode):
     #     (measured 0.11-0.34 max-abs at |out| <= 4.5 for both); only the RMS is a meaningful bound here
     st = C.err_stats(got, C.oracle_forward(q, k, v, ex, ak, cross, 0.01))
     assert st["finite"] and st["rel_rms"] <= 3e-2, st
+
+
+def test_few_rounds_launch_takes_the_persistent_grid_and_matches():
+    """Launches of more than one and at most two rounds of resident workgroups are given the persistent grid by
+    gta_attn_fwd itself (the 600-token CLEVR-TR encoder at B = 32: 960 items on 768 slots).  Here 816 items of the dh = 64
+    layout; the result must agree with the single-kernel plan (a different kernel, same bf16 products) and the oracle."""
+    B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3 = 8, 6, 2, 1088, 2, 96, {"se3": 32, "so2": 32}, 8, 0
+    q, k, v, ex, ak, cross = C.synth_inputs(B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, torch.float32, seed=5)
+    items = B * H * ((Nq * Pq + 127) // 128)
+    assert 768 < items <= 2 * 768
+    got = C.hip_forward(q, k, v, ex, ak, cross, 0.01, torch.bfloat16, kv_mode="prepass").float().cpu()
+    classic = C.hip_forward(q, k, v, ex, ak, cross, 0.01, torch.bfloat16, kv_mode="fused").float().cpu()
+    st = C.err_stats(got, classic)
+    assert st["finite"] and st["max_abs"] <= 2.0 ** -7 * st["ref_max"] and st["rel_rms"] <= 4e-3, st     # one bf16 ulp of the output
+    ref = C.oracle_forward(q[:2], k[:2], v[:2], {n: t[:2] for n, t in ex.items()}, ak, cross, 0.01)
+    _check(got[:2], ref)
