@@ -16,7 +16,8 @@ def short(name):
 
 
 def main(src, anchor="build_reps"):
-    files = sorted(glob.glob(f"{src}/**/*_kernel_trace.csv", recursive=True))
+    import os
+    files = sorted(glob.glob(f"{src}/**/*_kernel_trace.csv", recursive=True), key=os.path.getmtime)     # newest last
     rows = []
     for r in csv.DictReader(open(files[-1])):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))

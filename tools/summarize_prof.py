@@ -19,12 +19,12 @@ def short(name):
 
 
 def latest(files):
-    """gpurun merges every call's outputs into the same local directory: keep the newest run (highest numeric prefix)
-    of each directory only."""
+    """gpurun merges every call's outputs into the same local directory: keep the newest run (by modification time; the
+    numeric prefix is a process id and says nothing about order) of each directory only."""
+    import os
     by_dir = collections.defaultdict(list)
     for f in files:
-        m = re.match(r"(\d+)_", f.rsplit("/", 1)[-1])
-        by_dir[f.rsplit("/", 1)[0]].append((int(m.group(1)) if m else -1, f))
+        by_dir[f.rsplit("/", 1)[0]].append((os.path.getmtime(f), f))
     return [max(v)[1] for v in by_dir.values()]
 
 
