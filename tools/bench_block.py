@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--mlp", type=int, default=1536, help="MSN gta_so3: mlp_dim = attdim * 2 (encoder.py) = 1536")
     ap.add_argument("--layers", type=int, default=1)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--dropout", type=float, default=0.0, help="the reference configs train with 0.01 (forward+backward leg only)")
     ap.add_argument("--mode", default="both", choices=["both", "fused", "modules"])
     ap.add_argument("--no-launch-count", action="store_true")
     args = ap.parse_args()
@@ -29,7 +30,7 @@ def main():
     torch.manual_seed(0)
     f_dims = {"triv": 0, "se3": 48, "so3": 24, "so2": 24}
     ak = {"f_dims": f_dims, "so2": 6, "so3": 2, "max_freq_h": 1, "max_freq_w": 1}
-    tr = gta_amd.Transformer(768, args.layers, 8, 96, args.mlp, 0.0, True, None, False, {"method": {"name": "gta", "args": ak}}).to(dev)
+    tr = gta_amd.Transformer(768, args.layers, 8, 96, args.mlp, args.dropout, True, None, False, {"method": {"name": "gta", "args": ak}}).to(dev)
     B, V, hw = args.batch, 5, 16
     gen = torch.Generator().manual_seed(1)
     ex = {"input_transforms": synth.random_extrinsics(B, V, gen).to(dev), "input_coord": torch.rand(B, V, hw, hw, 2, generator=gen).to(dev)}
@@ -37,10 +38,12 @@ def main():
     x0 = torch.randn(B, V * hw * hw, 768, device=dev)
 
     def fwd():
+        tr.eval()
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
             return tr(x0, None, ex)
 
     def fwd_bwd():
+        tr.train()
         x = x0.requires_grad_(True)
         with torch.autocast("cuda", dtype=torch.bfloat16):
             y = tr(x, None, ex)
