@@ -200,7 +200,10 @@ GTA_DEV void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std:
 template <int N, class F>
 GTA_DEV void static_for(F&& f) { static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
 
-constexpr int NSTAGE = 3;
+#ifndef GTA_NSTAGE
+#define GTA_NSTAGE 3
+#endif
+constexpr int NSTAGE = GTA_NSTAGE;       // ring stages (K' + V' tile images each); the skewed loop needs 3, the plain loop 2 or 3
 // Skewed tile loop in the 128-row kernel (QK^T of tile j+1 beside the softmax of tile j), used at dh = 96.
 // Measured on MI355X by CYCLE counts (tools/bench_kernels.py timeline on an instrumented build; MSN encoder, B=32):
 // 362-366k shader cycles per launch against 396-406k un-skewed (tile loop 48.5k vs 52.7k cycles per workgroup), -9 %.

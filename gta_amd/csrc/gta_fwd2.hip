@@ -183,8 +183,11 @@ GTA_DEV KArgs kargs() {
     return a;
 }
 
+#ifndef GTA_OCC96
+#define GTA_OCC96 2
+#endif
 template <int DHP, int ESZ, int LAYOUT>
-__global__ __launch_bounds__(256, (DHP <= 64 ? 3 : 2)) void gta_fwd2_kernel(const GtaFwdParams p_kernarg) {
+__global__ __launch_bounds__(256, (DHP <= 64 ? 3 : GTA_OCC96)) void gta_fwd2_kernel(const GtaFwdParams p_kernarg) {
     using S = Smem2<DHP>;
     // chunk descriptor: a compile-time constant for the shipped layouts (c is constant per unrolled item)
 #define GTA_DESC(c) (LAYOUT == GTA_LAYOUT_GENERIC ? pp->ctab[c] : gta_layout_desc(LAYOUT, c))
@@ -310,9 +313,9 @@ __global__ __launch_bounds__(256, (DHP <= 64 ? 3 : 2)) void gta_fwd2_kernel(cons
         };
         if (full) q_loads(std::true_type{}); else q_loads(std::false_type{});
         if (pp->vrep_q) qrec_seg_load(rb0, pp->vrep_q, b, pp->Nq, n_first, n_cnt, wave, lane);
-        if (V == (int)blockIdx.x) {          // the stream's first two tiles (later ones: requested by the tile steps)
-            dma_next(lane);
-            dma_next(lane);
+        if (V == (int)blockIdx.x) {          // the stream's first NSTAGE - 1 tiles (later ones: requested by the tile steps)
+#pragma unroll
+            for (int i0 = 0; i0 < NSTAGE - 1; ++i0) dma_next(lane);
         }
     }
     float* qrec = reinterpret_cast<float*>(smem + S::OFF_QREC) + par * pp->nrec * GTA_QREC;
@@ -411,6 +414,7 @@ __global__ __launch_bounds__(256, (DHP <= 64 ? 3 : 2)) void gta_fwd2_kernel(cons
         for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
     const float* kn_base = pp->kn + (long)(b * pp->H + h) * n_tiles;
 
+    static_assert(!(PIPE1 && DHP == 96) || NSTAGE == 3, "the skewed loop keeps K'(j+1), V'(j) and one tile in flight: three stages");
     if constexpr (PIPE1 && DHP == 96) {      // (dh = 64: 230 VGPRs would cost the third workgroup per CU)
     // ---- skewed tile loop: the QK^T MFMAs of tile j+1 issue beside the softmax VALU of tile j ----
     // Two of these waves share a SIMD (two workgroups per CU).  Measured (tests/probes/probe_coissue.hip): two
@@ -557,7 +561,7 @@ __global__ __launch_bounds__(256, (DHP <= 64 ? 3 : 2)) void gta_fwd2_kernel(cons
     for (int j = 0; j < n_tiles; ++j) {
         // tile j has landed (only the stream's next tile may still be in flight), everyone is past tile j-1.
         // (younger requests -- the next item's Q loads, this item's predecessor's stores -- only make the wait longer)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * DMA_PER_WAVE) : "memory");
         if (dma_V >= n_items) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the stream has ended: nothing younger to count on)
         __builtin_amdgcn_s_barrier();
         dma_next(lane);
