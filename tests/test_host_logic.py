@@ -49,7 +49,8 @@ def test_fused_blocks_do_not_engage_off_gpu():
     """On CPU tensors the Transformer keeps the module-by-module path (and the attention operator then refuses)."""
     from gta_amd import fused
     assert fused.compute_dtype(torch.zeros(2, 3, 8)) is None
-    assert fused.norm_ok(torch.nn.LayerNorm(48)) and not fused.norm_ok(torch.nn.LayerNorm(20))
+    assert fused.norm_ok(torch.nn.LayerNorm(48)) and fused.norm_ok(torch.nn.LayerNorm(180)) and fused.norm_ok(torch.nn.LayerNorm(20))
+    assert not fused.norm_ok(torch.nn.LayerNorm(18)) and not fused.norm_ok(torch.nn.LayerNorm(2052))     # rows of 4k elements, <= 2048
     assert not fused.norm_ok(torch.nn.LayerNorm(48, elementwise_affine=False))
 
 
