@@ -19,17 +19,14 @@
 // between its two 16-token MFMA blocks, so every fragment read flies under an MFMA block.  Each wave owns 128 x 64 of the
 // tile: 8 accumulators of 32 x 32, 16 MFMAs against 24 transpose-reads and 4 DMA instructions per step.
 //
-// What bounds it (profiles/r02/README.md).  Switch experiment on dW[2304,768]: 231 us as is, 191 us with the DMA switched
-// off (compute on stale LDS), 114 us with the MFMAs and fragment reads switched off (the DMA alone: 11 TB/s into the LDS)
-// -- so neither HBM (FETCH_SIZE 1.7x the algorithmic bytes) nor the DMA path is the limit; it is the wave's own stream of
-// fragment reads and MFMAs.  The LDS array is not saturated (SQ_LDS_IDX_ACTIVE: 2 cycles per ds_read_b64_tr_b16, 384 per
-// 32-token step against 1 024 cycles of MFMA per SIMD, zero bank conflicts), but 8-byte-per-lane reads reach the array's
-// rate only from about four waves per SIMD (MI355X_MICROARCH.md, LDS table: one wave alone gets a fifth), and a TN
-// product needs two of them per operand fragment for BOTH operands: 1 to 1.5 reads per MFMA with one or two waves per
-// SIMD.  Four structurally different loops (128 x 128 or 128 x 64 per wave, two to four stages, 64-B or 128-B row segments
-// per DMA lane group) land within 2 % of each other at 600-760 TFLOP/s.  The way out is an operand the PRODUCER already
-// wrote token-major, so that fragments are one ds_read_b128 each (as the K/V pre-pass does for the attention kernel's
-// K'); none of this block's producers do that yet.
+// What bounds it (profiles/r02/README.md) is not settled.  Switch experiments on dW[2304,768]: 231 us as is; 191 us with
+// the DMA switched off (compute on stale LDS); 114 us with the MFMAs and fragment reads switched off (the DMA alone: 11 TB/s
+// into the LDS); 232 us with every pair of transpose-reads replaced by one ds_read_b128 (half the LDS instructions, wrong
+// data).  So it is neither HBM (FETCH_SIZE 1.7x the algorithmic bytes), nor the DMA path, nor the LDS (array busy 384 of
+// ~3 000 cycles per step, zero conflicts, and the read form does not matter): what remains is the waves' own
+// MFMA / wait / barrier stream -- 16 MFMAs per wave between barriers, SQ_WAIT_ANY 35 % of the wave cycles, matrix pipe
+// busy 46 % of SIMD time.  Four structurally different loops (128 x 128 or 128 x 64 per wave, two to four stages, 64-B or
+// 128-B row segments per DMA lane group) land within 2 % of each other at 600-760 TFLOP/s.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "gta_common.h"
