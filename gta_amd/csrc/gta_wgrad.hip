@@ -25,7 +25,10 @@
 // data).  So it is neither HBM (FETCH_SIZE 1.7x the algorithmic bytes), nor the DMA path, nor the LDS (array busy 384 of
 // ~3 000 cycles per step, zero conflicts, and the read form does not matter): what remains is the waves' own
 // MFMA / wait / barrier stream -- 16 MFMAs per wave between barriers, SQ_WAIT_ANY 35 % of the wave cycles, matrix pipe
-// busy 46 % of SIMD time.  Four structurally different loops (128 x 128 or 128 x 64 per wave, two to four stages, 64-B or
+// busy 46 % of SIMD time.  With DMA, fragment reads AND the barrier switched off the loop still takes 62 cycles per MFMA
+// and SIMD at 2.3 GHz (286k of the 410k cycles), while the same 8-accumulator MFMA sequence alone runs at the pipe's 32
+// (tests/probes/probe_mfma_tile.hip: 2.1 PFLOP/s with one or two waves per SIMD): the loss sits in what surrounds the
+// MFMA blocks of a step (~100 scalar / address instructions per wave), not yet pinned down.  Four structurally different loops (128 x 128 or 128 x 64 per wave, two to four stages, 64-B or
 // 128-B row segments per DMA lane group) land within 2 % of each other at 600-760 TFLOP/s.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -188,13 +191,17 @@ __global__ __launch_bounds__(64 * WG_WAVES) void wgrad_kernel(WgradParams p) {
 
     int st = 0;                                                             // ring stage of step t
     for (int t = 0; t < n_steps; ++t) {
-        // A: token group 0 of step t; group 1's fragments fly under its MFMAs
+        // A: token group 0 of step t; group 1's fragments fly under its MFMAs.  (Scheduling barriers on BOTH sides of the
+        // wait: without the one in front hipcc sinks the previous block's MFMAs below the wait, behind the fragment reads
+        // that were issued to fly under them.)
+        __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         load_frags((uint32_t)(st * WG_STAGE), std::integral_constant<int, 1>{}, 1);
         mfma_block(0);
         // B: token group 1; before its MFMAs the ring turns: step t's stage is read out by everyone (barrier) and takes
         // step t + NSTAGE, and the first fragments of step t + 1 fly under these MFMAs
+        __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         const int st1 = st + 1 == WG_NSTAGE ? 0 : st + 1;
