@@ -75,7 +75,8 @@ GTA_DEV float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 template <bool BIAS>
 __global__ __launch_bounds__(64 * WG_WAVES) void wgrad_kernel(WgradParams p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);             // wave-uniform: everything derived from it stays scalar
     const int wn = wave >> 2, wk = wave & 3;
     // XCD-aware work map: workgroup L runs on XCD L % 8.  Workgroups of one token split share their operand tiles (the G
     // tile of a row of dW tiles, the X tile of a column), so each XCD takes a CONTIGUOUS run of the (split, tile) list and
@@ -100,18 +101,19 @@ __global__ __launch_bounds__(64 * WG_WAVES) void wgrad_kernel(WgradParams p) {
     const int c0 = is_x ? k0 : n0;
     const int piece0 = (wave & 3) * WG_DMA_PER_WAVE;                       // this wave's 4 sub-tiles of its operand
     const int drow = lane >> 3, dchunk = (lane & 7) ^ (((drow >> 1) & 1) << 2);
-    const long lane_src = ((long)drow * ld + dchunk * 8) * 2;
+    const unsigned lane_src = (unsigned)(((long)drow * ld + dchunk * 8) * 2);   // (< 2^32: checked by the launcher)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)smem;
 
+    // scalar-base form of the LDS-DMA (gta_common.h dma_group): global address = SGPR pair + the lane's 32-bit offset,
+    // LDS address = M0 + 16 * lane -- no vector arithmetic per piece
     auto stage_dma = [&](int step, int stage) {
         const long m0 = (long)(step0 + step) * WG_BT;
+        const char* sbase = src + (m0 * ld + c0) * 2;
+        const uint32_t lbase = lds0 + stage * WG_STAGE + (is_x ? WG_OPER : 0);
 #pragma unroll
         for (int q = 0; q < WG_DMA_PER_WAVE; ++q) {
             const int pc = piece0 + q, t8 = pc >> 2, cg = pc & 3;           // [token group of 8][column group of 64]
-            const char* gp = src + ((m0 + t8 * 8) * ld + c0 + cg * 64) * 2 + lane_src;
-            char* lp = smem + stage * WG_STAGE + (is_x ? WG_OPER : 0) + pc * 1024;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                             (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
+            dma_group<1>(lbase + pc * 1024, sbase + ((long)t8 * 8 * ld + cg * 64) * 2, lane_src);
         }
     };
     // wait until at most `groups` of my DMA groups (WG_DMA_PER_WAVE instructions each) are still in flight
@@ -190,7 +192,10 @@ __global__ __launch_bounds__(64 * WG_WAVES) void wgrad_kernel(WgradParams p) {
     load_frags(0u, std::integral_constant<int, 0>{}, 0);
 
     int st = 0;                                                             // ring stage of step t
-    for (int t = 0; t < n_steps; ++t) {
+    // One step.  STEADY (t + NSTAGE < n_steps): the ring is full behind this step, so the wait count, the barrier and the
+    // request of step t + NSTAGE need no conditions -- the steady-state loop carries no branches besides its own.
+    auto step = [&](int t, auto STEADYC) {
+        constexpr bool STEADY = decltype(STEADYC)::value;
         // A: token group 0 of step t; group 1's fragments fly under its MFMAs.  (Scheduling barriers on BOTH sides of the
         // wait: without the one in front hipcc sinks the previous block's MFMAs below the wait, behind the fragment reads
         // that were issued to fly under them.)
@@ -205,16 +210,24 @@ __global__ __launch_bounds__(64 * WG_WAVES) void wgrad_kernel(WgradParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         const int st1 = st + 1 == WG_NSTAGE ? 0 : st + 1;
-        if (t + 1 < n_steps) {
-            const int last_issued = t + WG_NSTAGE - 1 < n_steps - 1 ? t + WG_NSTAGE - 1 : n_steps - 1;
-            dma_wait(last_issued - (t + 1));                                // step t + 1 has landed (my share of it)
+        if constexpr (STEADY) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WG_NSTAGE - 2) * WG_DMA_PER_WAVE) : "memory");   // step t + 1 has landed (my share)
             __builtin_amdgcn_s_barrier();                                    // ... and everyone's; stage st is free
+            stage_dma(t + WG_NSTAGE, st);
+            load_frags((uint32_t)(st1 * WG_STAGE), std::integral_constant<int, 0>{}, 0);
+        } else if (t + 1 < n_steps) {
+            const int last_issued = t + WG_NSTAGE - 1 < n_steps - 1 ? t + WG_NSTAGE - 1 : n_steps - 1;
+            dma_wait(last_issued - (t + 1));
+            __builtin_amdgcn_s_barrier();
             if (t + WG_NSTAGE < n_steps) stage_dma(t + WG_NSTAGE, st);
             load_frags((uint32_t)(st1 * WG_STAGE), std::integral_constant<int, 0>{}, 0);
         }
         mfma_block(1);
         st = st1;
-    }
+    };
+    int t = 0;
+    for (; t + WG_NSTAGE < n_steps; ++t) step(t, std::true_type{});
+    for (; t < n_steps; ++t) step(t, std::false_type{});
 
     // ---- epilogue: accumulators -> this split's partial tile (rows n, 128-B segments along k) ----
     float* out = p.part + (long)split * p.N * p.ldo;
@@ -289,6 +302,7 @@ int gta_wgrad(const void* g, int64_t ldg, const void* x, int64_t ldx, int64_t m,
     if (ldg % 8 != 0 || ldx % 8 != 0 || (reinterpret_cast<uintptr_t>(g) & 15) || (reinterpret_cast<uintptr_t>(x) & 15) ||
         (reinterpret_cast<uintptr_t>(dw) & 15))
         return GTA_E_BADARG;
+    if (ldg > (1ll << 27) || ldx > (1ll << 27)) return GTA_E_UNSUPPORTED;     // the DMA's per-lane offsets are 32-bit
     if (workspace_bytes < gta_wgrad_workspace_bytes(m, n, k)) return GTA_E_BADARG;
     const Split sp = choose_split(m, n, k);
     WgradParams p;
