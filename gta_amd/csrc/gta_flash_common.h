@@ -174,23 +174,22 @@ GTA_DEV void stage_qrec(float* qrec, const float* vrep_q, int b, int Nq, int n0,
         qrec_batch_store(q, qrec, tc, i0, nthreads);
     }
 }
+// element i of the k-side records of scene b (record layout: gta_common.h) = vrep_k[krec_source(..., &m)] * m.
+// Branch-free, and the load is the caller's, so a thread's several elements can be requested back to back.
+GTA_DEV long krec_source(int b, int Nk, int i, float tc, float* m) {
+    const int n = i / GTA_KREC, e = i - n * GTA_KREC;
+    const bool se3 = e < GTA_KREC_D1, d1 = e < GTA_KREC_D2;
+    const int ee = se3 ? e : d1 ? e - GTA_KREC_D1 : e - GTA_KREC_D2;
+    const int r = (se3 || d1) ? ee >> 2 : ee >> 3, c = (se3 || d1) ? ee & 3 : ee & 7;
+    const int idx = se3 ? GTA_VREP_REP + e : d1 ? GTA_VREP_D1 + r * 3 + (c < 3 ? c : 2) : GTA_VREP_D2 + r * 5 + (c < 5 ? c : 4);
+    *m = se3 ? ((r == 3) ? (c == 3 ? 1.f : 0.f) : (c == 3 ? tc : 1.f)) : d1 ? (c < 3 ? 1.f : 0.f) : (c < 5 ? 1.f : 0.f);
+    return ((long)b * Nk + n) * GTA_VREP_STRIDE + idx;
+}
 GTA_DEV void stage_krec(float* krec, const float* vrep_k, int b, int Nk, float tc, int tid, int nthreads) {
     for (int i = tid; i < Nk * GTA_KREC; i += nthreads) {
-        const int n = i / GTA_KREC, e = i - n * GTA_KREC;
-        const float* src = vrep_k + ((long)b * Nk + n) * GTA_VREP_STRIDE;
-        float val = 0.f;
-        if (e < 16) {
-            const int r = e >> 2, c = e & 3;
-            const float m = (r == 3) ? (c == 3 ? 1.f : 0.f) : (c == 3 ? tc : 1.f);
-            val = src[GTA_VREP_REP + e] * m;
-        } else if (e < GTA_KREC_D2) {
-            const int ee = e - GTA_KREC_D1, r = ee >> 2, c = ee & 3;
-            val = c < 3 ? src[GTA_VREP_D1 + r * 3 + c] : 0.f;
-        } else {
-            const int ee = e - GTA_KREC_D2, r = ee >> 3, c = ee & 7;
-            val = c < 5 ? src[GTA_VREP_D2 + r * 5 + c] : 0.f;
-        }
-        krec[i] = val;
+        float m;
+        const long src = krec_source(b, Nk, i, tc, &m);
+        krec[i] = vrep_k[src] * m;
     }
 }
 

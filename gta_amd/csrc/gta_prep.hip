@@ -22,11 +22,20 @@ struct PrepSmem {
     static constexpr int IMG = BN * DHP * 2;
     static constexpr int OFF_IMGK = (ESZ == 2) ? OFF_RAWK : OFF_RAWV + RAW_BYTES;
     static constexpr int OFF_IMGV = (ESZ == 2) ? OFF_RAWV : OFF_IMGK + IMG;
-    // the k-side view records (and later the 4 x 64 row-norm partials) sit behind the data, sized by the actual
-    // number of views: 5 workgroups per CU with 16 views' worth reserved, 6 with the 5 views of the MSN config
-    static constexpr int OFF_KREC = (ESZ == 2) ? OFF_RAWV + RAW_BYTES : OFF_IMGV + IMG;
-    static int total(int Nk) { const int rec = Nk * GTA_KREC * 4; return OFF_KREC + (rec > 1024 ? rec : 1024); }
+    // the 4 x 64 row-norm partials and the k-side view records sit behind the data, sized by the actual number of views:
+    // 5 workgroups per CU with 16 views' worth reserved, 6 with the 5 views of the MSN config
+    static constexpr int OFF_ROWSQ = (ESZ == 2) ? OFF_RAWV + RAW_BYTES : OFF_IMGV + IMG;
+    static constexpr int OFF_KREC = OFF_ROWSQ + 1024;
+    static int total(int Nk) { return OFF_KREC + Nk * GTA_KREC * 4; }
 };
+
+// One 1-KiB LDS-DMA piece with per-lane source addresses (the row gather), as asm (hipcc puts a vmcnt(0) in front of every
+// LDS access that follows the builtin form: it cannot tell the LDS ranges apart).  Consumers sit behind an explicit
+// s_waitcnt vmcnt + s_barrier.
+GTA_DEV void dma_piece(const char* lds_dst, const char* src) {
+    const uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)lds_dst;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(lds)), "v"(src) : "memory");
+}
 
 template <int DHP, int ESZ>
 __global__ __launch_bounds__(256) void gta_kv_prep_kernel(const GtaFwdParams p) {
@@ -56,100 +65,177 @@ __global__ __launch_bounds__(256) void gta_kv_prep_kernel(const GtaFwdParams p) 
     const long k_rs = p.k_st * ESZ, v_rs = p.v_st * ESZ;
     const int ch_real = p.dh >> 3, real_units = p.dh * ESZ / 16;
 
-    // raw rows -> LDS (coalesced LDS-DMA; the per-lane source address carries the swizzle)
-    constexpr int NI = BN * U / 256;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int u0 = (wave * NI + i) * 64, u = u0 + lane;
-        const int r = u / U, pos = u - r * U;
-        constexpr int tz = (U % 16 == 0) ? 4 : (U % 8 == 0) ? 3 : (U % 4 == 0) ? 2 : (U % 2 == 0) ? 1 : 0;
-        const int rot = (r >> (4 - tz)) & ((1 << tz) - 1);
-        int gu = pos - rot;
-        gu = gu < 0 ? gu + U : gu;
-        gu = gu < real_units ? gu : real_units - 1;
-        int gr = j * BN + r;
-        gr = gr < p.Tk ? gr : p.Tk - 1;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kg + (long)gr * k_rs + gu * 16),
-                                         (__attribute__((address_space(3))) void*)(smem + S::OFF_RAWK + u0 * 16), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vg + (long)gr * v_rs + gu * 16),
-                                         (__attribute__((address_space(3))) void*)(smem + S::OFF_RAWV + u0 * 16), 16, 0, 0);
-    }
+    // The k-side view records: requested first (plain loads into registers), written to LDS once the tile's DMAs are on
+    // their way, so the latencies overlap.
     float* krec = reinterpret_cast<float*>(smem + S::OFF_KREC);
-    if (p.vrep_k) stage_krec(krec, p.vrep_k, b, p.Nk, p.trans_coeff ? *p.trans_coeff : 1.0f, tid, 256);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    const bool xv = (p.flags & GTA_FLAG_V_TRANSFORM) != 0;
+    constexpr int KQ = (GTA_MAX_VIEWS * GTA_KREC + 255) / 256;
+    float kval[KQ], kmul[KQ];
+    const int krec_n = p.vrep_k ? p.Nk * GTA_KREC : 0;
+    {
+        const float tc = p.trans_coeff ? *p.trans_coeff : 1.0f;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const int i = tid + 256 * q;
+            kval[q] = 0.f; kmul[q] = 0.f;
+            if (256 * q < krec_n) kval[q] = p.vrep_k[krec_source(b, p.Nk, i < krec_n ? i : 0, tc, &kmul[q])];
+        }
+    }
+    // ... and this row's (cos, sin) pairs of the so2 chunks this wave will handle (lane == key row)
     const int r = lane;
     const int t_raw = j * BN + r;
     const bool valid = t_raw < p.Tk;
     const int t = valid ? t_raw : p.Tk - 1;
+    f32x4_t cs_pre[CHP / 4][2] = {};
+    if (p.cs_k) {
+        const float* cs_base = p.cs_k + ((long)b * p.Tk + t) * 2 * p.nso2;
+#pragma unroll
+        for (int it = 0; it < CHP / 4; ++it) {
+            const int c = wave + 4 * it;
+            const uint32_t desc = c < ch_real ? p.ctab[c] : 0u;
+            if (!(desc & GTA_CHUNK_SO3) && cd_lo(desc) == GTA_HALF_SO2 && cd_hi(desc) == GTA_HALF_SO2) {
+                cs_pre[it][0] = *reinterpret_cast<const f32x4_t*>(cs_base + 2 * cd_so2_lo(desc));
+                cs_pre[it][1] = *reinterpret_cast<const f32x4_t*>(cs_base + 2 * cd_so2_hi(desc));
+            }
+        }
+    }
+    // raw rows -> LDS (coalesced LDS-DMA; the per-lane source address carries the swizzle): all of K, then all of V
+    constexpr int NI = BN * U / 256;
+#pragma unroll
+    for (int w2 = 0; w2 < 2; ++w2) {
+        const char* g = w2 ? vg : kg;
+        const long rs = w2 ? v_rs : k_rs;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int u0 = (wave * NI + i) * 64, u = u0 + lane;
+            const int r = u / U, pos = u - r * U;
+            constexpr int tz = (U % 16 == 0) ? 4 : (U % 8 == 0) ? 3 : (U % 4 == 0) ? 2 : (U % 2 == 0) ? 1 : 0;
+            const int rot = (r >> (4 - tz)) & ((1 << tz) - 1);
+            int gu = pos - rot;
+            gu = gu < 0 ? gu + U : gu;
+            gu = gu < real_units ? gu : real_units - 1;
+            int gr = j * BN + r;
+            gr = gr < p.Tk ? gr : p.Tk - 1;
+            dma_piece(smem + (w2 ? S::OFF_RAWV : S::OFF_RAWK) + u0 * 16, g + (long)gr * rs + gu * 16);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+        const int i = tid + 256 * q;
+        if (i < krec_n) krec[i] = kval[q] * kmul[q];
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // this wave's pieces have landed, its records are written
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // a use of the preloaded pairs here: hipcc's own wait for them lands at this point (nothing is outstanding) instead of
+    // in the V pass, where it would wait for the K' stores
+#pragma unroll
+    for (int it = 0; it < CHP / 4; ++it) asm volatile("" ::"v"(cs_pre[it][0]), "v"(cs_pre[it][1]));
+
+    const bool xv = (p.flags & GTA_FLAG_V_TRANSFORM) != 0;
     const int n = view_of(t, p.Pk, p.invPk);
     const float* rec = krec + n * GTA_KREC;
-    char* kimg_l = smem + S::OFF_IMGK;
-    char* vimg_l = smem + S::OFF_IMGV;
+    const float* cs_base = p.cs_k ? p.cs_k + ((long)b * p.Tk + t) * 2 * p.nso2 : nullptr;
     float ksq = 0.f;                                     // this thread's share of |k'_r|^2 (bf16-rounded values)
+
+    // One pass over a tile's rows (K, then V): an 8-channel chunk per wave and iteration, lane == key row.  The chunk's
+    // kind is wave-uniform; every kind runs its own load -> rho -> pack -> store body, so no register arrays are merged
+    // behind the branches (the phi copies of a shared body were a third of this kernel's VALU instructions, and its
+    // compute phase is VALU-issue bound: profiles/r02/README.md).
+    auto pass = [&](auto ISK, auto XF) {
+        constexpr bool is_k = decltype(ISK)::value, xf = decltype(XF)::value;
+        const char* raw = smem + (is_k ? S::OFF_RAWK : S::OFF_RAWV);
+        char* img = smem + (is_k ? S::OFF_IMGK : S::OFF_IMGV);
 #pragma unroll
-    for (int it = 0; it < CHP / 4; ++it) {
-        const int c = wave + 4 * it;
-        float x[2][8];
-        if (c < ch_real && valid) {
-            const uint32_t desc = p.ctab[c];
-            if (ESZ == 2) {
-                unpack8(*reinterpret_cast<const u32x4_t*>(smem + S::OFF_RAWK + (r * U + swz<U>(r, c)) * 16), x[0]);
-                unpack8(*reinterpret_cast<const u32x4_t*>(smem + S::OFF_RAWV + (r * U + swz<U>(r, c)) * 16), x[1]);
-            } else {
-#pragma unroll
-                for (int w2 = 0; w2 < 2; ++w2) {
-                    const char* raw = smem + (w2 ? S::OFF_RAWV : S::OFF_RAWK);
+        for (int it = 0; it < CHP / 4; ++it) {
+            const int c = wave + 4 * it;
+            const int off = (r * CHP + swz<CHP>(r, c)) * 16;
+            auto run = [&](auto&& apply) {
+                float x[1][8];
+                if (ESZ == 2) {
+                    unpack8(*reinterpret_cast<const u32x4_t*>(raw + (r * U + swz<U>(r, c)) * 16), x[0]);
+                } else {
                     const f32x4_t a = *reinterpret_cast<const f32x4_t*>(raw + (r * U + swz<U>(r, 2 * c)) * 16);
                     const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(raw + (r * U + swz<U>(r, 2 * c + 1)) * 16);
-                    x[w2][0] = a.x; x[w2][1] = a.y; x[w2][2] = a.z; x[w2][3] = a.w;
-                    x[w2][4] = bb.x; x[w2][5] = bb.y; x[w2][6] = bb.z; x[w2][7] = bb.w;
+                    x[0][0] = a.x; x[0][1] = a.y; x[0][2] = a.z; x[0][3] = a.w;
+                    x[0][4] = bb.x; x[0][5] = bb.y; x[0][6] = bb.z; x[0][7] = bb.w;
                 }
-            }
-            if (desc) {
-                f32x2_t cs[4];
-                if (p.cs_k) load_cs(desc, p.cs_k + ((long)b * p.Tk + t) * 2 * p.nso2, cs);
-                if (xv) chunk_apply<false, 2>(desc, rec + GTA_KREC_B, rec + GTA_KREC_D1, rec + GTA_KREC_D2, cs, x);
-                else    chunk_apply<false, 1>(desc, rec + GTA_KREC_B, rec + GTA_KREC_D1, rec + GTA_KREC_D2, cs, x);
-            }
-        } else {
+                apply(x);
+                const u32x4_t w = pack8(x[0]);
+                *reinterpret_cast<u32x4_t*>(img + off) = w;
+                if (is_k) {
+                    float kr[8];
+                    unpack8(w, kr);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { x[0][i] = 0.f; x[1][i] = 0.f; }
+                    for (int i = 0; i < 8; ++i) ksq += kr[i] * kr[i];
+                }
+            };
+            if (c < ch_real && valid) {
+                const uint32_t desc = xf ? p.ctab[c] : 0u;
+                const uint32_t lo = cd_lo(desc), hi = cd_hi(desc);
+                if (desc == 0) {
+                    run([](float (*)[8]) {});
+                } else if (desc & GTA_CHUNK_SO3) {
+                    run([&](float (*x)[8]) {
+                        float M1[12], M2[40];
+                        lds_loadN4<3>(rec + GTA_KREC_D1, M1);
+                        lds_loadN4<10>(rec + GTA_KREC_D2, M2);
+                        mat3_apply_p4(M1, x[0]); mat5_apply_p8(M2, x[0] + 3);
+                    });
+                } else if (lo == GTA_HALF_SE3 && hi == GTA_HALF_SE3) {
+                    run([&](float (*x)[8]) {
+                        float M[16];
+                        lds_load16(rec + GTA_KREC_B, M);
+                        mat4_apply(M, x[0]); mat4_apply(M, x[0] + 4);
+                    });
+                } else if (lo == GTA_HALF_SO2 && hi == GTA_HALF_SO2 && cs_base) {
+                    run([&](float (*x)[8]) {
+                        const f32x4_t t0 = cs_pre[it][0], t1 = cs_pre[it][1];
+                        rot2_apply<false>(t0.x, t0.y, x[0]); rot2_apply<false>(t0.z, t0.w, x[0] + 2);
+                        rot2_apply<false>(t1.x, t1.y, x[0] + 4); rot2_apply<false>(t1.z, t1.w, x[0] + 6);
+                    });
+                } else {                                 // mixed halves (no shipped config): the generic body
+                    run([&](float (*x)[8]) {
+                        f32x2_t cs[4];
+                        if (cs_base) load_cs(desc, cs_base, cs);
+                        chunk_apply<false, 1>(desc, rec + GTA_KREC_B, rec + GTA_KREC_D1, rec + GTA_KREC_D2, cs, x);
+                    });
+                }
+            } else {
+                *reinterpret_cast<u32x4_t*>(img + off) = u32x4_t{0u, 0u, 0u, 0u};
+            }
         }
-        const int off = (r * CHP + swz<CHP>(r, c)) * 16;
-        const u32x4_t kw = pack8(x[0]);
-        *reinterpret_cast<u32x4_t*>(kimg_l + off) = kw;
-        *reinterpret_cast<u32x4_t*>(vimg_l + off) = pack8(x[1]);
-        float kr[8];
-        unpack8(kw, kr);
+    };
+    // LDS image -> workspace, 1 KiB contiguous per wave-instruction
+    char* gimg = (char*)p.kp + (((long)b * p.H + h) * n_tiles + j) * (2L * IMG);
+    constexpr int PIECES = IMG / 1024;            // per image
+    auto store_image = [&](const char* img_l, char* g) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ksq += kr[i] * kr[i];
-    }
-    // per-tile bound for the flash kernel's deferred max: max over the tile's keys of |k'| (exactly the rows
-    // the MFMA will see).  krec is dead by now (every thread is past its last chunk_apply after the barrier).
-    __syncthreads();
-    float* rowsq = reinterpret_cast<float*>(smem + S::OFF_KREC);
+        for (int i = 0; i < (PIECES + 3) / 4; ++i) {
+            const int piece = wave + 4 * i;
+            if (piece < PIECES)
+                *reinterpret_cast<u32x4_t*>(g + piece * 1024 + lane * 16) = *reinterpret_cast<const u32x4_t*>(img_l + piece * 1024 + lane * 16);
+        }
+    };
+
+    pass(std::true_type{}, std::true_type{});                     // K rows -> K' image (in place for bf16 input)
+    float* rowsq = reinterpret_cast<float*>(smem + S::OFF_ROWSQ);
     if (p.kn) rowsq[wave * 64 + lane] = ksq;
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // this wave's K' units and partials are written
+    __builtin_amdgcn_s_barrier();                                  // K' image complete
+    asm volatile("" ::: "memory");
+    store_image(smem + S::OFF_IMGK, gimg);                         // K' goes out while V is transformed
+    // per-tile bound for the flash kernel's deferred max: max over the tile's keys of |k'| (exactly the rows the MFMA will see)
     if (p.kn && wave == 0) {
         float tot = rowsq[lane] + rowsq[64 + lane] + rowsq[128 + lane] + rowsq[192 + lane];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) tot = fmaxf(tot, __shfl_xor(tot, o));
         if (lane == 0) p.kn[((long)b * p.H + h) * n_tiles + j] = sqrtf(tot) * 1.0001f;
     }
-    // LDS image -> workspace, 1 KiB contiguous per wave-instruction
-    char* gimg = (char*)p.kp + (((long)b * p.H + h) * n_tiles + j) * (2L * IMG);
-    constexpr int PIECES = IMG / 1024;            // per image
-#pragma unroll
-    for (int i = 0; i < (2 * PIECES + 3) / 4; ++i) {
-        const int piece = wave + 4 * i;            // 0 .. 2*PIECES-1 : K' pieces then V' pieces
-        if (piece < 2 * PIECES) {
-            const char* src = (piece < PIECES ? kimg_l + piece * 1024 : vimg_l + (piece - PIECES) * 1024) + lane * 16;
-            *reinterpret_cast<u32x4_t*>(gimg + piece * 1024 + lane * 16) = *reinterpret_cast<const u32x4_t*>(src);
-        }
-    }
+    if (xv) pass(std::false_type{}, std::true_type{}); else pass(std::false_type{}, std::false_type{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // (the K' stores may still be in flight)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    store_image(smem + S::OFF_IMGV, gimg + IMG);
 }
 
 template <int DHP, int ESZ>
