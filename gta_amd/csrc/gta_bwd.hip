@@ -166,15 +166,14 @@ struct BPrepSmem {
     static constexpr int U = DHP * ESZ / 16;
     static constexpr int RAW = BN * DHP * ESZ;
     static constexpr int IMG = BN * DHP * 2;
-    static constexpr int OFF_REC = 0;
-    static constexpr int REC_BYTES = GTA_MAX_VIEWS * BREC * 4;
-    static constexpr int OFF_RQ = REC_BYTES;
+    static constexpr int OFF_RQ = 0;
     static constexpr int OFF_RDO = OFF_RQ + RAW;
     static constexpr int OFF_RO = OFF_RDO + RAW;
     static constexpr int OFF_IQ = (ESZ == 2) ? OFF_RQ : OFF_RO + RAW;      // images in place for bf16 input
     static constexpr int OFF_IDO = (ESZ == 2) ? OFF_RDO : OFF_IQ + IMG;
     static constexpr int OFF_D = (ESZ == 2) ? OFF_RO + RAW : OFF_IDO + IMG;  // D[64] + 4 scratch floats
-    static constexpr int TOTAL = OFF_D + 64 * 4 + 16;
+    static constexpr int OFF_REC = OFF_D + 64 * 4 + 16;                      // records last, sized by the actual number of views
+    static int total(int nviews) { return OFF_REC + nviews * BREC * 4; }
 };
 
 template <int DHP, int ESZ>
@@ -214,7 +213,6 @@ __global__ __launch_bounds__(256) void gta_bwd_prep_kernel(const GtaBwdParams p)
     __syncthreads();
 
     const float qscale = p.scale * LOG2E / (p.tau ? *p.tau : 1.0f);
-    const bool xo = (p.flags & GTA_FLAG_V_TRANSFORM) != 0;
     const int r = lane;
     const int t_raw = j * BN + r;
     const bool valid = t_raw < p.Tq;
@@ -222,39 +220,84 @@ __global__ __launch_bounds__(256) void gta_bwd_prep_kernel(const GtaBwdParams p)
     const int n = view_of(t, p.Pq, p.invPq);
     const float* rc = rec + n * BREC;
     float dpart = 0.f, dcpart = 0.f;
+    const float* cs_base = p.cs_q ? p.cs_q + ((long)b * p.Tq + t) * 2 * p.nso2 : nullptr;
+    // One chunk of q, dout and out per wave and iteration, lane == query row.  As in gta_kv_prep_kernel: the chunk's kind
+    // is wave-uniform and every kind has its own load -> rho -> pack -> store body (no register arrays merged behind branches).
+    auto chunks = [&](auto XO) {
+        constexpr bool xo = decltype(XO)::value;
 #pragma unroll
-    for (int it = 0; it < CHP / 4; ++it) {
-        const int c = wave + 4 * it;
-        float x[2][8];
-        if (c < ch_real && valid) {
-            const uint32_t desc = p.ctab[c];
-            float o8[8];
-            raw_chunk<U, ESZ>(smem + S::OFF_RQ, r, c, x[0]);
-            raw_chunk<U, ESZ>(smem + S::OFF_RDO, r, c, x[1]);
-            raw_chunk<U, ESZ>(smem + S::OFF_RO, r, c, o8);
+        for (int it = 0; it < CHP / 4; ++it) {
+            const int c = wave + 4 * it;
+            const int off = (r * CHP + swz<CHP>(r, c)) * 16;
+            auto run = [&](auto SE3LO, auto SE3HI, auto&& apply) {
+                float x[2][8], o8[8];
+                raw_chunk<U, ESZ>(smem + S::OFF_RQ, r, c, x[0]);
+                raw_chunk<U, ESZ>(smem + S::OFF_RDO, r, c, x[1]);
+                raw_chunk<U, ESZ>(smem + S::OFF_RO, r, c, o8);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) dpart += x[1][i] * o8[i];
-            if (desc && xo && !(desc & GTA_CHUNK_SO3)) {     // d trans_coeff through C_q = E.m (output rep)
-                const float t0 = rc[BREC_T], t1 = rc[BREC_T + 1], t2 = rc[BREC_T + 2];
-                if (cd_lo(desc) == GTA_HALF_SE3) dcpart += (x[1][0] * t0 + x[1][1] * t1 + x[1][2] * t2) * o8[3];
-                if (cd_hi(desc) == GTA_HALF_SE3) dcpart += (x[1][4] * t0 + x[1][5] * t1 + x[1][6] * t2) * o8[7];
+                for (int i = 0; i < 8; ++i) dpart += x[1][i] * o8[i];
+                if constexpr (xo && (decltype(SE3LO)::value || decltype(SE3HI)::value)) {   // d trans_coeff through C_q = E.m (output rep)
+                    const float t0 = rc[BREC_T], t1 = rc[BREC_T + 1], t2 = rc[BREC_T + 2];
+                    if constexpr (decltype(SE3LO)::value) dcpart += (x[1][0] * t0 + x[1][1] * t1 + x[1][2] * t2) * o8[3];
+                    if constexpr (decltype(SE3HI)::value) dcpart += (x[1][4] * t0 + x[1][5] * t1 + x[1][6] * t2) * o8[7];
+                }
+                apply(x);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[0][i] *= qscale;
+                *reinterpret_cast<u32x4_t*>(smem + S::OFF_IQ + off) = pack8(x[0]);
+                *reinterpret_cast<u32x4_t*>(smem + S::OFF_IDO + off) = pack8(x[1]);
+            };
+            constexpr std::true_type T{};
+            constexpr std::false_type F{};
+            if (c < ch_real && valid) {
+                const uint32_t desc = p.ctab[c];
+                const uint32_t lo = cd_lo(desc), hi = cd_hi(desc);
+                if (desc == 0) {
+                    run(F, F, [](float (*)[8]) {});
+                } else if (desc & GTA_CHUNK_SO3) {
+                    run(F, F, [&](float (*x)[8]) {
+                        float M1[12], M2[40];
+                        lds_loadN4<3>(rc + BREC_D1, M1);
+                        lds_loadN4<10>(rc + BREC_D2, M2);
+                        mat3_apply_p4(M1, x[0]); mat5_apply_p8(M2, x[0] + 3);
+                        if constexpr (xo) { mat3_apply_p4(M1, x[1]); mat5_apply_p8(M2, x[1] + 3); }
+                    });
+                } else if (lo == GTA_HALF_SE3 && hi == GTA_HALF_SE3) {
+                    run(T, T, [&](float (*x)[8]) {
+                        float M[16];
+                        lds_load16(rc + BREC_M, M);
+                        mat4_apply(M, x[0]); mat4_apply(M, x[0] + 4);
+                        if constexpr (xo) { mat4_apply(M, x[1]); mat4_apply(M, x[1] + 4); }
+                    });
+                } else if (lo == GTA_HALF_SO2 && hi == GTA_HALF_SO2 && cs_base) {
+                    run(F, F, [&](float (*x)[8]) {
+                        const f32x4_t t0 = *reinterpret_cast<const f32x4_t*>(cs_base + 2 * cd_so2_lo(desc));
+                        const f32x4_t t1 = *reinterpret_cast<const f32x4_t*>(cs_base + 2 * cd_so2_hi(desc));
+                        rot2_apply<false>(t0.x, t0.y, x[0]); rot2_apply<false>(t0.z, t0.w, x[0] + 2);
+                        rot2_apply<false>(t1.x, t1.y, x[0] + 4); rot2_apply<false>(t1.z, t1.w, x[0] + 6);
+                        if constexpr (xo) {
+                            rot2_apply<false>(t0.x, t0.y, x[1]); rot2_apply<false>(t0.z, t0.w, x[1] + 2);
+                            rot2_apply<false>(t1.x, t1.y, x[1] + 4); rot2_apply<false>(t1.z, t1.w, x[1] + 6);
+                        }
+                    });
+                } else {                                 // mixed halves (no shipped config): the generic body
+                    auto generic = [&](float (*x)[8]) {
+                        f32x2_t cs[4];
+                        if (cs_base) load_cs(desc, cs_base, cs);
+                        chunk_apply<false, xo ? 2 : 1>(desc, rc + BREC_M, rc + BREC_D1, rc + BREC_D2, cs, x);   // q and do: same A_q
+                    };
+                    if (lo == GTA_HALF_SE3) run(T, F, generic);
+                    else if (hi == GTA_HALF_SE3) run(F, T, generic);
+                    else run(F, F, generic);
+                }
+            } else {
+                const u32x4_t z = {0u, 0u, 0u, 0u};
+                *reinterpret_cast<u32x4_t*>(smem + S::OFF_IQ + off) = z;
+                *reinterpret_cast<u32x4_t*>(smem + S::OFF_IDO + off) = z;
             }
-            if (desc) {
-                f32x2_t cs[4];
-                if (p.cs_q) load_cs(desc, p.cs_q + ((long)b * p.Tq + t) * 2 * p.nso2, cs);
-                if (xo) chunk_apply<false, 2>(desc, rc + BREC_M, rc + BREC_D1, rc + BREC_D2, cs, x);   // q and do: same A_q
-                else    chunk_apply<false, 1>(desc, rc + BREC_M, rc + BREC_D1, rc + BREC_D2, cs, x);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) x[0][i] *= qscale;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { x[0][i] = 0.f; x[1][i] = 0.f; }
         }
-        const int off = (r * CHP + swz<CHP>(r, c)) * 16;
-        *reinterpret_cast<u32x4_t*>(smem + S::OFF_IQ + off) = pack8(x[0]);
-        *reinterpret_cast<u32x4_t*>(smem + S::OFF_IDO + off) = pack8(x[1]);
-    }
+    };
+    if (p.flags & GTA_FLAG_V_TRANSFORM) chunks(std::true_type{}); else chunks(std::false_type{});
     atomicAdd(&dsum[r], dpart);
     const float dc_wg = wg_sum256(dcpart, dsum + 64, tid);      // (includes a __syncthreads)
     __syncthreads();
@@ -800,10 +843,10 @@ __global__ __launch_bounds__(1024) void gta_reduce_kernel(const float* __restric
 template <int DHP, int ESZ>
 int run_bwd(const GtaBwdParams& p, hipStream_t stream) {
     const int n_qt = (p.Tq + BN - 1) / BN;
-    if (int rc = gta_lds_optin<&gta_bwd_prep_kernel<DHP, ESZ>>(BPrepSmem<DHP, ESZ>::TOTAL)) return rc;
+    if (int rc = gta_lds_optin<&gta_bwd_prep_kernel<DHP, ESZ>>(BPrepSmem<DHP, ESZ>::total(GTA_MAX_VIEWS))) return rc;
     if (int rc = gta_lds_optin<&gta_bwd_dq_kernel<DHP, ESZ>>(DqSmem<DHP>::total(GTA_MAX_VIEWS))) return rc;
     if (int rc = gta_lds_optin<&gta_bwd_dkv_kernel<DHP, ESZ>>(DkvSmem<DHP>::total(GTA_MAX_VIEWS))) return rc;
-    constexpr int lds_prep = BPrepSmem<DHP, ESZ>::TOTAL;
+    const int lds_prep = BPrepSmem<DHP, ESZ>::total(p.vrep_q ? p.Nq : 0);
     const long prep_grid = ((long)p.B * n_qt + 7) / 8 * 8 * p.H;
     if (prep_grid > 0x7fffffffL) return GTA_E_UNSUPPORTED;
     hipLaunchKernelGGL((gta_bwd_prep_kernel<DHP, ESZ>), dim3((unsigned)prep_grid), dim3(256), lds_prep, stream, p);
