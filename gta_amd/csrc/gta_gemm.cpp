@@ -250,7 +250,13 @@ int gta_gemm(const GtaGemmDesc* desc, const void* a, const void* b, const void* 
     }
     const float alpha = g.alpha, beta = g.beta;
     if (!p.tuned) {
-        if (tuning_enabled() && !(c == d && beta != 0.f))
+        // timing needs to run and wait on the stream: not while it is being captured into a graph (the plan stays
+        // untuned -- hipBLASLt's first answer -- until a call outside a capture)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
+        if (cap != hipStreamCaptureStatusNone)
+            ;
+        else if (tuning_enabled() && !(c == d && beta != 0.f))
             tune_plan(p, ts.handle, g, &alpha, &beta, b, a, c ? c : d, d, workspace, (size_t)workspace_bytes, static_cast<hipStream_t>(stream));
         else
             p.tuned = true;

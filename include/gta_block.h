@@ -98,6 +98,9 @@ int gta_colsum(const void* a, int32_t dtype, int64_t m, int32_t n, int64_t ld, f
  *   GTA_EPI_DGELU_BGRAD     same, and bias[n] <- column sums of D       ... + d bias of net[0]
  *   GTA_EPI_BGRAD_A         bias[m] <- sum over k of op_a(A)            d bias of a Linear inside its wgrad GEMM
  * bias: bias_dtype (F32 or the d_dtype); aux: aux_dtype, leading dimension ldaux.
+ * The first call of a problem (per host thread) times hipBLASLt's candidate kernels on the caller's own buffers and keeps
+ * the fastest: that call runs the GEMM several times and waits on `stream` (environment GTA_GEMM_TUNE=0 turns it off,
+ * =2 searches every kernel of the library).  Not done while `stream` is being captured into a graph.
  * --------------------------------------------------------------------------------------------------------------- */
 #define GTA_EPI_NONE          0
 #define GTA_EPI_BIAS          1
