@@ -125,9 +125,17 @@ def _stream():
 
 
 def _require_cuda(*ts):
+    """Every tensor on a GPU, and that GPU the current device: the kernels are launched on ITS current stream."""
+    cur = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise GtaError("gta_amd kernels need CUDA/HIP tensors (MI355X); there is no CPU path")
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise GtaError(f"operand on {t.device} while the current device is cuda:{cur}: call under torch.cuda.device({t.device.index})")
 
 
 def check_table(name: str, t: Optional[torch.Tensor], shape, device, allow_none: bool = False):

@@ -100,9 +100,33 @@ def _stream(t: torch.Tensor):
 
 
 def _need_cuda(*ts):
+    """Every tensor on ONE GPU, and that GPU the current device (the kernels are launched on its current stream)."""
+    dev = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise GtaError("gta_amd block kernels need tensors on an MI355X (there is no CPU path)")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise GtaError(f"operands on different devices ({dev} and {t.device})")
+    if dev is not None and dev.index != torch.cuda.current_device():
+        raise GtaError(f"operands on {dev} while the current device is cuda:{torch.cuda.current_device()}: "
+                       f"call under torch.cuda.device({dev.index})")
+
+
+def _need_vec(name: str, t: Optional[torch.Tensor], n: int, dtype=torch.float32):
+    """t is a contiguous [n] vector of ``dtype`` (the kernels index it by the row length alone)."""
+    if t is not None and (t.dtype != dtype or t.numel() != n or not t.is_contiguous()):
+        raise GtaError(f"{name}: expected a contiguous {dtype} vector of {n} elements, got {tuple(t.shape)} {t.dtype}")
+
+
+def _need_like(name: str, t: Optional[torch.Tensor], ref: torch.Tensor, dtype=None):
+    """t is contiguous, shaped like ref (and of ``dtype`` when given)."""
+    if t is not None and (t.shape != ref.shape or not t.is_contiguous() or (dtype is not None and t.dtype != dtype)):
+        raise GtaError(f"{name}: expected a contiguous tensor of shape {tuple(ref.shape)}"
+                       f"{'' if dtype is None else ' ' + str(dtype)}, got {tuple(t.shape)} {t.dtype}")
 
 
 _ws_cache: dict = {}
@@ -124,6 +148,9 @@ def ln_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
     _need_cuda(x, gamma, beta)
     d = x.shape[-1]
     rows = x.numel() // d
+    _need_like("ln_fwd: x", x, x)
+    _need_vec("ln_fwd: gamma", gamma, d)
+    _need_vec("ln_fwd: beta", beta, d)
     y = torch.empty(x.shape, device=x.device, dtype=out_dtype)
     mean = torch.empty(rows, device=x.device, dtype=torch.float32) if want_stats else None
     rstd = torch.empty(rows, device=x.device, dtype=torch.float32) if want_stats else None
@@ -136,9 +163,15 @@ def ln_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: torch.T
            dres: Optional[torch.Tensor], bf16_copy: bool = False):
     """-> (dx like x [= dres + LayerNorm backward], dgamma [d] fp32, dbeta [d] fp32); with ``bf16_copy`` (fp32 x) the
     kernel also writes dx in bf16, returned as ``dx._gta_bf16`` for the block upstream (gta_amd.fused)."""
-    _need_cuda(dy, x)
+    _need_cuda(dy, x, gamma, mean, rstd, dres)
     d = x.shape[-1]
     rows = x.numel() // d
+    _need_like("ln_bwd: x", x, x)
+    _need_like("ln_bwd: dy", dy, x)
+    _need_like("ln_bwd: dres", dres, x, x.dtype)
+    _need_vec("ln_bwd: gamma", gamma, d)
+    _need_vec("ln_bwd: mean", mean, rows)
+    _need_vec("ln_bwd: rstd", rstd, rows)
     dx = torch.empty_like(x)
     dxb = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16) if (bf16_copy and x.dtype == torch.float32) else None
     dgamma = torch.empty(d, device=x.device, dtype=torch.float32)
@@ -156,6 +189,7 @@ def ln_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: torch.T
 def gelu_fwd(x: torch.Tensor, p: float = 0.0, seed: int = 0) -> torch.Tensor:
     """gelu(x), followed by dropout(p) with the mask of ``seed`` when p > 0 (x contiguous)."""
     _need_cuda(x)
+    _need_like("gelu_fwd: x", x, x)
     y = torch.empty_like(x)
     check(lib().gta_gelu_fwd(_ptr(x), _ptr(y), dtype_code(x.dtype), x.numel(), float(p), int(seed), _stream(x)), "gta_gelu_fwd")
     return y
@@ -163,6 +197,8 @@ def gelu_fwd(x: torch.Tensor, p: float = 0.0, seed: int = 0) -> torch.Tensor:
 
 def gelu_bwd(dy: torch.Tensor, x: torch.Tensor, p: float = 0.0, seed: int = 0) -> torch.Tensor:
     _need_cuda(x, dy)
+    _need_like("gelu_bwd: x", x, x)
+    _need_like("gelu_bwd: dy", dy, x, x.dtype)
     dx = torch.empty_like(x)
     check(lib().gta_gelu_bwd(_ptr(dy), _ptr(x), _ptr(dx), dtype_code(x.dtype), x.numel(), float(p), int(seed), _stream(x)),
           "gta_gelu_bwd")
@@ -194,6 +230,8 @@ def dropout_bwd(dout: torch.Tensor, out_dtype: torch.dtype, p: float, seed: int)
 def colsum(a: torch.Tensor) -> torch.Tensor:
     """a [m, n] (row stride a.stride(0)) -> fp32 [n]."""
     _need_cuda(a)
+    if a.dim() != 2 or a.stride(1) != 1:
+        raise GtaError("colsum: a 2-D operand with unit column stride")
     m, n = a.shape
     out = torch.empty(n, device=a.device, dtype=torch.float32)
     nbytes = lib().gta_colsum_workspace_bytes(m, n)
@@ -216,6 +254,12 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out_
     out_dtype = out_dtype or (c.dtype if c is not None else a.dtype)
     if out is None:
         out = torch.empty(m, n, device=a.device, dtype=out_dtype)
+    _need_cuda(out)
+    for name, t in (("out", out), ("c", c), ("aux", aux)):
+        if t is not None and (t.shape != (m, n) or t.stride(1) != 1):
+            raise GtaError(f"gemm: {name} must be [{m}, {n}] with unit column stride, got {tuple(t.shape)}")
+    if bias is not None and (bias.numel() != (m if epilogue == EPI_BGRAD_A else n) or not bias.is_contiguous()):
+        raise GtaError(f"gemm: bias of {bias.numel()} elements for an [{m}, {n}] result")
     desc = GtaGemmDesc()
     desc.abi_version = BLOCK_ABI_VERSION
     desc.epilogue = epilogue
@@ -245,10 +289,10 @@ def wgrad_supported(g: torch.Tensor, x: torch.Tensor) -> bool:
 def wgrad(g: torch.Tensor, x: torch.Tensor, want_bias: bool):
     """g [m,n] bf16 (d out), x [m,k] bf16 (layer input) -> (dW [n,k] fp32 = g^T x, db [n] fp32 = column sums of g or None)."""
     _need_cuda(g, x)
+    if not wgrad_supported(g, x) or x.shape[0] != g.shape[0]:
+        raise GtaError(f"wgrad: unsupported operands {tuple(g.shape)} {g.dtype} / {tuple(x.shape)} {x.dtype} (gta_block.h)")
     m, n = g.shape
     k = x.shape[1]
-    if x.shape[0] != m:
-        raise GtaError(f"wgrad: {tuple(g.shape)} vs {tuple(x.shape)}")
     dw = torch.empty(n, k, device=g.device, dtype=torch.float32)
     db = torch.empty(n, device=g.device, dtype=torch.float32) if want_bias else None
     nbytes = lib().gta_wgrad_workspace_bytes(m, n, k)

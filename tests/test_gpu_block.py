@@ -64,6 +64,34 @@ def test_layernorm_refuses_bad_shapes():
         nb.ln_fwd(torch.randn(4, 16), torch.ones(16), torch.zeros(16), 1e-5, BF)      # CPU tensors: no fallback
 
 
+def test_bindings_refuse_malformed_operands():
+    """The kernels index by the sizes they are told: the bindings check what the pointers stand for."""
+    x = torch.randn(8, 64, device=DEV)
+    g, b = torch.ones(64, device=DEV), torch.zeros(64, device=DEV)
+    y, mean, rstd = nb.ln_fwd(x, g, b, 1e-5, BF)
+    with pytest.raises(GtaError):
+        nb.ln_fwd(x, g.to(BF), b, 1e-5, BF)                       # gamma is read as fp32
+    with pytest.raises(GtaError):
+        nb.ln_fwd(x, g[:32], b, 1e-5, BF)                          # too short
+    with pytest.raises(GtaError):
+        nb.ln_fwd(x.t().contiguous().t(), g, b, 1e-5, BF)          # rows not contiguous
+    with pytest.raises(GtaError):
+        nb.ln_bwd(y[:4], x, g, mean, rstd, None)                   # gradient of another shape
+    with pytest.raises(GtaError):
+        nb.ln_bwd(y, x, g, mean[:4], rstd, None)                   # statistics of another row count
+    with pytest.raises(GtaError):
+        nb.ln_bwd(y, x, g, mean, rstd, x.to(BF))                   # skip gradient must have x's dtype
+    with pytest.raises(GtaError):
+        nb.gelu_bwd(y.float(), y)                                  # dtypes differ
+    a, w = torch.randn(16, 64, device=DEV, dtype=BF), torch.randn(32, 64, device=DEV, dtype=BF)
+    with pytest.raises(GtaError):
+        nb.gemm(a, w, trans_b=True, epilogue=nb.EPI_BIAS, bias=torch.zeros(16, device=DEV, dtype=BF))   # bias of the wrong length
+    with pytest.raises(GtaError):
+        nb.gemm(a, w, trans_b=True, c=torch.zeros(16, 16, device=DEV, dtype=BF), beta=1.0)              # C of the wrong shape
+    with pytest.raises(GtaError):
+        nb.wgrad(torch.randn(64, 100, device=DEV, dtype=BF), torch.randn(64, 256, device=DEV, dtype=BF), False)   # n % 256 != 0
+
+
 @pytest.mark.parametrize("dt", [torch.float32, BF])
 def test_gelu_and_colsum(dt):
     g = torch.Generator(device=DEV).manual_seed(5)
