@@ -19,17 +19,19 @@
 // between its two 16-token MFMA blocks, so every fragment read flies under an MFMA block.  Each wave owns 128 x 64 of the
 // tile: 8 accumulators of 32 x 32, 16 MFMAs against 24 transpose-reads and 4 DMA instructions per step.
 //
-// What bounds it (profiles/r02/README.md) is not settled.  Switch experiments on dW[2304,768]: 231 us as is; 191 us with
-// the DMA switched off (compute on stale LDS); 114 us with the MFMAs and fragment reads switched off (the DMA alone: 11 TB/s
-// into the LDS); 232 us with every pair of transpose-reads replaced by one ds_read_b128 (half the LDS instructions, wrong
-// data).  So it is neither HBM (FETCH_SIZE 1.7x the algorithmic bytes), nor the DMA path, nor the LDS (array busy 384 of
-// ~3 000 cycles per step, zero conflicts, and the read form does not matter): what remains is the waves' own
-// MFMA / wait / barrier stream -- 16 MFMAs per wave between barriers, SQ_WAIT_ANY 35 % of the wave cycles, matrix pipe
-// busy 46 % of SIMD time.  With DMA, fragment reads AND the barrier switched off the loop still takes 62 cycles per MFMA
-// and SIMD at 2.3 GHz (286k of the 410k cycles), while the same 8-accumulator MFMA sequence alone runs at the pipe's 32
-// (tests/probes/probe_mfma_tile.hip: 2.1 PFLOP/s with one or two waves per SIMD): the loss sits in what surrounds the
-// MFMA blocks of a step (~100 scalar / address instructions per wave), not yet pinned down.  Four structurally different loops (128 x 128 or 128 x 64 per wave, two to four stages, 64-B or
-// 128-B row segments per DMA lane group) land within 2 % of each other at 600-760 TFLOP/s.
+// What bounds it (profiles/r02/README.md).  The steady-state step keeps everything that is not an MFMA BETWEEN the MFMAs of
+// its two blocks (one fragment's two transpose-reads or one DMA request per gap, pinned by scheduling barriers), runs on a
+// running scalar source pointer and writes M0 with one s_add per request: 75 instructions per step and wave, 16 of them
+// MFMAs (the first form of this loop had 127, with ~60 scalar / address instructions and the 12 reads of a block standing
+// between the blocks -- where, with the eight waves leaving the barrier in step, all four matrix pipes idle).  Switch
+// experiments on the final loop, dW[2304,768] over 40 960 tokens, finish kernel (14 us) included: 191.6 us as is; 167.3 without
+// the DMA (stale LDS); 116.4 without the fragment reads (the DMA's own floor is 114: 10-11 TB/s from L2 into the LDS);
+// 190.2 without the barrier; **105.8 with all three off = the MFMA stream alone**.  So the operand traffic through the LDS
+// is what is left: 96 KB of fragment reads + 32 KB of DMA writes per step and CU = 1 024 cycles at 128 B/clk, exactly the
+// 1 024 matrix-pipe cycles of the step's 128 MFMAs -- a pipeline without slack, and the measured times add rather than
+// overlap (92 + 60 + 24 us).  The read FORM does not matter (one ds_read_b128 per pair of transpose-reads: 193 us); the read
+// BYTES do: every G fragment is read by the four waves that share its columns, every X fragment by two.  What would cut
+// them is 128 x 128 per wave (four waves, accumulators in AGPRs: 64 KB of reads per step) -- not built.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "gta_common.h"
@@ -163,26 +165,45 @@ __global__ __launch_bounds__(64 * WG_WAVES) void wgrad_kernel(WgradParams p) {
             bf[buf][j][1] = tr16<off + 512>(bb);
         });
     };
-    auto mfma_block = [&](int cur) {
-        bf16x8_t a[4], b[2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const u32x4_t av = {af[cur][i][0].x, af[cur][i][0].y, af[cur][i][1].x, af[cur][i][1].y};
-            a[i] = __builtin_bit_cast(bf16x8_t, av);
-            if (BIAS && wk == 0 && k0 == 0)
-                dbs[i] += ((bf16_lo(av.x) + bf16_hi(av.x)) + (bf16_lo(av.y) + bf16_hi(av.y))) +
-                          ((bf16_lo(av.z) + bf16_hi(av.z)) + (bf16_lo(av.w) + bf16_hi(av.w)));
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const u32x4_t bv = {bf[cur][j][0].x, bf[cur][j][0].y, bf[cur][j][1].x, bf[cur][j][1].y};
-            b[j] = __builtin_bit_cast(bf16x8_t, bv);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    // operands of block `cur` as MFMA registers; one MFMA; the bias share of one G fragment (token sums of its 32 columns)
+    auto a_of = [&](int cur, int i) {
+        const u32x4_t av = {af[cur][i][0].x, af[cur][i][0].y, af[cur][i][1].x, af[cur][i][1].y};
+        return av;
     };
+    auto mfma_one = [&](int cur, auto I, auto J) {
+        constexpr int i = decltype(I)::value, j = decltype(J)::value;
+        const u32x4_t bv = {bf[cur][j][0].x, bf[cur][j][0].y, bf[cur][j][1].x, bf[cur][j][1].y};
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a_of(cur, i)), __builtin_bit_cast(bf16x8_t, bv),
+                                                            acc[i][j], 0, 0, 0);
+    };
+    auto bias_acc = [&](int cur, int i) {
+        const u32x4_t av = a_of(cur, i);
+        dbs[i] += ((bf16_lo(av.x) + bf16_hi(av.x)) + (bf16_lo(av.y) + bf16_hi(av.y))) +
+                  ((bf16_lo(av.z) + bf16_hi(av.z)) + (bf16_lo(av.w) + bf16_hi(av.w)));
+    };
+    auto mfma_block = [&](int cur, bool bias_wave) {
+        if (bias_wave) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bias_acc(cur, i);
+        }
+        gta_static_for<4>([&](auto I) { gta_static_for<2>([&](auto J) { mfma_one(cur, I, J); }); });
+    };
+    // fragment reads of one 32-column group (i < 4: G group i, else X group i - 4) of token group U of the stage at `so`
+    auto load_frag = [&](uint32_t so, auto U, int buf, auto IDX) {
+        constexpr int u = decltype(U)::value, idx = decltype(IDX)::value;
+        if constexpr (idx < 4) {
+            constexpr int off = (2 * u * 4 + (idx >> 1)) * 1024;
+            const uint32_t ab = ((idx & 1) ? a_base1 : a_base0) + so;
+            af[buf][idx][0] = tr16<off>(ab);
+            af[buf][idx][1] = tr16<off + 512>(ab);
+        } else {
+            constexpr int j = idx - 4, off = 2 * u * 4 * 1024;
+            const uint32_t bb = (j ? b_base1 : b_base0) + so;
+            bf[buf][j][0] = tr16<off>(bb);
+            bf[buf][j][1] = tr16<off + 512>(bb);
+        }
+    };
+    const bool bias_wave = BIAS && wk == 0 && k0 == 0;
 
     // prologue: the ring's first NSTAGE steps are requested; step 0 is awaited
     const int pre = n_steps < WG_NSTAGE ? n_steps : WG_NSTAGE;
@@ -192,42 +213,84 @@ __global__ __launch_bounds__(64 * WG_WAVES) void wgrad_kernel(WgradParams p) {
     load_frags(0u, std::integral_constant<int, 0>{}, 0);
 
     int st = 0;                                                             // ring stage of step t
-    // One step.  STEADY (t + NSTAGE < n_steps): the ring is full behind this step, so the wait count, the barrier and the
-    // request of step t + NSTAGE need no conditions -- the steady-state loop carries no branches besides its own.
-    auto step = [&](int t, auto STEADYC) {
-        constexpr bool STEADY = decltype(STEADYC)::value;
-        // A: token group 0 of step t; group 1's fragments fly under its MFMAs.  (Scheduling barriers on BOTH sides of the
-        // wait: without the one in front hipcc sinks the previous block's MFMAs below the wait, behind the fragment reads
-        // that were issued to fly under them.)
+    // The steady-state requests (step t + NSTAGE while step t runs) keep a running scalar source pointer -- this wave's
+    // row group and column band folded in -- and write M0 with one s_add: LDS address = M0 + offset + 16 * lane and global
+    // address = base + offset + lane offset share the instruction's immediate, so piece q (128 B further in memory,
+    // 1 KiB further in LDS) takes M0 = stage base + 896 q and offset 128 q.
+    const char* dma_sb = src + (((long)(step0 + WG_NSTAGE) * WG_BT + (piece0 >> 2) * 8) * ld + c0) * 2;
+    const long dma_stride = (long)WG_BT * ld * 2;
+    const uint32_t lb_wave = lds0 + (is_x ? WG_OPER : 0) + piece0 * 1024;
+    auto dma_piece = [&](uint32_t lbase, auto Q) {
+        constexpr int q = decltype(Q)::value;
+        const unsigned voff = lane_src;                                     // (asm operands do not capture by themselves)
+        const char* sb = dma_sb;
+        asm volatile("s_add_i32 m0, %0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4"
+                     ::"s"(lbase), "v"(voff), "s"(sb), "n"(q * 896), "n"(q * 128) : "memory");
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+#define WG_SB __builtin_amdgcn_sched_barrier(0)
+    // One steady-state step (t + NSTAGE < n_steps: the ring is full behind it, no conditions).  Everything that is not an
+    // MFMA sits BETWEEN the MFMAs of a block, pinned by scheduling barriers: the eight waves leave the barrier in step, so
+    // whatever runs outside the MFMA blocks runs with the matrix pipes of all four SIMDs idle (the loop took 62 cycles per
+    // MFMA with the memory side switched off when fragment reads, DMA requests and address arithmetic stood between the blocks).
+    auto steady_step = [&](auto BW) {
+        constexpr bool bw = decltype(BW)::value;
+        // A: token group 0 of step t; group 1's fragments are requested under its MFMAs
+        const uint32_t so = (uint32_t)(st * WG_STAGE);
+        WG_SB; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); WG_SB;
+        mfma_one(0, I0{}, I0{}); load_frag(so, I1{}, 1, I0{}); WG_SB;
+        mfma_one(0, I0{}, I1{}); load_frag(so, I1{}, 1, I1{}); WG_SB;
+        mfma_one(0, I1{}, I0{}); load_frag(so, I1{}, 1, I2{}); WG_SB;
+        mfma_one(0, I1{}, I1{}); load_frag(so, I1{}, 1, I3{}); WG_SB;
+        mfma_one(0, I2{}, I0{}); load_frag(so, I1{}, 1, I4{}); WG_SB;
+        mfma_one(0, I2{}, I1{}); load_frag(so, I1{}, 1, I5{}); WG_SB;
+        mfma_one(0, I3{}, I0{}); if constexpr (bw) { bias_acc(0, 0); bias_acc(0, 1); } WG_SB;
+        mfma_one(0, I3{}, I1{}); if constexpr (bw) { bias_acc(0, 2); bias_acc(0, 3); } WG_SB;
+        // B: token group 1.  The ring turns first: step t + 1 has landed (my share, then everyone's), stage st is read out
+        // and takes step t + NSTAGE; the first fragments of step t + 1 are requested under these MFMAs.
+        const int st1 = st + 1 == WG_NSTAGE ? 0 : st + 1;
+        const uint32_t so1 = (uint32_t)(st1 * WG_STAGE), lbase = lb_wave + so;
+        asm volatile("s_waitcnt lgkmcnt(0) vmcnt(%0)" ::"n"((WG_NSTAGE - 2) * WG_DMA_PER_WAVE) : "memory");
+        __builtin_amdgcn_s_barrier();
+        WG_SB;
+        mfma_one(1, I0{}, I0{}); load_frag(so1, I0{}, 0, I0{}); WG_SB;
+        mfma_one(1, I0{}, I1{}); load_frag(so1, I0{}, 0, I1{}); WG_SB;
+        mfma_one(1, I1{}, I0{}); load_frag(so1, I0{}, 0, I2{}); WG_SB;
+        mfma_one(1, I1{}, I1{}); load_frag(so1, I0{}, 0, I3{}); WG_SB;
+        mfma_one(1, I2{}, I0{}); load_frag(so1, I0{}, 0, I4{}); dma_piece(lbase, I0{}); WG_SB;
+        mfma_one(1, I2{}, I1{}); load_frag(so1, I0{}, 0, I5{}); dma_piece(lbase, I1{}); WG_SB;
+        mfma_one(1, I3{}, I0{}); dma_piece(lbase, I2{}); if constexpr (bw) { bias_acc(1, 0); bias_acc(1, 1); } WG_SB;
+        mfma_one(1, I3{}, I1{}); dma_piece(lbase, I3{}); if constexpr (bw) { bias_acc(1, 2); bias_acc(1, 3); } WG_SB;
+        dma_sb += dma_stride;
+        st = st1;
+    };
+#undef WG_SB
+    // The ring's last NSTAGE steps: conditions on what is still to request and to await.
+    auto tail_step = [&](int t) {
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         load_frags((uint32_t)(st * WG_STAGE), std::integral_constant<int, 1>{}, 1);
-        mfma_block(0);
-        // B: token group 1; before its MFMAs the ring turns: step t's stage is read out by everyone (barrier) and takes
-        // step t + NSTAGE, and the first fragments of step t + 1 fly under these MFMAs
+        mfma_block(0, bias_wave);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         const int st1 = st + 1 == WG_NSTAGE ? 0 : st + 1;
-        if constexpr (STEADY) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WG_NSTAGE - 2) * WG_DMA_PER_WAVE) : "memory");   // step t + 1 has landed (my share)
-            __builtin_amdgcn_s_barrier();                                    // ... and everyone's; stage st is free
-            stage_dma(t + WG_NSTAGE, st);
-            load_frags((uint32_t)(st1 * WG_STAGE), std::integral_constant<int, 0>{}, 0);
-        } else if (t + 1 < n_steps) {
+        if (t + 1 < n_steps) {
             const int last_issued = t + WG_NSTAGE - 1 < n_steps - 1 ? t + WG_NSTAGE - 1 : n_steps - 1;
             dma_wait(last_issued - (t + 1));
             __builtin_amdgcn_s_barrier();
-            if (t + WG_NSTAGE < n_steps) stage_dma(t + WG_NSTAGE, st);
             load_frags((uint32_t)(st1 * WG_STAGE), std::integral_constant<int, 0>{}, 0);
         }
-        mfma_block(1);
+        mfma_block(1, bias_wave);
         st = st1;
     };
     int t = 0;
-    for (; t + WG_NSTAGE < n_steps; ++t) step(t, std::true_type{});
-    for (; t < n_steps; ++t) step(t, std::false_type{});
+    if (bias_wave) { for (; t + WG_NSTAGE < n_steps; ++t) steady_step(std::true_type{}); }
+    else           { for (; t + WG_NSTAGE < n_steps; ++t) steady_step(std::false_type{}); }
+    for (; t < n_steps; ++t) tail_step(t);
 
     // ---- epilogue: accumulators -> this split's partial tile (rows n, 128-B segments along k) ----
     float* out = p.part + (long)split * p.N * p.ldo;
