@@ -7,7 +7,7 @@
 // reduction runs over the M = batch x tokens rows, the SLOW index of both row-major operands, and the outputs are small
 // (768..2304 squared).  hipBLASLt's best kernel for it reaches 370-540 TFLOP/s at the MSN shapes (profiles/r02/README.md).
 //
-// Structure.  One workgroup (8 waves, 512 threads, one per CU) owns a 256 x 256 tile of dW over a slice of the tokens
+// Structure.  One workgroup (4 waves, one per SIMD and CU) owns a 256 x 256 tile of dW over a slice of the tokens
 // (split-M, partial tiles reduced in a fixed order by wgrad_finish_kernel: deterministic).  Per step of 32 tokens the two
 // operand tiles [32][256] are brought in by LDS-DMA (global_load_lds, 16 B per lane) as [8 token][64 column] sub-tiles of
 // 1 KiB -- one DMA instruction each: eight lanes fetch one whole 128-B line of a row, and the lane-linear LDS image of
@@ -16,8 +16,9 @@
 // group reads a [4 token][16 column] block and transposes it), so an operand of v_mfma_f32_32x32x16_bf16 is two such
 // reads.  With the swizzle the 32 lanes serviced together cover all 64 banks once: conflict-free (SQ_LDS_BANK_CONFLICT 0).
 // A ring of four 32-KiB stages keeps three steps of DMA in flight under the MFMAs; the ring turns in the MIDDLE of a step,
-// between its two 16-token MFMA blocks, so every fragment read flies under an MFMA block.  Each wave owns 128 x 64 of the
-// tile: 8 accumulators of 32 x 32, 16 MFMAs against 24 transpose-reads and 4 DMA instructions per step.
+// between its two 16-token MFMA blocks, so every fragment read flies under an MFMA block.  Each wave owns 128 x 128 of the
+// tile: 16 accumulators of 32 x 32 (256 registers: the AGPR half of the wave's file), 32 MFMAs against 32 transpose-reads and
+// 8 DMA instructions per step.  (GTA_WGRAD_WAVES=8 builds the earlier tiling: 128 x 64 per wave, two waves per SIMD.)
 //
 // What bounds it (profiles/r02/README.md).  The steady-state step keeps everything that is not an MFMA BETWEEN the MFMAs of
 // its two blocks (one fragment's two transpose-reads or one DMA request per gap, pinned by scheduling barriers), runs on a
@@ -31,7 +32,9 @@
 // 1 024 matrix-pipe cycles of the step's 128 MFMAs -- a pipeline without slack, and the measured times add rather than
 // overlap (92 + 60 + 24 us).  The read FORM does not matter (one ds_read_b128 per pair of transpose-reads: 193 us); the read
 // BYTES do: every G fragment is read by the four waves that share its columns, every X fragment by two.  What would cut
-// them is 128 x 128 per wave (four waves, accumulators in AGPRs: 64 KB of reads per step) -- not built.
+// them is the 128 x 128 wave tile (four waves, accumulators in AGPRs: 64 KB of reads per step), which is what the kernel now
+// uses: 191.6 -> 169.6 us on that shape (135 -> 115, 133 -> 114, 241 -> 197 us on the layer's others; the experiments above
+// are of the 8-wave tiling).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "gta_common.h"
@@ -49,8 +52,17 @@ constexpr int WG_STAGE = 2 * WG_OPER;              // G tile + X tile (32 KiB)
 #endif
 constexpr int WG_NSTAGE = GTA_WGRAD_STAGES;        // ring depth: NSTAGE - 1 steps of DMA in flight under the MFMAs
 constexpr int WG_LDS = WG_NSTAGE * WG_STAGE;
-constexpr int WG_WAVES = 8;                        // 2 (n) x 4 (k): 128 x 64 of the tile per wave, two waves per SIMD
-constexpr int WG_DMA_PER_WAVE = 4;                 // 1-KiB sub-tiles a wave brings per step
+#ifndef GTA_WGRAD_WAVES
+#define GTA_WGRAD_WAVES 4
+#endif
+constexpr int WG_WAVES = GTA_WGRAD_WAVES;          // 4: 2 (n) x 2 (k), 128 x 128 of the tile per wave, one wave per SIMD, accumulators
+                                                   //    in AGPRs;  8: 2 x 4, 128 x 64 per wave, two waves per SIMD
+static_assert(WG_WAVES == 4 || WG_WAVES == 8, "wave tilings of the 256 x 256 workgroup tile");
+constexpr int WG_WK = WG_WAVES / 2;                // waves along k
+constexpr int WG_JB = 256 / WG_WK / 32;            // 32-column X fragments per wave (4 or 2); G fragments: always 4
+constexpr int WG_NF = 4 + WG_JB;                   // fragments a wave reads per 16-token block
+constexpr int WG_NM = 4 * WG_JB;                   // MFMAs per block
+constexpr int WG_DMA_PER_WAVE = 32 / WG_WAVES;     // 1-KiB sub-tiles a wave brings per step
 
 struct WgradParams {
     const char* g;       // [M][ldg] bf16
@@ -79,7 +91,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) void wgrad_kernel(WgradParams p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);             // wave-uniform: everything derived from it stays scalar
-    const int wn = wave >> 2, wk = wave & 3;
+    const int wn = wave / WG_WK, wk = wave % WG_WK;
     // XCD-aware work map: workgroup L runs on XCD L % 8.  Workgroups of one token split share their operand tiles (the G
     // tile of a row of dW tiles, the X tile of a column), so each XCD takes a CONTIGUOUS run of the (split, tile) list and
     // its L2 serves the re-reads (measured: the kernel is bound by the fabric otherwise, 4.8 TB/s into the LDS).
@@ -92,16 +104,16 @@ __global__ __launch_bounds__(64 * WG_WAVES) void wgrad_kernel(WgradParams p) {
     int n_steps = p.M / WG_BT - step0;                                     // 32-token steps of this split
     if (n_steps > p.steps_per_split) n_steps = p.steps_per_split;
 
-    // ---- DMA plan: 32 sub-tiles of 1 KiB per step; waves 0,1 bring G (16 sub-tiles), waves 2,3 bring X ----
+    // ---- DMA plan: 32 sub-tiles of 1 KiB per step; the first half of the waves bring G (16 sub-tiles), the second X ----
     // A sub-tile is [8 tokens][64 columns]: lane l fetches 16 B of row l/8 -- eight lanes cover one whole 128-B line (the
     // vector-memory path works per line: 64-B row segments cost twice the address work for the same bytes).  Which of
     // the row's eight 16-B chunks a lane fetches is swizzled, chunk = (l % 8) ^ 4*((row >> 1) & 1), so that in the
     // lane-linear LDS image (128-B rows) rows 0..3 of a 64-B column band land in four different bank quarters.
-    const bool is_x = wave >= 4;
+    const bool is_x = wave >= WG_WAVES / 2;
     const char* src = is_x ? p.x : p.g;
     const long ld = is_x ? p.ldx : p.ldg;
     const int c0 = is_x ? k0 : n0;
-    const int piece0 = (wave & 3) * WG_DMA_PER_WAVE;                       // this wave's 4 sub-tiles of its operand
+    const int piece0 = (wave % (WG_WAVES / 2)) * WG_DMA_PER_WAVE;          // this wave's sub-tiles of its operand
     const int drow = lane >> 3, dchunk = (lane & 7) ^ (((drow >> 1) & 1) << 2);
     const unsigned lane_src = (unsigned)(((long)drow * ld + dchunk * 8) * 2);   // (< 2^32: checked by the launcher)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)smem;
@@ -137,34 +149,19 @@ __global__ __launch_bounds__(64 * WG_WAVES) void wgrad_kernel(WgradParams p) {
     const uint32_t la0 = (uint32_t)((lane >> 5) * 4096 + rrow * 128 + chunk0 * 16 + (pl & 1) * 8);
     const uint32_t la1 = la0 ^ 64u;
     const uint32_t a_base0 = lds0 + wn * 2048 + la0, a_base1 = lds0 + wn * 2048 + la1;                 // G bands wn*2, wn*2+1
-    const uint32_t b_base0 = lds0 + WG_OPER + wk * 1024 + la0, b_base1 = lds0 + WG_OPER + wk * 1024 + la1;     // X band wk
+    const uint32_t b_base0 = lds0 + WG_OPER + wk * (WG_JB / 2) * 1024 + la0, b_base1 = b_base0 ^ 64u;     // X bands of wk
 
-    f32x16_t acc[4][2];
+    f32x16_t acc[4][WG_JB];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WG_JB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     float dbs[4] = {0.f, 0.f, 0.f, 0.f};
 
-    u32x2_t af[2][4][2], bf[2][2][2];                                       // [buffer][32-column group][token half]
+    u32x2_t af[2][4][2], bf[2][WG_JB][2];                                   // [buffer][32-column group][token half]
     // fragments of the 16-token group u (sub-tile row groups 2u, 2u+1) of the stage at byte offset `so`
-    auto load_frags = [&](uint32_t so, auto U, int buf) {
-        constexpr int u = decltype(U)::value;
-        gta_static_for<4>([&](auto I) {
-            constexpr int i = decltype(I)::value, off = (2 * u * 4 + (i >> 1)) * 1024;
-            const uint32_t ab = ((i & 1) ? a_base1 : a_base0) + so;
-            af[buf][i][0] = tr16<off>(ab);
-            af[buf][i][1] = tr16<off + 512>(ab);
-        });
-        gta_static_for<2>([&](auto J) {
-            constexpr int j = decltype(J)::value, off = 2 * u * 4 * 1024;
-            const uint32_t bb = (j ? b_base1 : b_base0) + so;
-            bf[buf][j][0] = tr16<off>(bb);
-            bf[buf][j][1] = tr16<off + 512>(bb);
-        });
-    };
     // operands of block `cur` as MFMA registers; one MFMA; the bias share of one G fragment (token sums of its 32 columns)
     auto a_of = [&](int cur, int i) {
         const u32x4_t av = {af[cur][i][0].x, af[cur][i][0].y, af[cur][i][1].x, af[cur][i][1].y};
@@ -186,22 +183,24 @@ __global__ __launch_bounds__(64 * WG_WAVES) void wgrad_kernel(WgradParams p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) bias_acc(cur, i);
         }
-        gta_static_for<4>([&](auto I) { gta_static_for<2>([&](auto J) { mfma_one(cur, I, J); }); });
+        gta_static_for<4>([&](auto I) { gta_static_for<WG_JB>([&](auto J) { mfma_one(cur, I, J); }); });
     };
     // fragment reads of one 32-column group (i < 4: G group i, else X group i - 4) of token group U of the stage at `so`
     auto load_frag = [&](uint32_t so, auto U, int buf, auto IDX) {
         constexpr int u = decltype(U)::value, idx = decltype(IDX)::value;
+        constexpr int f = idx < 4 ? idx : idx - 4, off = (2 * u * 4 + (f >> 1)) * 1024;
         if constexpr (idx < 4) {
-            constexpr int off = (2 * u * 4 + (idx >> 1)) * 1024;
-            const uint32_t ab = ((idx & 1) ? a_base1 : a_base0) + so;
-            af[buf][idx][0] = tr16<off>(ab);
-            af[buf][idx][1] = tr16<off + 512>(ab);
+            const uint32_t ab = ((f & 1) ? a_base1 : a_base0) + so;
+            af[buf][f][0] = tr16<off>(ab);
+            af[buf][f][1] = tr16<off + 512>(ab);
         } else {
-            constexpr int j = idx - 4, off = 2 * u * 4 * 1024;
-            const uint32_t bb = (j ? b_base1 : b_base0) + so;
-            bf[buf][j][0] = tr16<off>(bb);
-            bf[buf][j][1] = tr16<off + 512>(bb);
+            const uint32_t bb = ((f & 1) ? b_base1 : b_base0) + so;
+            bf[buf][f][0] = tr16<off>(bb);
+            bf[buf][f][1] = tr16<off + 512>(bb);
         }
+    };
+    auto load_frags = [&](uint32_t so, auto U, int buf) {
+        gta_static_for<WG_NF>([&](auto IDX) { load_frag(so, U, buf, IDX); });
     };
     const bool bias_wave = BIAS && wk == 0 && k0 == 0;
 
@@ -220,16 +219,15 @@ __global__ __launch_bounds__(64 * WG_WAVES) void wgrad_kernel(WgradParams p) {
     const char* dma_sb = src + (((long)(step0 + WG_NSTAGE) * WG_BT + (piece0 >> 2) * 8) * ld + c0) * 2;
     const long dma_stride = (long)WG_BT * ld * 2;
     const uint32_t lb_wave = lds0 + (is_x ? WG_OPER : 0) + piece0 * 1024;
-    auto dma_piece = [&](uint32_t lbase, auto Q) {
-        constexpr int q = decltype(Q)::value;
+    const long dma_row8 = 8 * ld * 2;                                       // bytes between token groups of 8
+    auto dma_piece = [&](uint32_t lbase, auto Q) {                          // piece q of this wave: token group q / 4, column group q % 4
+        constexpr int q = decltype(Q)::value, qt = q >> 2, qc = q & 3;
         const unsigned voff = lane_src;                                     // (asm operands do not capture by themselves)
-        const char* sb = dma_sb;
+        const char* sb = dma_sb + qt * dma_row8;
         asm volatile("s_add_i32 m0, %0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4"
-                     ::"s"(lbase), "v"(voff), "s"(sb), "n"(q * 896), "n"(q * 128) : "memory");
+                     ::"s"(lbase), "v"(voff), "s"(sb), "n"(qt * 4096 + qc * 896), "n"(qc * 128) : "memory");
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-    using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
 #define WG_SB __builtin_amdgcn_sched_barrier(0)
     // One steady-state step (t + NSTAGE < n_steps: the ring is full behind it, no conditions).  Everything that is not an
     // MFMA sits BETWEEN the MFMAs of a block, pinned by scheduling barriers: the eight waves leave the barrier in step, so
@@ -240,14 +238,13 @@ __global__ __launch_bounds__(64 * WG_WAVES) void wgrad_kernel(WgradParams p) {
         // A: token group 0 of step t; group 1's fragments are requested under its MFMAs
         const uint32_t so = (uint32_t)(st * WG_STAGE);
         WG_SB; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); WG_SB;
-        mfma_one(0, I0{}, I0{}); load_frag(so, I1{}, 1, I0{}); WG_SB;
-        mfma_one(0, I0{}, I1{}); load_frag(so, I1{}, 1, I1{}); WG_SB;
-        mfma_one(0, I1{}, I0{}); load_frag(so, I1{}, 1, I2{}); WG_SB;
-        mfma_one(0, I1{}, I1{}); load_frag(so, I1{}, 1, I3{}); WG_SB;
-        mfma_one(0, I2{}, I0{}); load_frag(so, I1{}, 1, I4{}); WG_SB;
-        mfma_one(0, I2{}, I1{}); load_frag(so, I1{}, 1, I5{}); WG_SB;
-        mfma_one(0, I3{}, I0{}); if constexpr (bw) { bias_acc(0, 0); bias_acc(0, 1); } WG_SB;
-        mfma_one(0, I3{}, I1{}); if constexpr (bw) { bias_acc(0, 2); bias_acc(0, 3); } WG_SB;
+        gta_static_for<WG_NM>([&](auto G) {
+            constexpr int g = decltype(G)::value;
+            mfma_one(0, std::integral_constant<int, g / WG_JB>{}, std::integral_constant<int, g % WG_JB>{});
+            if constexpr (g < WG_NF) load_frag(so, I1{}, 1, G);
+            if constexpr (bw && g >= WG_NM - 4) bias_acc(0, g - (WG_NM - 4));
+            WG_SB;
+        });
         // B: token group 1.  The ring turns first: step t + 1 has landed (my share, then everyone's), stage st is read out
         // and takes step t + NSTAGE; the first fragments of step t + 1 are requested under these MFMAs.
         const int st1 = st + 1 == WG_NSTAGE ? 0 : st + 1;
@@ -255,14 +252,14 @@ __global__ __launch_bounds__(64 * WG_WAVES) void wgrad_kernel(WgradParams p) {
         asm volatile("s_waitcnt lgkmcnt(0) vmcnt(%0)" ::"n"((WG_NSTAGE - 2) * WG_DMA_PER_WAVE) : "memory");
         __builtin_amdgcn_s_barrier();
         WG_SB;
-        mfma_one(1, I0{}, I0{}); load_frag(so1, I0{}, 0, I0{}); WG_SB;
-        mfma_one(1, I0{}, I1{}); load_frag(so1, I0{}, 0, I1{}); WG_SB;
-        mfma_one(1, I1{}, I0{}); load_frag(so1, I0{}, 0, I2{}); WG_SB;
-        mfma_one(1, I1{}, I1{}); load_frag(so1, I0{}, 0, I3{}); WG_SB;
-        mfma_one(1, I2{}, I0{}); load_frag(so1, I0{}, 0, I4{}); dma_piece(lbase, I0{}); WG_SB;
-        mfma_one(1, I2{}, I1{}); load_frag(so1, I0{}, 0, I5{}); dma_piece(lbase, I1{}); WG_SB;
-        mfma_one(1, I3{}, I0{}); dma_piece(lbase, I2{}); if constexpr (bw) { bias_acc(1, 0); bias_acc(1, 1); } WG_SB;
-        mfma_one(1, I3{}, I1{}); dma_piece(lbase, I3{}); if constexpr (bw) { bias_acc(1, 2); bias_acc(1, 3); } WG_SB;
+        gta_static_for<WG_NM>([&](auto G) {
+            constexpr int g = decltype(G)::value;
+            mfma_one(1, std::integral_constant<int, g / WG_JB>{}, std::integral_constant<int, g % WG_JB>{});
+            if constexpr (g < WG_NF) load_frag(so1, I0{}, 0, G);
+            if constexpr (g >= WG_NM - WG_DMA_PER_WAVE) dma_piece(lbase, std::integral_constant<int, g - (WG_NM - WG_DMA_PER_WAVE)>{});
+            if constexpr (bw && g >= WG_NM - 4) bias_acc(1, g - (WG_NM - 4));
+            WG_SB;
+        });
         dma_sb += dma_stride;
         st = st1;
     };
@@ -297,11 +294,11 @@ __global__ __launch_bounds__(64 * WG_WAVES) void wgrad_kernel(WgradParams p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WG_JB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wn * 128 + i * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
-                const int k = k0 + wk * 64 + j * 32 + (lane & 31);
+                const int k = k0 + wk * (32 * WG_JB) + j * 32 + (lane & 31);
                 out[(long)n * p.ldo + k] = acc[i][j][r];
             }
     if (BIAS && wk == 0 && k0 == 0) {
