@@ -31,6 +31,9 @@
 
 namespace {
 
+template <int N, class F>
+GTA_DEV void static_for_bwd(F&& f) { gta_static_for<N>(static_cast<F&&>(f)); }
+
 constexpr int BN = 64;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
@@ -738,23 +741,33 @@ __global__ __launch_bounds__(256, 2) void gta_bwd_dkv_kernel(const GtaBwdParams 
             dsf[0] = __builtin_bit_cast(bf16x8_t, pack_acc8(ds, 0)); dsf[1] = __builtin_bit_cast(bf16x8_t, pack_acc8(ds, 1));
             // dV'^T += dO~^T P ; dK'^T += Q''^T dS   (A operands by transpose-read of the row-major images)
             const uint32_t qb_l = lds_addr(qi) + qb * 32 * CHP * 16, db_l = lds_addr(di) + qb * 32 * CHP * 16;
-#pragma unroll
-            for (int d = 0; d < DB; ++d) {
-                u32x2_t qlo[2], qhi[2], dlo[2], dhi[2];
-                qlo[0] = lds_tr16_b64<0>(qb_l + voff[d][0]);  qhi[0] = lds_tr16_b64<0>(qb_l + voff[d][1]);
-                qlo[1] = lds_tr16_b64<SL>(qb_l + voff[d][0]); qhi[1] = lds_tr16_b64<SL>(qb_l + voff[d][1]);
-                dlo[0] = lds_tr16_b64<0>(db_l + voff[d][0]);  dhi[0] = lds_tr16_b64<0>(db_l + voff[d][1]);
-                dlo[1] = lds_tr16_b64<SL>(db_l + voff[d][0]); dhi[1] = lds_tr16_b64<SL>(db_l + voff[d][1]);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // the transpose-reads of channel block d + 1 are requested before the MFMAs of block d (two register sets)
+            u32x2_t qlo[2][2], qhi[2][2], dlo[2][2], dhi[2][2];
+            auto tr_reads = [&](int d, int set) {
+                qlo[set][0] = lds_tr16_b64<0>(qb_l + voff[d][0]);  qhi[set][0] = lds_tr16_b64<0>(qb_l + voff[d][1]);
+                qlo[set][1] = lds_tr16_b64<SL>(qb_l + voff[d][0]); qhi[set][1] = lds_tr16_b64<SL>(qb_l + voff[d][1]);
+                dlo[set][0] = lds_tr16_b64<0>(db_l + voff[d][0]);  dhi[set][0] = lds_tr16_b64<0>(db_l + voff[d][1]);
+                dlo[set][1] = lds_tr16_b64<SL>(db_l + voff[d][0]); dhi[set][1] = lds_tr16_b64<SL>(db_l + voff[d][1]);
+            };
+            tr_reads(0, 0);
+            static_for_bwd<DB>([&](auto DC) {
+                constexpr int d = decltype(DC)::value, set = d & 1;
+                if constexpr (d + 1 < DB) {
+                    tr_reads(d + 1, set ^ 1);
+                    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const u32x4_t aq = {qlo[t].x, qlo[t].y, qhi[t].x, qhi[t].y};
-                    const u32x4_t ad = {dlo[t].x, dlo[t].y, dhi[t].x, dhi[t].y};
+                    const u32x4_t aq = {qlo[set][t].x, qlo[set][t].y, qhi[set][t].x, qhi[set][t].y};
+                    const u32x4_t ad = {dlo[set][t].x, dlo[set][t].y, dhi[set][t].x, dhi[set][t].y};
                     dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ad), pf[t], dv[d], 0, 0, 0);
                     dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, aq), dsf[t], dk[d], 0, 0, 0);
                 }
-            }
+                __builtin_amdgcn_sched_barrier(0);
+            });
         }
         if (j + 1 < n_qt && tid < 128) stats[((j + 1) & 1) * 128 + tid] = st_next;
     }
