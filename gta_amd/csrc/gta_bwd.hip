@@ -478,6 +478,19 @@ __global__ __launch_bounds__(256, 2) void gta_bwd_dq_kernel(const GtaBwdParams p
             e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, dof[ks], e0, 0, 0, 0);    // dP^T = V' dO~^T
             e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, dof[ks], e1, 0, 0, 0);
         }
+        // dQ'^T += K'^T dS^T below takes A = K'^T by transpose-reads of the K' image: channel block 0's are requested here, under
+        // the softmax arithmetic; block d + 1's before the MFMAs of block d (two register sets, counted waits)
+        const uint32_t kbase_l = lds_addr(kf);
+        constexpr int SL = 16 * CHP * 16;
+        u32x2_t klo[2][4], khi[2][4];
+        auto tr_reads = [&](int d, int set) {
+            const uint32_t a0 = kbase_l + voff[d][0], a1 = kbase_l + voff[d][1];
+            klo[set][0] = lds_tr16_b64<0>(a0);      khi[set][0] = lds_tr16_b64<0>(a1);
+            klo[set][1] = lds_tr16_b64<SL>(a0);     khi[set][1] = lds_tr16_b64<SL>(a1);
+            klo[set][2] = lds_tr16_b64<2 * SL>(a0); khi[set][2] = lds_tr16_b64<2 * SL>(a1);
+            klo[set][3] = lds_tr16_b64<3 * SL>(a0); khi[set][3] = lds_tr16_b64<3 * SL>(a1);
+        };
+        tr_reads(0, 0);
         // P = exp2(S - lse2);  dS = P (dP - D);  keys past Tk contribute nothing
         const bool tail = (j == n_tiles - 1) && (p.Tk & (BN - 1));
         const int kbase = j * BN + 4 * lh;
@@ -496,25 +509,22 @@ __global__ __launch_bounds__(256, 2) void gta_bwd_dq_kernel(const GtaBwdParams p
         dsf[0][0] = __builtin_bit_cast(bf16x8_t, pack_acc8(s0, 0)); dsf[0][1] = __builtin_bit_cast(bf16x8_t, pack_acc8(s0, 1));
         dsf[1][0] = __builtin_bit_cast(bf16x8_t, pack_acc8(s1, 0)); dsf[1][1] = __builtin_bit_cast(bf16x8_t, pack_acc8(s1, 1));
 
-        // dQ'^T += K'^T dS^T   (A = K'^T by transpose-read of the K' image)
-        const uint32_t kbase_l = lds_addr(kf);
-        constexpr int SL = 16 * CHP * 16;
-#pragma unroll
-        for (int d = 0; d < DB; ++d) {
-            const uint32_t a0 = kbase_l + voff[d][0], a1 = kbase_l + voff[d][1];
-            u32x2_t lo[4], hi[4];
-            lo[0] = lds_tr16_b64<0>(a0);      hi[0] = lds_tr16_b64<0>(a1);
-            lo[1] = lds_tr16_b64<SL>(a0);     hi[1] = lds_tr16_b64<SL>(a1);
-            lo[2] = lds_tr16_b64<2 * SL>(a0); hi[2] = lds_tr16_b64<2 * SL>(a1);
-            lo[3] = lds_tr16_b64<3 * SL>(a0); hi[3] = lds_tr16_b64<3 * SL>(a1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        static_for_bwd<DB>([&](auto DC) {
+            constexpr int d = decltype(DC)::value, set = d & 1;
+            if constexpr (d + 1 < DB) {
+                tr_reads(d + 1, set ^ 1);
+                asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int sl = 0; sl < 4; ++sl) {
-                const u32x4_t av = {lo[sl].x, lo[sl].y, hi[sl].x, hi[sl].y};
+                const u32x4_t av = {klo[set][sl].x, klo[set][sl].y, khi[set][sl].x, khi[set][sl].y};
                 dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av), dsf[sl >> 1][sl & 1], dq[d], 0, 0, 0);
             }
-        }
+            __builtin_amdgcn_sched_barrier(0);
+        });
     }
 
     // ---- epilogue: dq = A_q^T (c1 dQ') ; d trans_coeff through A_q ----
