@@ -45,6 +45,26 @@ def test_block_library_loads_and_exports_declared_symbols():
         nb.ln_fwd(torch.zeros(4, 16), torch.ones(16), torch.zeros(16), 1e-5, torch.bfloat16)     # CPU tensors: no fallback
 
 
+def test_wgrad_plan_without_gpu():
+    """gta_wgrad's shape rule and split-M plan are host code: the workspace covers S partial tiles (+ bias partials), every
+    split has at least eight 32-token steps, and the splits cover all tokens."""
+    from gta_amd import native_block as nb
+    lib = nb.lib()
+    assert lib.gta_wgrad_supported(40960, 2304, 768) == 1 and lib.gta_wgrad_supported(64, 256, 256) == 1
+    for bad in ((40961, 768, 768), (40960, 700, 768), (40960, 768, 100), (0, 256, 256), (32, 256, 128)):
+        assert lib.gta_wgrad_supported(*bad) == 0 and lib.gta_wgrad_workspace_bytes(*bad) == 0, bad
+    for m, n, k in ((40960, 2304, 768), (40960, 768, 768), (4160, 768, 256), (64, 256, 512), (256, 256, 256)):
+        nbytes = lib.gta_wgrad_workspace_bytes(m, n, k)
+        per_split = (n * k + n) * 4
+        assert nbytes > 0 and nbytes % per_split == 0
+        S, steps_total, tiles = nbytes // per_split, m // 32, (n // 256) * (k // 256)
+        assert 1 <= S <= max(1, steps_total // 8) and S * tiles <= 256 + tiles      # about one workgroup per CU
+        per = -(-steps_total // S)
+        assert per * (S - 1) < steps_total <= per * S                               # every split has work, all tokens covered
+    # argument checks run before anything touches a device
+    assert lib.gta_wgrad(None, 0, None, 0, 64, 256, 256, None, None, None, 0, None) == -1
+
+
 def test_fused_blocks_do_not_engage_off_gpu():
     """On CPU tensors the Transformer keeps the module-by-module path (and the attention operator then refuses)."""
     from gta_amd import fused
