@@ -190,6 +190,23 @@ def test_attention_kernel_is_spill_free():
     assert not problems, problems
 
 
+def test_tuned_kernels_keep_their_register_budgets():
+    """Pre-pass, backward kernels and the weight-gradient kernel's steady-state loop: no scratch where the measurements
+    of DESIGN.md were taken without it (tools/audit_spills.py audit_others compiles the three files to assembly)."""
+    import importlib.util
+    import os
+    import shutil
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("audit_spills", os.path.join(root, "tools", "audit_spills.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    report, problems = mod.audit_others()
+    assert len(report) >= 8 + 24 + 2, report
+    assert not problems, problems
+
+
 def test_srt_wrapper_state_dict_is_reference_compatible():
     """gta_amd.srt.TransformingSRT takes the reference's cfg and loads the reference's own state dict
     (fixture srt_ms_tiny: parameters of the reference TransformingSRT) with strict=True."""

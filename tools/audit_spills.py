@@ -41,9 +41,67 @@ def audit():
     return report, problems
 
 
+def _asm(src_name, extra=()):
+    src = os.path.join(ROOT, "gta_amd", "csrc", src_name)
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", *extra, "-S",
+                        "--cuda-device-only", "-o", out, src], check=True, stderr=subprocess.DEVNULL)
+        return open(out).read()
+
+
+def _kernels(text, pattern):
+    for m in re.finditer(r"^(_ZN\w*" + pattern + r"\w*):", text, re.M):
+        name = m.group(1)
+        body = text[m.start():text.index(".Lfunc_end", m.start())]
+        meta = text[text.index(".amdhsa_kernel " + name):][:4000]
+        yield name, m.groups()[1:], body, int(re.search(r"\.amdhsa_next_free_vgpr\s+(\d+)", meta).group(1))
+
+
+def audit_others():
+    """The kernels beside the attention forward that were tuned by instruction counts and occupancy (DESIGN.md sections 4.1,
+    4.3, 8): the K/V pre-pass must stay scratch-free and within the registers of five workgroups per CU at the shipped head
+    sizes (it is at 89 VGPRs at dh = 96: the LDS would allow six), the backward kernels scratch-free at dh <= 96, and the weight-gradient kernel's steady-state loop (the loops with
+    one step's 32 MFMAs) free of scratch accesses."""
+    report, problems = [], []
+    text = _asm("gta_prep.hip", ("-fno-slp-vectorize",))
+    for name, (dhp, esz), body, vgpr in _kernels(text, r"gta_kv_prep_kernelILi(\d+)ELi(\d+)E"):
+        row = {"kernel": f"gta_kv_prep_kernel<{dhp},{esz}>", "vgpr": vgpr, "scratch": body.count("scratch_")}
+        report.append(row)
+        if row["scratch"]:
+            problems.append(f"{row['kernel']}: {row['scratch']} scratch accesses")
+        if int(dhp) <= 96 and int(esz) == 2 and vgpr > 96:
+            problems.append(f"{row['kernel']}: {vgpr} VGPRs (five 4-wave workgroups per CU need <= 96; six would need <= 80)")
+    text = _asm("gta_bwd.hip", ("-fno-slp-vectorize",))
+    for kern in ("gta_bwd_prep_kernel", "gta_bwd_dq_kernel", "gta_bwd_dkv_kernel"):
+        for name, (dhp, esz), body, vgpr in _kernels(text, kern + r"ILi(\d+)ELi(\d+)E"):
+            row = {"kernel": f"{kern}<{dhp},{esz}>", "vgpr": vgpr, "scratch": body.count("scratch_")}
+            report.append(row)
+            if int(dhp) <= 96 and row["scratch"]:
+                problems.append(f"{row['kernel']}: {row['scratch']} scratch accesses")
+    text = _asm("gta_wgrad.hip")
+    for name, _, body, vgpr in _kernels(text, r"wgrad_kernelILb(\d)E"):
+        lines = body.split("\n")
+        labels = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+        steady = 0
+        for i, l in enumerate(lines):
+            m = re.search(r"s_c?branch\S*\s+(\.LBB\d+_\d+)", l)
+            if m and m.group(1) in labels and labels[m.group(1)] < i:
+                loop = lines[labels[m.group(1)]:i]
+                if sum("v_mfma" in x for x in loop) == 32 and len(loop) < 400:
+                    steady += 1
+                    if any("scratch_" in x for x in loop):
+                        problems.append(f"{name}: scratch access inside a steady-state loop")
+        report.append({"kernel": name, "vgpr": vgpr, "steady_loops": steady})
+        if not steady:
+            problems.append(f"{name}: no loop with one step's 32 MFMAs found")
+    return report, problems
+
+
 if __name__ == "__main__":
     rep, prob = audit()
-    for r in rep:
+    rep2, prob2 = audit_others()
+    for r in rep + rep2:
         print(r)
-    print("problems:", prob or "none")
-    sys.exit(1 if prob else 0)
+    print("problems:", (prob + prob2) or "none")
+    sys.exit(1 if prob or prob2 else 0)
