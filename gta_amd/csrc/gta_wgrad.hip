@@ -27,14 +27,14 @@
 // between the blocks -- where, with the eight waves leaving the barrier in step, all four matrix pipes idle).  Switch
 // experiments on the final loop, dW[2304,768] over 40 960 tokens, finish kernel (14 us) included: 191.6 us as is; 167.3 without
 // the DMA (stale LDS); 116.4 without the fragment reads (the DMA's own floor is 114: 10-11 TB/s from L2 into the LDS);
-// 190.2 without the barrier; **105.8 with all three off = the MFMA stream alone**.  So the operand traffic through the LDS
-// is what is left: 96 KB of fragment reads + 32 KB of DMA writes per step and CU = 1 024 cycles at 128 B/clk, exactly the
-// 1 024 matrix-pipe cycles of the step's 128 MFMAs -- a pipeline without slack, and the measured times add rather than
-// overlap (92 + 60 + 24 us).  The read FORM does not matter (one ds_read_b128 per pair of transpose-reads: 193 us); the read
-// BYTES do: every G fragment is read by the four waves that share its columns, every X fragment by two.  What would cut
-// them is the 128 x 128 wave tile (four waves, accumulators in AGPRs: 64 KB of reads per step), which is what the kernel now
-// uses: 191.6 -> 169.6 us on that shape (135 -> 115, 133 -> 114, 241 -> 197 us on the layer's others; the experiments above
-// are of the 8-wave tiling).
+// 190.2 without the barrier; **105.8 with all three off = the MFMA stream alone**.  Inside the kernel the parts add (92 + 60 + 24
+// us) rather than overlap, but that is not a property of fragment reads beside the matrix pipe: tests/probes/probe_lds_mfma.hip
+// (the same MFMA stream with the reads in its gaps, no DMA, no barrier) runs at 2 004-2 066 TFLOP/s against 2 144-2 194 without
+// the reads, at ~230 LDS bytes per clock and CU.  The cost sits in the per-step barrier and in the DMA writes next door; the firm
+// bound is the DMA's own floor, 114 us at the 10-11 TB/s the L2 -> LDS path delivers (73 % of this kernel's time).  The read form
+// does not matter either (one ds_read_b128 per pair of transpose-reads: 193 us).  The 128 x 128 wave tile on four waves (a third
+// fewer fragment bytes, half the waves at the barrier) took 191.6 -> 169.6 us on that shape (135 -> 115, 133 -> 114, 241 -> 197 us
+// on the layer's others; the experiments above are of the 8-wave tiling).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "gta_common.h"
