@@ -1,0 +1,1012 @@
+#!/usr/bin/env python3
+"""gen_attn64.py -- generator of the tile loop of gta_attn64_kernel (gta_fwd64.hip) as one gfx950 assembly stream.
+
+The attention kernel of the two-stage forward plan (source/layers.py:202-211 over the K'/V' images of the pre-pass,
+source/utils/gta.py:160-219) with 64 query rows per wave and ONE wave per SIMD: every K' fragment read, every V'
+transpose-read pair and every LDS-DMA piece feeds TWO matrix instructions, the O accumulators, the Q' / K' / V' fragments
+live in the accumulator half of the register file and never pass through the VALU in the steady state (lazy softmax:
+the O rescale is a rare, separate path).  hipcc cannot be made to place ~400 live registers and 5 issue slots per MFMA gap
+(r01's gta_fwd3), so the loop is emitted here, instruction by instruction, and included by the kernel as one asm statement.
+
+What this file guarantees on the CPU (run by `make` and by tests/test_host_logic.py):
+  * a typed-dataflow simulation of the emitted stream (one wave, the dynamic instruction order for several tile counts,
+    with and without forced rebase steps): every MFMA sees exactly the fragments / P words / accumulators it must,
+    every score is exponentiated, summed and packed exactly once, no register is overwritten while a consumer is
+    outstanding, every LDS read is behind its DMA's wait + barrier and every use of a read behind its lgkmcnt wait;
+  * the manual wait-state rules of the ISA on that same order (XDL write -> VALU read, VALU write -> XDL read,
+    transcendental forwarding, permlane, M0 -> LDS-DMA).
+Numerical parity is the GPU tests' job (tests/test_gpu_forward.py runs every fixture through this kernel).
+
+Register map (dh = 96: KS = 6 k-steps, DB = 3 channel blocks, RB = 2 row blocks of 32 query rows per wave)
+  a[  0: 95]  O^T[rb][d]        16 each            v[ 64: 95]  S'[rb], key half 0           16 each
+  a[ 96:143]  Q' fragments      [rb][ks] 4 each    v[ 96:159]  S'[p][rb], key half 1        16 each (p = step parity)
+  a[144:191]  K' fragments      [ks][hh] 4 each    v[160:191]  P[p][rb][t], key half 0      4 each (bf16 pairs)
+  a[192:239]  V'^T fragments    [slab][d] 4 each   v[192:207]  P[rb][t], key half 1         4 each
+                                                   v[208:239]  -m splat[rb]  16 each (C operand of a tile's first MFMAs)
+                                                   v[ 32: 63]  addresses, row sums, m, temporaries
+  v[0:31] and the SGPRs not named here belong to the compiler (operands of the statement).
+"""
+import argparse
+import sys
+
+KS, DB, RB = 6, 3, 2
+CHP = 12
+IMG = 64 * CHP * 16          # one K' or V' tile image (12288 B)
+TILE = 2 * IMG               # [K' image | V' image] of one key tile in HBM
+WSHARE = IMG // 4            # a wave's share of an image (3 pieces of 1 KiB)
+THR_BITS = 0x42c00000        # BOUND_THR = 96.0f (gta_flash_common.h)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# registers
+# ------------------------------------------------------------------------------------------------------------------
+def _sbase(p, rb, hh):
+    # S' of the hh = 0 half is consumed (phase B of step j - 1) before the next tile's is written (phase A of step j): one
+    # buffer; the hh = 1 half of tile j is consumed in phase A of step j while tile j + 1's is written: two (p = step parity)
+    return 64 + 16 * rb if hh == 0 else 96 + 16 * (p * 2 + rb)
+
+
+def S(p, rb, hh, r=None):
+    b = _sbase(p, rb, hh)
+    return f"v[{b}:{b + 15}]" if r is None else f"v{b + r}"
+
+
+def Sregs(p, rb, hh):
+    b = _sbase(p, rb, hh)
+    return [f"v{b + i}" for i in range(16)]
+
+
+def _pbase(p, rb, hh, t):
+    # P of the hh = 0 half of tile j + 1 is packed (phase B of step j) while tile j's is being multiplied: two buffers
+    return 160 + 4 * ((p * 2 + rb) * 2 + t) if hh == 0 else 192 + 4 * (rb * 2 + t)
+
+
+def P(p, rb, hh, t, w=None):
+    b = _pbase(p, rb, hh, t)
+    return f"v[{b}:{b + 3}]" if w is None else f"v{b + w}"
+
+
+def Pregs(p, rb, hh, t):
+    b = _pbase(p, rb, hh, t)
+    return [f"v{b + i}" for i in range(4)]
+
+
+def MS(rb, i=None):
+    b = 208 + 16 * rb
+    return f"v[{b}:{b + 15}]" if i is None else f"v{b + i}"
+
+
+def MSregs(rb):
+    return [f"v{208 + 16 * rb + i}" for i in range(16)]
+
+
+def O(rb, d, i=None):
+    b = 16 * (rb * DB + d)
+    return f"a[{b}:{b + 15}]" if i is None else f"a{b + i}"
+
+
+def Oregs(rb, d):
+    return [f"a{16 * (rb * DB + d) + i}" for i in range(16)]
+
+
+def Q(rb, ks):
+    b = 96 + 4 * (rb * KS + ks)
+    return f"a[{b}:{b + 3}]"
+
+
+def Qregs(rb, ks):
+    return [f"a{96 + 4 * (rb * KS + ks) + i}" for i in range(4)]
+
+
+def K(ks, hh):
+    b = 144 + 4 * (ks * 2 + hh)
+    return f"a[{b}:{b + 3}]"
+
+
+def Kregs(ks, hh):
+    return [f"a{144 + 4 * (ks * 2 + hh) + i}" for i in range(4)]
+
+
+def V(sl, d, half=None):
+    b = 192 + 4 * (sl * DB + d)
+    return f"a[{b}:{b + 3}]" if half is None else f"a[{b + 2 * half}:{b + 2 * half + 1}]"
+
+
+def Vregs(sl, d, half=None):
+    b = 192 + 4 * (sl * DB + d)
+    return [f"a{b + i}" for i in range(4)] if half is None else [f"a{b + 2 * half}", f"a{b + 2 * half + 1}"]
+
+
+# low literal VGPRs
+KOFF = [f"v{32 + i}" for i in range(KS)]             # K' fragment byte offsets (ring base 0)
+VOFF = [[f"v{38 + 2 * d + h}" for h in range(2)] for d in range(DB)]   # V' transpose-read offsets (V ring base folded in)
+LA = [[f"v{44 + 2 * rb + e}" for e in range(2)] for rb in range(RB)]   # row sums of the hh = 1 halves (phase A), even / odd
+LB = [[f"v{48 + 2 * rb + e}" for e in range(2)] for rb in range(RB)]   # row sums of the hh = 0 halves (phase B)
+MRUN = [f"v{52 + rb}" for rb in range(RB)]
+T = [f"v{54 + i}" for i in range(10)]                # temporaries v54..v63
+# literal SGPRs
+S_J, S_J1, S_KN, S_WOFF, S_T0, S_T1 = "s84", "s85", "s86", "s87", "s88", "s89"
+S_KPTR, S_VPTR = "s[90:91]", "s[92:93]"
+S_KPTR_LO, S_KPTR_HI, S_VPTR_LO, S_VPTR_HI = "s90", "s91", "s92", "s93"
+S_NM1, S_NMR, S_NMR1 = "s94", "s95", "s96"           # n-1, n-R, n-R+1
+
+
+class Ins:
+    __slots__ = ("text", "kind", "rd", "wr", "sem", "label", "target")
+
+    def __init__(self, text, kind, rd=(), wr=(), sem=None, label=None, target=None):
+        self.text, self.kind, self.rd, self.wr, self.sem = text, kind, tuple(rd), tuple(wr), sem
+        self.label, self.target = label, target
+
+    def __repr__(self):
+        return self.text
+
+
+def nop(n):
+    return Ins(f"s_nop {n - 1}", "nop", sem=("nop", n))
+
+
+def lgkm(n):
+    return Ins(f"s_waitcnt lgkmcnt({n})", "wait", sem=("lgkm", n))
+
+
+def vmw(n):
+    return Ins(f"s_waitcnt vmcnt({n})", "wait", sem=("vm", n))
+
+
+def barrier():
+    return Ins("s_barrier", "barrier", sem=("barrier",))
+
+
+def label(name):
+    return Ins(f"{name}:", "label", label=name)
+
+
+def salu(text, rd=(), wr=(), sem=None):
+    return Ins(text, "salu", rd, wr, sem)
+
+
+def branch(text, target, sem):
+    return Ins(f"{text} {target}", "branch", sem=sem, target=target)
+
+
+class Gen:
+    def __init__(self, R=4, kread_early=True, sched=True, boundary_in_a=False):
+        assert R in (2, 4)
+        self.R, self.early, self.sched, self.bina = R, kread_early and R == 4, sched, boundary_in_a
+        self.KRING, self.VRING = 0, R * IMG            # LDS byte offsets of the two rings
+
+    # ---- primitive emitters --------------------------------------------------------------------------------------
+    def ds_k(self, slot, ks, hh, tile_rel):
+        off = self.KRING + slot * IMG + hh * 32 * CHP * 16
+        return Ins(f"ds_read_b128 {K(ks, hh)}, {KOFF[ks]} offset:{off}", "ds", [KOFF[ks]], Kregs(ks, hh),
+                   ("ds_k", slot, ks, hh, tile_rel))
+
+    def ds_v(self, slot, sl, d, half):
+        off = slot * IMG + sl * 16 * CHP * 16
+        return Ins(f"ds_read_b64_tr_b16 {V(sl, d, half)}, {VOFF[d][half]} offset:{off}", "ds", [VOFF[d][half]],
+                   Vregs(sl, d, half), ("ds_v", slot, sl, d, half))
+
+    def qk(self, p, rb, hh, ks, tile_rel, c_zero=False):
+        c = "0" if c_zero else (MS(rb) if ks == 0 else S(p, rb, hh))
+        rd = Kregs(ks, hh) + Qregs(rb, ks) + ([] if c_zero else (MSregs(rb) if ks == 0 else Sregs(p, rb, hh)))
+        return Ins(f"v_mfma_f32_32x32x16_bf16 {S(p, rb, hh)}, {K(ks, hh)}, {Q(rb, ks)}, {c}", "mfma", rd, Sregs(p, rb, hh),
+                   ("qk", p, rb, hh, ks, tile_rel, c_zero))
+
+    def pv(self, p, sl, d, rb):
+        hh, t = sl >> 1, sl & 1
+        return Ins(f"v_mfma_f32_32x32x16_bf16 {O(rb, d)}, {V(sl, d)}, {P(p, rb, hh, t)}, {O(rb, d)}", "mfma",
+                   Vregs(sl, d) + Pregs(p, rb, hh, t) + Oregs(rb, d), Oregs(rb, d), ("pv", p, sl, d, rb))
+
+    def exp(self, p, rb, hh, r, tile_rel):
+        x = S(p, rb, hh, r)
+        return Ins(f"v_exp_f32 {x}, {x}", "trans", [x], [x], ("exp", p, rb, hh, r, tile_rel))
+
+    def add(self, p, rb, hh, r, acc):
+        x = S(p, rb, hh, r)
+        return Ins(f"v_add_f32 {acc}, {acc}, {x}", "valu", [acc, x], [acc], ("add", p, rb, hh, r))
+
+    def pack(self, p, rb, hh, e2):
+        # packed word k = e2 of half hh: values r = 2 e2, 2 e2 + 1 -> P[rb][hh][r >> 3][(r & 7) >> 1]
+        r = 2 * e2
+        dst = P(p, rb, hh, r >> 3, (r & 7) >> 1)
+        a, b = S(p, rb, hh, r), S(p, rb, hh, r + 1)
+        return Ins(f"v_cvt_pk_bf16_f32 {dst}, {a}, {b}", "valu", [a, b], [dst], ("pack", p, rb, hh, r >> 3, (r & 7) >> 1))
+
+    # ---- softmax VALU of one 32-key half of one tile, as an ordered list (exp first, sums / packs trail) -----------
+    def softmax_items(self, p, hh, tile_rel, phase):
+        """-> list of Ins in dependency-safe order: exps of pair k, then (one pair later) its adds and its pack."""
+        acc = LA if phase == "A" else LB
+        out = []
+        pairs = [(rb, e2) for e2 in range(8) for rb in range(RB)]      # interleave the row blocks
+        prev = None
+        for rb, e2 in pairs:
+            out.append(self.exp(p, rb, hh, 2 * e2, tile_rel))
+            out.append(self.exp(p, rb, hh, 2 * e2 + 1, tile_rel))
+            if prev is not None:
+                prb, pe2 = prev
+                out.append(self.add(p, prb, hh, 2 * pe2, acc[prb][0]))
+                out.append(self.add(p, prb, hh, 2 * pe2 + 1, acc[prb][1]))
+                out.append(self.pack(p, prb, hh, pe2))
+            prev = (rb, e2)
+        prb, pe2 = prev
+        out.append(self.add(p, prb, hh, 2 * pe2, acc[prb][0]))
+        out.append(self.add(p, prb, hh, 2 * pe2 + 1, acc[prb][1]))
+        out.append(self.pack(p, prb, hh, pe2))
+        return out
+
+    # ---- the boundary of step copy c: tiles landed, everyone past the previous step, next DMA requests ------------
+    def boundary(self, c, first_of_item=False):
+        R = self.R
+        out = []
+        # landed before this step: with R = 4 everything but the last two boundaries' requests (K'(j+2), V'(j+1) and older);
+        # with R = 2 everything (K'(j+1), V'(j) were requested one boundary ago)
+        out.append(vmw(6 if R == 4 else 0))
+        out.append(barrier())
+        out += self.dma_requests(c)
+        return out
+
+    def dma_requests(self, c):
+        """K'(j + R) -> K slot c (tile j's slot, consumed), V'(j + R - 1) -> V slot c - 1 (tile j - 1's)."""
+        R = self.R
+        out = []
+        # the K stream passes to the next item's images at j == n - R (a step of copy 0), the V stream at j == n - R + 1
+        if c == 0:
+            out.append(salu(f"s_cmp_eq_u32 {S_J}, {S_NMR}", [S_J, S_NMR], ["scc"], ("cmp_nmr",)))
+            out.append(salu(f"s_cselect_b64 {S_KPTR}, %[nxt_k], {S_KPTR}", ["scc", S_KPTR], [S_KPTR], ("ksel",)))
+        if c == 1 % R:
+            out.append(salu(f"s_cmp_eq_u32 {S_J}, {S_NMR1}", [S_J, S_NMR1], ["scc"], ("cmp_nmr1",)))
+            out.append(salu(f"s_cselect_b64 {S_VPTR}, %[nxt_v], {S_VPTR}", ["scc", S_VPTR], [S_VPTR], ("vsel",)))
+        kslot, vslot = c, (c - 1) % R
+        out.append(salu(f"s_add_u32 m0, {S_WOFF}, {self.KRING + kslot * IMG}", [S_WOFF], ["m0"]))
+        out.append(nop(1))
+        for i in range(3):
+            out.append(Ins(f"global_load_lds_dwordx4 %[lane16], {S_KPTR} offset:{1024 * i}", "dma", ["m0", S_KPTR], [],
+                           ("dma", "K", kslot, i)))
+        out.append(salu(f"s_add_u32 m0, {S_WOFF}, {self.VRING + vslot * IMG}", [S_WOFF], ["m0"]))
+        out.append(nop(1))
+        for i in range(3):
+            out.append(Ins(f"global_load_lds_dwordx4 %[lane16], {S_VPTR} offset:{1024 * i}", "dma", ["m0", S_VPTR], [],
+                           ("dma", "V", vslot, i)))
+        out.append(salu(f"s_add_u32 {S_KPTR_LO}, {S_KPTR_LO}, {TILE}", [S_KPTR_LO], [S_KPTR_LO, "scc"], ("kadv", 0)))
+        out.append(salu(f"s_addc_u32 {S_KPTR_HI}, {S_KPTR_HI}, 0", [S_KPTR_HI, "scc"], [S_KPTR_HI, "scc"], ("kadv", 1)))
+        out.append(salu(f"s_add_u32 {S_VPTR_LO}, {S_VPTR_LO}, {TILE}", [S_VPTR_LO], [S_VPTR_LO, "scc"], ("vadv", 0)))
+        out.append(salu(f"s_addc_u32 {S_VPTR_HI}, {S_VPTR_HI}, 0", [S_VPTR_HI, "scc"], [S_VPTR_HI, "scc"], ("vadv", 1)))
+        return out
+
+    # ---- decision for tile j + 1 (lazy softmax: does |q'| max|k'| - m stay below the threshold?) -----------------
+    def decision(self, c, slow_label):
+        out = [salu(f"s_add_u32 {S_J1}, {S_J}, 1", [S_J], [S_J1, "scc"], ("j1",)),
+               Ins(f"v_readlane_b32 {S_KN}, %[kn], {S_J1}", "valu", [S_J1], [S_KN], ("readkn",)),
+               Ins(f"v_fma_f32 {T[0]}, %[qn0], {S_KN}, -{MRUN[0]}", "valu", [S_KN, MRUN[0]], [T[0]]),
+               Ins(f"v_fma_f32 {T[1]}, %[qn1], {S_KN}, -{MRUN[1]}", "valu", [S_KN, MRUN[1]], [T[1]]),
+               Ins(f"v_max_f32 {T[0]}, {T[0]}, {T[1]}", "valu", [T[0], T[1]], [T[0]]),
+               Ins(f"v_cmp_lt_f32 vcc, 0x{THR_BITS:08x}, {T[0]}", "valu", [T[0]], ["vcc"])]
+        tail = []
+        if c == self.R - 2:      # only this copy can be the step in front of the item's last tile (n % R == 0)
+            tail = [salu(f"s_cmp_eq_u32 {S_J1}, %[tailj]", [S_J1], ["scc"]),
+                    branch("s_cbranch_scc1", slow_label, ("br_tail",))]
+        return out, [branch("s_cbranch_vccnz", slow_label, ("br_need",))] + tail
+
+    # ---- phase A of step copy c: S'(j+1) = K'(j+1) Q'^T - m   ||  softmax of the hh = 1 half of tile j -------------
+    def phase_a(self, c, slow_label):
+        R, p, pn = self.R, c & 1, (c + 1) & 1
+        # g -> (ks, hh, rb): the two row blocks of a K' fragment back to back; the hh = 0 accumulators finish first (phase B
+        # exponentiates them right away: an XDL result needs 12 states before the VALU may read it)
+        mf = [self.qk(pn, g & 1, (g >> 1) & 1, g >> 2, 1) for g in range(4 * KS)]
+        valu = self.softmax_items(p, 1, 0, "A")
+        dec, dec_br = self.decision(c, slow_label)
+        vreads = [self.ds_v(c, sl, d, h) for sl in (0, 1) for d in range(DB) for h in range(2)]
+        kreads = [] if self.early else [self.ds_k((c + 1) % R, ks, hh, 1) for ks in range(KS) for hh in range(2)]
+        pre, gaps = [], [[] for _ in mf]
+        if not self.sched:
+            pre = kreads + vreads + valu + dec
+            return self.weave(pre, mf, gaps) + dec_br
+        # K' reads (not early): ks 0, 1 in front of the MFMAs, the rest two k-steps ahead of their first use
+        if kreads:
+            pre += kreads[:4]
+            for i, kr in enumerate(kreads[4:]):
+                gaps[2 * i].append(kr)           # fragment (ks, hh), ks >= 2, is requested in gap 2 i and used from MFMA 4 ks + 2 hh >= 8
+        # V' reads of slabs 0, 1: one per gap from gap 10 on (they only have to be there for phase B)
+        for i, vr in enumerate(vreads):
+            gaps[10 + i].append(vr)
+        # decision: needs nothing but scalars; early enough that the branch is resolved at the phase's end
+        for i, di in enumerate(dec):
+            gaps[2 + i].append(di)
+        # (gap 0 stays free of softmax work: the S' accumulators of phase A's last MFMAs need 12 states before the VALU reads them)
+        self.deal(valu, gaps, range(1, len(mf)))
+        return self.weave(pre, mf, gaps) + dec_br
+
+    # ---- phase B of step copy c: O += V'(j) P(j)   ||  softmax of the hh = 0 half of tile j + 1 -------------------
+    def phase_b(self, c, plain=False, last=False):
+        R, pn = self.R, (c + 1) & 1
+        mf = [self.pv(c & 1, g // (2 * DB), (g % (2 * DB)) >> 1, g & 1) for g in range(4 * 2 * DB)]   # g -> (slab, d, rb)
+        vreads = [self.ds_v(c, sl, d, h) for sl in (2, 3) for d in range(DB) for h in range(2)]
+        kreads = [self.ds_k((c + 2) % R, ks, hh, 2) for ks in range(KS) for hh in range(2)] if (self.early and not last) else []
+        valu = [] if plain else self.softmax_items(pn, 0, 1, "B")
+        pre, gaps = [], [[] for _ in mf]
+        if not self.sched or plain:
+            pre = vreads + kreads + [x for x in valu if x.sem[0] != "pack"]
+            packs = [x for x in valu if x.sem[0] == "pack"]
+            return self.weave(pre, mf, gaps) + packs
+        # V' reads of slabs 2 (needed by MFMA 12) and 3 (MFMA 18): one per gap from gap 0
+        for i, vr in enumerate(vreads):
+            gaps[i].append(vr)
+        # K' reads of tile j + 2: one per gap in the second half
+        for i, kr in enumerate(kreads):
+            gaps[12 + i].append(kr)
+        # (gap 0 stays free of softmax work: the S' accumulators of phase A's last MFMAs need 12 states before the VALU reads them)
+        self.deal(valu, gaps, range(1, len(mf)))
+        return self.weave(pre, mf, gaps)
+
+    def deal(self, valu, gaps, grange, pack_earliest=None):
+        """deal the ordered VALU list into the gaps so that every gap carries about the same issue cost; a pack whose
+        destination is still being read is held back (with everything behind it that depends on nothing it blocks)."""
+        cost = lambda x: 5 if x.kind == "trans" else 3
+        grange = list(grange)
+        load = [sum(cost(x) for x in gaps[g]) for g in range(len(gaps))]
+        total = sum(cost(x) for x in valu) + sum(load[g] for g in grange)
+        target = total / len(grange)
+        held = []
+        gi = 0
+        cum = 0.0
+        for x in valu:
+            while gi < len(grange) - 1 and load[grange[gi]] >= target:
+                gi += 1
+            g = grange[gi]
+            if pack_earliest and x.sem[0] == "pack" and g < pack_earliest[x.sem[4]]:
+                held.append(x)
+                continue
+            # release held packs as soon as their gap is reached
+            if held:
+                rel = [h for h in held if g >= pack_earliest[h.sem[4]]]
+                for h in rel:
+                    gaps[g].append(h)
+                    load[g] += cost(h)
+                    held.remove(h)
+            gaps[g].append(x)
+            load[g] += cost(x)
+        for h in held:
+            g = max(pack_earliest[h.sem[4]], grange[gi])
+            gaps[g].append(h)
+
+    def weave(self, pre, mf, gaps):
+        """pre, then MFMA g followed by the fillers of gap g; lgkmcnt waits are inserted later (insert_waits)."""
+        out = list(pre)
+        for g, m in enumerate(mf):
+            out.append(m)
+            out += gaps[g]
+        return out
+
+    # ---- last step of an item (j = n - 1, copy R - 1): softmax of the hh = 1 half of the last tile, then O += V' P ---
+    def tail_step(self):
+        c, p = self.R - 1, (self.R - 1) & 1
+        out = self.boundary(c)
+        vreads = [self.ds_v(c, sl, d, h) for sl in (0, 1) for d in range(DB) for h in range(2)]
+        out += vreads + self.softmax_items(p, 1, 0, "A")
+        out += self.phase_b(c, plain=True, last=True)
+        return out
+
+    # ---- rebase (the lazy softmax's full path) on the S' buffer of parity p ----------------------------------------
+    def rebase(self, p, first, tile_rel, uid=""):
+        """true row max of S' (relative to m), m += delta, l and O rescaled, S' and the -m splat re-based.
+        first: tile 0 of an item (m = 0, O and l are set to zero instead of rescaled).  The masked tail tile
+        (keys >= Tk) is handled in front of the max when s_J1-or-0 == %[tailj]."""
+        out = []
+        tid = "first" if first else "nf"
+        lab_nomask = f"L_reb_nomask_{p}_{tid}{uid}_%="
+        # XDL writes of S' (and, from the plain phase B in front, of O) must have retired before the VALU reads them
+        out.append(nop(16))
+        out.append(Ins("", "pseudo", sem=("rebase_begin", p, first, tile_rel)))
+        # ---- tail mask: key of register r of half hh = 64 t + 4 lh + (r & 3) + 8 (r >> 2) + 32 hh ----
+        if first:
+            out.append(salu(f"s_mov_b32 {S_T0}, 0", [], [S_T0]))
+            out.append(salu(f"s_cmp_eq_u32 0, %[tailj]", [], ["scc"]))
+        else:
+            out.append(salu(f"s_lshl_b32 {S_T0}, {S_J1}, 6", [S_J1], [S_T0, "scc"]))
+            out.append(salu(f"s_cmp_eq_u32 {S_J1}, %[tailj]", [S_J1], ["scc"]))
+        out.append(branch("s_cbranch_scc0", lab_nomask, ("br_nomask",)))
+        # T[2] = Tk - (64 t + 4 lh) : register (hh, r) is masked when (r & 3) + 8 (r >> 2) + 32 hh >= T[2]
+        out.append(Ins(f"v_mbcnt_lo_u32_b32 {T[2]}, -1, 0", "valu", [], [T[2]]))
+        out.append(Ins(f"v_mbcnt_hi_u32_b32 {T[2]}, -1, {T[2]}", "valu", [T[2]], [T[2]]))
+        out.append(Ins(f"v_lshrrev_b32 {T[2]}, 5, {T[2]}", "valu", [T[2]], [T[2]]))
+        out.append(Ins(f"v_lshlrev_b32 {T[2]}, 2, {T[2]}", "valu", [T[2]], [T[2]]))
+        out.append(Ins(f"v_add_u32 {T[2]}, {S_T0}, {T[2]}", "valu", [T[2], S_T0], [T[2]]))
+        out.append(Ins(f"v_sub_u32 {T[2]}, %[Tk], {T[2]}", "valu", [T[2]], [T[2]]))
+        out.append(Ins(f"v_mov_b32 {T[3]}, 0xf149f2ca", "valu", [], [T[3]]))         # -1e30f
+        for rb in range(RB):
+            for hh in range(2):
+                for r in range(16):
+                    koff = (r & 3) + 8 * (r >> 2) + 32 * hh
+                    x = S(p, rb, hh, r)
+                    out.append(Ins(f"v_cmp_ge_i32 vcc, {koff}, {T[2]}", "valu", [T[2]], ["vcc"]))
+                    out.append(Ins(f"v_cndmask_b32 {x}, {x}, {T[3]}, vcc", "valu", [x, T[3], "vcc"], [x]))
+        out.append(label(lab_nomask))
+        for rb in range(RB):
+            mx, dl, al = T[4], T[5], T[6]
+            vals = Sregs(p, rb, 0) + Sregs(p, rb, 1)
+            out.append(Ins(f"v_max3_f32 {mx}, {vals[0]}, {vals[1]}, {vals[2]}", "valu", vals[:3], [mx]))
+            for i in range(3, 31, 2):
+                out.append(Ins(f"v_max3_f32 {mx}, {mx}, {vals[i]}, {vals[i + 1]}", "valu", [mx, vals[i], vals[i + 1]], [mx]))
+            out.append(Ins(f"v_max_f32 {mx}, {mx}, {vals[31]}", "valu", [mx, vals[31]], [mx]))
+            # the row's other 32 keys sit in lane ^ 32
+            out.append(Ins(f"v_mov_b32 {T[7]}, {mx}", "valu", [mx], [T[7]]))
+            out.append(nop(2))
+            out.append(Ins(f"v_permlane32_swap_b32 {mx}, {T[7]}", "perm", [mx, T[7]], [mx, T[7]]))
+            out.append(Ins(f"v_max_f32 {mx}, {mx}, {T[7]}", "valu", [mx, T[7]], [mx]))
+            if first:
+                out.append(Ins(f"v_mov_b32 {dl}, {mx}", "valu", [mx], [dl]))
+            else:
+                out.append(Ins(f"v_max_f32 {dl}, {mx}, 0", "valu", [mx], [dl]))
+            out.append(Ins(f"v_add_f32 {MRUN[rb]}, {MRUN[rb]}, {dl}", "valu", [MRUN[rb], dl], [MRUN[rb]]))
+            if first:
+                for e in range(2):
+                    out.append(Ins(f"v_mov_b32 {LA[rb][e]}, 0", "valu", [], [LA[rb][e]]))
+                    out.append(Ins(f"v_mov_b32 {LB[rb][e]}, 0", "valu", [], [LB[rb][e]]))
+                for d in range(DB):
+                    for i in range(16):
+                        out.append(Ins(f"v_accvgpr_write_b32 {O(rb, d, i)}, 0", "valu", [], [O(rb, d, i)]))
+            else:
+                out.append(Ins(f"v_sub_f32 {al}, 0, {dl}", "valu", [dl], [al]))
+                out.append(Ins(f"v_exp_f32 {al}, {al}", "trans", [al], [al]))
+                out.append(nop(1))
+                for e in range(2):
+                    out.append(Ins(f"v_mul_f32 {LA[rb][e]}, {LA[rb][e]}, {al}", "valu", [LA[rb][e], al], [LA[rb][e]]))
+                    out.append(Ins(f"v_mul_f32 {LB[rb][e]}, {LB[rb][e]}, {al}", "valu", [LB[rb][e], al], [LB[rb][e]]))
+                for d in range(DB):
+                    for i in range(0, 16, 2):
+                        a0, a1 = O(rb, d, i), O(rb, d, i + 1)
+                        out.append(Ins(f"v_accvgpr_read_b32 {T[8]}, {a0}", "valu", [a0], [T[8]]))
+                        out.append(Ins(f"v_accvgpr_read_b32 {T[9]}, {a1}", "valu", [a1], [T[9]]))
+                        out.append(Ins(f"v_mul_f32 {T[8]}, {T[8]}, {al}", "valu", [T[8], al], [T[8]]))
+                        out.append(Ins(f"v_mul_f32 {T[9]}, {T[9]}, {al}", "valu", [T[9], al], [T[9]]))
+                        out.append(Ins(f"v_accvgpr_write_b32 {a0}, {T[8]}", "valu", [T[8]], [a0]))
+                        out.append(Ins(f"v_accvgpr_write_b32 {a1}, {T[9]}", "valu", [T[9]], [a1]))
+            for x in vals:
+                out.append(Ins(f"v_sub_f32 {x}, {x}, {dl}", "valu", [x, dl], [x]))
+            for i in range(16):
+                out.append(Ins(f"v_sub_f32 {MS(rb, i)}, 0, {MRUN[rb]}", "valu", [MRUN[rb]], [MS(rb, i)]))
+        out.append(Ins("", "pseudo", sem=("rebase_end", p, first, tile_rel)))
+        out.append(nop(4))
+        return out
+
+    def exph0_plain(self, p, tile_rel):
+        return self.softmax_items(p, 0, tile_rel, "B")
+
+    # ---- the whole statement --------------------------------------------------------------------------------------
+    def program(self):
+        R = self.R
+        L = lambda s: f"L_{s}_%="
+        out = []
+        # per-lane address tables (written to LDS once per kernel by the C++ side: koff[6], voff[3][2] as 12 dwords)
+        for i, r in enumerate(KOFF + [VOFF[d][h] for d in range(DB) for h in range(2)]):
+            out.append(Ins(f"ds_read_b32 {r}, %[tab] offset:{256 * i}", "ds", [], [r], ("ds_tab", i)))
+        out.append(salu(f"s_mov_b32 {S_J}, 0", [], [S_J], ("j0",)))
+        out.append(salu(f"s_mov_b32 {S_WOFF}, %[woff]", [], [S_WOFF]))
+        out.append(salu(f"s_mov_b64 {S_KPTR}, %[kptr]", [], [S_KPTR], ("kinit",)))
+        out.append(salu(f"s_mov_b64 {S_VPTR}, %[vptr]", [], [S_VPTR], ("vinit",)))
+        out.append(salu(f"s_sub_u32 {S_NM1}, %[n], 1", [], [S_NM1, "scc"], ("nm1",)))
+        out.append(salu(f"s_sub_u32 {S_NMR}, %[n], {R}", [], [S_NMR, "scc"], ("nmr",)))
+        out.append(salu(f"s_sub_u32 {S_NMR1}, %[n], {R - 1}", [], [S_NMR1, "scc"], ("nmr1",)))
+        for rb in range(RB):
+            out.append(Ins(f"v_mov_b32 {MRUN[rb]}, 0", "valu", [], [MRUN[rb]]))
+        out.append(lgkm(0))
+        # tile 0 (and whatever else of this item's first tiles was requested by the previous item / the kernel prologue)
+        out.append(vmw(0))
+        out.append(barrier())
+        out.append(Ins("", "pseudo", sem=("item_begin",)))
+        for ks in range(KS):
+            for hh in range(2):
+                out.append(self.ds_k(0, ks, hh, 0))
+        mf = [self.qk(0, g & 1, (g >> 1) & 1, g >> 2, 0, c_zero=(g >> 2) == 0) for g in range(4 * KS)]
+        gaps = [[] for _ in mf]
+        k1 = []
+        if self.early:                       # K'(1) fragments: re-use the registers of fragments already consumed
+            for ks in range(KS):
+                for hh in range(2):
+                    g_free = 4 * ks + 2 * hh + 1             # last MFMA reading fragment (ks, hh)
+                    tgt = min(g_free + 1, len(mf) - 1)
+                    (gaps[tgt] if g_free + 1 <= len(mf) - 1 else k1).append(self.ds_k(1 % R, ks, hh, 1))
+        out += self.weave([], mf, gaps) + k1
+        out += self.rebase(0, True, 0)
+        out += self.exph0_plain(0, 0)
+        # ---- the unrolled steps ----
+        for c in range(R):
+            out.append(label(L(f"step{c}")))
+            if c == R - 1:
+                out.append(salu(f"s_cmp_eq_u32 {S_J}, {S_NM1}", [S_J, S_NM1], ["scc"]))
+                out.append(branch("s_cbranch_scc1", L("tail"), ("br_tailstep",)))
+            out += self.boundary(c)
+            out += self.phase_a(c, L(f"slow{c}"))
+            out += self.phase_b(c)
+            out.append(salu(f"s_add_u32 {S_J}, {S_J}, 1", [S_J], [S_J, "scc"], ("jinc",)))
+            if c == R - 1:
+                out.append(branch("s_branch", L("step0"), ("br_always",)))
+        # ---- slow continuations: O += V'(j) P(j) alone, rebase for tile j + 1, its hh = 0 half, on to the next step ----
+        for c in range(R):
+            out.append(label(L(f"slow{c}")))
+            out += self.phase_b(c, plain=True)
+            out += self.rebase((c + 1) & 1, False, 1, uid=f"_c{c}")
+            out += self.exph0_plain((c + 1) & 1, 1)
+            out.append(salu(f"s_add_u32 {S_J}, {S_J}, 1", [S_J], [S_J, "scc"], ("jinc",)))
+            out.append(branch("s_branch", L(f"step{(c + 1) % R}"), ("br_always",)))
+        # ---- last step ----
+        out.append(label(L("tail")))
+        out += self.tail_step()
+        out.append(nop(16))                   # the last XDL writes of O retire before the epilogue's v_accvgpr_read
+        for rb in range(RB):
+            out.append(Ins(f"v_add_f32 {LA[rb][0]}, {LA[rb][0]}, {LA[rb][1]}", "valu", [LA[rb][0], LA[rb][1]], [LA[rb][0]]))
+            out.append(Ins(f"v_add_f32 {LB[rb][0]}, {LB[rb][0]}, {LB[rb][1]}", "valu", [LB[rb][0], LB[rb][1]], [LB[rb][0]]))
+            out.append(Ins(f"v_add_f32 %[lr{rb}], {LA[rb][0]}, {LB[rb][0]}", "valu", [LA[rb][0], LB[rb][0]], []))
+            out.append(Ins(f"v_mov_b32 %[mr{rb}], {MRUN[rb]}", "valu", [MRUN[rb]], []))
+        out.append(Ins("", "pseudo", sem=("item_end",)))
+        return insert_waits(out)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# lgkmcnt waits: LDS reads return in order; a use of a read's destination needs lgkmcnt(<= reads issued after it)
+# ------------------------------------------------------------------------------------------------------------------
+def insert_waits(prog):
+    """straight-line pass per basic block (labels / branches end a block; every block starts and ends drained so that
+    the counts are path-independent)."""
+    out = []
+    pend = []                    # outstanding reads, oldest first: sets of destination registers
+
+    def need(regs):
+        idx = -1
+        for i, d in enumerate(pend):
+            if any(r in d for r in regs):
+                idx = i
+        return idx
+
+    for ins in prog:
+        if ins.kind in ("label", "branch"):
+            if pend:
+                out.append(lgkm(0))
+                pend.clear()
+            out.append(ins)
+            continue
+        if ins.kind == "wait" and ins.sem[0] == "lgkm":
+            n = ins.sem[1]
+            del pend[:max(0, len(pend) - n)]
+            out.append(ins)
+            continue
+        touched = list(ins.rd) + list(ins.wr)
+        i = need(touched)
+        if i >= 0:
+            left = min(len(pend) - 1 - i, 15)            # (the counter has four bits)
+            out.append(lgkm(left))
+            del pend[:len(pend) - left]
+        out.append(ins)
+        if ins.kind == "ds":
+            pend.append(set(ins.wr))
+    if pend:
+        out.append(lgkm(0))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# checker: dynamic order of one wave, typed registers, counters, wait states
+# ------------------------------------------------------------------------------------------------------------------
+class CheckError(Exception):
+    pass
+
+
+class Sim:
+    def __init__(self, gen, prog, n_tiles, rebase_at=(), has_tail=False, items=2):
+        self.g, self.prog, self.n, self.rebase_at, self.has_tail, self.items = gen, prog, n_tiles, set(rebase_at), has_tail, items
+        self.labels = {ins.label: i for i, ins in enumerate(prog) if ins.kind == "label"}
+        self.count = 0
+
+    def fail(self, msg, ins=None):
+        raise CheckError(f"{msg}" + (f"   at: {ins.text}" if ins is not None else ""))
+
+    def run(self):
+        R = self.g.R
+        # persistent state across items: LDS slots, DMA queue
+        self.kslot = [None] * R
+        self.vslot = [None] * R
+        self.vmq = []            # outstanding DMA pieces of this wave: (ring, slot, piece, tile)  tile = (item, t)
+        self.got = {}            # (ring, slot) -> set of pieces landed for the pending tile
+        self.hist = []           # last instructions (for wait-state rules): list of Ins
+        stats = {"instr": 0, "mfma": 0}
+        # kernel prologue's requests of the first item: K'(0..R-1), V'(0..R-2)
+        for t in range(R):
+            for i in range(3):
+                self.vmq.append(("K", t % R, i, (0, t)))
+        for t in range(R - 1):
+            for i in range(3):
+                self.vmq.append(("V", t % R, i, (0, t)))
+        kptr, vptr = (0, R), (0, R - 1)
+        for item in range(self.items):
+            kptr, vptr = self.run_item(item, kptr, vptr, stats)
+        return stats
+
+    # -- helpers --
+    def land(self, ent):
+        ring, slot, piece, tile = ent
+        key = (ring, slot)
+        cur = self.pending_tile.get(key)
+        if cur is None or cur[0] != tile:
+            self.pending_tile[key] = (tile, set())
+        self.pending_tile[key][1].add(piece)
+
+    def run_item(self, item, kptr, vptr, stats):
+        g, R, n = self.g, self.g.R, self.n
+        regs = {}                # physical register -> (tag tuple, need_reads)
+        pend_ds = []             # outstanding LDS reads: list of register lists
+        pending_regs = set()
+        sc = {}                  # scalar state: j, j1
+        self.pending_tile = getattr(self, "pending_tile", {})
+        msver = [0, 0]
+        o_done = {(rb, d): set() for rb in range(RB) for d in range(DB)}
+        sums = {}
+        exps = {}
+        flags = {"scc": 0, "vcc": 0}
+        ksel_done = vsel_done = False
+        pc = 0
+        prog = self.prog
+        rebased_tiles = set()
+        steps = 0
+
+        def setreg(r, tag, need):
+            old = regs.get(r)
+            if old is not None and old[1] > 0:
+                self.fail(f"register {r} overwritten with {old[1]} reads of {old[0]} outstanding", cur)
+            regs[r] = [tag, need]
+
+        def usereg(r, expect_prefix, cur_ins):
+            v = regs.get(r)
+            if v is None:
+                self.fail(f"register {r} read but never written (expected {expect_prefix})", cur_ins)
+            if r in pending_regs:
+                self.fail(f"register {r} read before its LDS read was waited for", cur_ins)
+            if tuple(v[0][:len(expect_prefix)]) != tuple(expect_prefix):
+                self.fail(f"register {r} holds {v[0]}, expected {expect_prefix}", cur_ins)
+            v[1] -= 1
+            return v[0]
+
+        while True:
+            if pc >= len(prog):
+                self.fail("fell off the end of the program")
+            cur = prog[pc]
+            pc += 1
+            if cur.kind == "label":
+                continue
+            stats["instr"] += 1
+            self.check_wait_states(cur)
+            sem = cur.sem
+            k = cur.kind
+            # any access to a register with an outstanding LDS read
+            for r in list(cur.rd) + list(cur.wr):
+                if r in pending_regs and k != "ds":
+                    self.fail(f"{r} touched while its LDS read is outstanding", cur)
+            if k == "mfma":
+                stats["mfma"] += 1
+            if sem is None:
+                self.hist.append(cur)
+                continue
+            op = sem[0]
+            if op == "nop":
+                pass
+            elif op == "lgkm":
+                keep = sem[1]
+                while len(pend_ds) > keep:
+                    for r in pend_ds.pop(0):
+                        pending_regs.discard(r)
+            elif op == "vm":
+                keep = sem[1]
+                while len(self.vmq) > keep:
+                    self.land(self.vmq.pop(0))
+            elif op == "barrier":
+                # every wave has waited for its share of the same tiles: a tile whose three pieces of THIS wave have landed
+                # is complete; the slots named by the requests that follow are free (checked at the request)
+                for key, (tile, pieces) in list(self.pending_tile.items()):
+                    if len(pieces) == 3:
+                        (self.kslot if key[0] == "K" else self.vslot)[key[1]] = tile
+                        del self.pending_tile[key]
+            elif op == "item_begin":
+                for t in range(R):
+                    if self.kslot[t] != (item, t):
+                        self.fail(f"item {item}: K slot {t} holds {self.kslot[t]} at item begin")
+                for t in range(R - 1):
+                    if self.vslot[t] != (item, t):
+                        self.fail(f"item {item}: V slot {t} holds {self.vslot[t]} at item begin")
+            elif op == "j0":
+                sc["j"] = 0
+            elif op == "j1":
+                sc["j1"] = sc["j"] + 1
+            elif op == "jinc":
+                sc["j"] += 1
+                steps += 1
+            elif op in ("nm1", "nmr", "nmr1", "readkn", "ds_tab"):
+                if op == "ds_tab":
+                    pend_ds.append(list(cur.wr))
+                    pending_regs.update(cur.wr)
+            elif op == "cmp_nmr":
+                flags["scc_eq"] = sc["j"] == n - R
+            elif op == "cmp_nmr1":
+                flags["scc_eq"] = sc["j"] == n - R + 1
+            elif op == "kinit":
+                sc["kptr"] = kptr
+            elif op == "vinit":
+                sc["vptr"] = vptr
+            elif op == "ksel":
+                if flags["scc_eq"]:
+                    if sc["kptr"] != (item, n):
+                        self.fail(f"K stream switches items at position {sc['kptr']}")
+                    sc["kptr"] = (item + 1, 0)
+                    ksel_done = True
+            elif op == "vsel":
+                if flags["scc_eq"]:
+                    if sc["vptr"] != (item, n):
+                        self.fail(f"V stream switches items at position {sc['vptr']}")
+                    sc["vptr"] = (item + 1, 0)
+                    vsel_done = True
+            elif op == "kadv":
+                if sem[1] == 0:
+                    sc["kptr"] = (sc["kptr"][0], sc["kptr"][1] + 1)
+            elif op == "vadv":
+                if sem[1] == 0:
+                    sc["vptr"] = (sc["vptr"][0], sc["vptr"][1] + 1)
+            elif op == "dma":
+                ring, slot, piece = sem[1], sem[2], sem[3]
+                tile = sc["kptr"] if ring == "K" else sc["vptr"]
+                # the slot's current tile must be consumed: K'(t) by phase A of step t - 1, V'(t) by phase B of step t
+                held = (self.kslot if ring == "K" else self.vslot)[slot]
+                if held is not None and held[0] == item:
+                    last_needed = held[1] - 1 if ring == "K" else held[1]
+                    if last_needed >= sc["j"]:
+                        self.fail(f"DMA into {ring} slot {slot} at step {sc['j']} while tile {held} is still needed", cur)
+                if piece == 0:
+                    (self.kslot if ring == "K" else self.vslot)[slot] = None
+                self.vmq.append((ring, slot, piece, tile))
+            elif op == "ds_k":
+                slot, ks, hh, rel = sem[1], sem[2], sem[3], sem[4]
+                t = sc.get("j", 0) + rel
+                held = self.kslot[slot]
+                tag = ("K", t, ks, hh) if held == (item, t) else ("Kjunk", held)
+                if held != (item, t) and t < n:
+                    self.fail(f"K slot {slot} holds {held}, the read wants tile {t} of item {item}", cur)
+                for r in cur.wr:
+                    setreg(r, tag, RB if t < n else 0)
+                pend_ds.append(list(cur.wr))
+                pending_regs.update(cur.wr)
+            elif op == "ds_v":
+                slot, sl, d, half = sem[1], sem[2], sem[3], sem[4]
+                t = sc["j"]
+                if self.vslot[slot] != (item, t):
+                    self.fail(f"V slot {slot} holds {self.vslot[slot]}, the read wants tile {t} of item {item}", cur)
+                for r in cur.wr:
+                    setreg(r, ("V", t, sl, d), RB)
+                pend_ds.append(list(cur.wr))
+                pending_regs.update(cur.wr)
+            elif op == "qk":
+                p, rb, hh, ks, rel, cz = sem[1:]
+                t = sc.get("j", 0) + rel
+                for r in Kregs(ks, hh):
+                    usereg(r, ("K", t, ks, hh), cur)
+                if ks == 0:
+                    for r in Sregs(p, rb, hh):
+                        old = regs.get(r)
+                        if old is not None and old[1] > 0:
+                            self.fail(f"S' register {r} overwritten with consumers outstanding: {old}", cur)
+                        regs[r] = [("SA", t, rb, hh, 1, msver[rb]), 1]
+                else:
+                    for r in Sregs(p, rb, hh):
+                        v = usereg(r, ("SA", t, rb, hh, ks), cur)
+                        regs[r] = [("SA", t, rb, hh, ks + 1, v[5]), 1]
+                if ks == KS - 1:
+                    for i, r in enumerate(Sregs(p, rb, hh)):
+                        regs[r] = [("S", t, rb, hh, i, "raw", regs[r][0][5]), 1]
+            elif op == "exp":
+                p, rb, hh, r_, rel = sem[1:]
+                t = sc.get("j", 0) + rel
+                x = S(p, rb, hh, r_)
+                v = usereg(x, ("S", t, rb, hh, r_, "raw"), cur)
+                if v[6] != msver[rb]:
+                    self.fail(f"{x}: score relative to an old running max (version {v[6]} vs {msver[rb]})", cur)
+                regs[x] = [("S", t, rb, hh, r_, "exp"), 2]         # one add, one pack
+                exps[(t, rb)] = exps.get((t, rb), 0) + 1
+            elif op == "add":
+                p, rb, hh, r_ = sem[1:]
+                x = S(p, rb, hh, r_)
+                v = regs.get(x)
+                if v is None or v[0][5] != "exp":
+                    self.fail(f"{x} summed before its exp", cur)
+                t = v[0][1]
+                if ("sum", x, t) in sums:
+                    self.fail(f"{x} of tile {t} summed twice", cur)
+                sums[("sum", x, t)] = 1
+                sums[(t, rb)] = sums.get((t, rb), 0) + 1
+                v[1] -= 1
+            elif op == "pack":
+                p, rb, hh, tt, w = sem[1:]
+                r0 = 8 * tt + 2 * w
+                a, b = S(p, rb, hh, r0), S(p, rb, hh, r0 + 1)
+                ta = regs.get(a)
+                tb = regs.get(b)
+                if ta is None or tb is None or ta[0][5] != "exp" or tb[0][5] != "exp" or ta[0][1] != tb[0][1]:
+                    self.fail(f"pack of {a}, {b} before both exps", cur)
+                ta[1] -= 1
+                tb[1] -= 1
+                setreg(P(p, rb, hh, tt, w), ("P", ta[0][1], rb, hh, tt, w), DB)
+            elif op == "pv":
+                p, sl, d, rb = sem[1:]
+                t = sc["j"]
+                for r in Vregs(sl, d):
+                    usereg(r, ("V", t, sl, d), cur)
+                for w, r in enumerate(Pregs(p, rb, sl >> 1, sl & 1)):
+                    usereg(r, ("P", t, rb, sl >> 1, sl & 1, w), cur)
+                if (t, sl) in o_done[(rb, d)]:
+                    self.fail(f"O[{rb}][{d}] accumulates tile {t} slab {sl} twice", cur)
+                if o_done[(rb, d)] and max(o_done[(rb, d)]) > (t, sl):
+                    self.fail(f"O[{rb}][{d}] accumulates out of order", cur)
+                o_done[(rb, d)].add((t, sl))
+            elif op == "rebase_begin":
+                p, first, rel = sem[1:]
+                t = sc.get("j", 0) + rel
+                for rb in range(RB):
+                    for hh in range(2):
+                        for i, r in enumerate(Sregs(p, rb, hh)):
+                            v = regs.get(r)
+                            if v is None or tuple(v[0][:6]) != ("S", t, rb, hh, i, "raw"):
+                                self.fail(f"rebase of tile {t}: {r} holds {v}", cur)
+                # no P V of an earlier tile may be outstanding: O must hold exactly tiles < t
+                for (rb, d), done in o_done.items():
+                    if len(done) != 4 * t:
+                        self.fail(f"rebase for tile {t} with O[{rb}][{d}] at {len(done)} slabs", cur)
+                rebased_tiles.add(t)
+            elif op == "rebase_end":
+                p, first, rel = sem[1:]
+                for rb in range(RB):
+                    msver[rb] += 1
+                    for hh in range(2):
+                        for r in Sregs(p, rb, hh):
+                            regs[r][0] = regs[r][0][:6] + (msver[rb],)
+            elif op in ("br_need", "br_tail", "br_nomask", "br_tailstep", "br_always"):
+                taken = False
+                if op == "br_always":
+                    taken = True
+                elif op == "br_need":
+                    taken = (sc["j"] + 1) in self.rebase_at
+                elif op == "br_tail":
+                    taken = self.has_tail and sc["j"] + 1 == n - 1
+                elif op == "br_nomask":
+                    taken = True       # (the mask block is plain VALU; walk around it)
+                elif op == "br_tailstep":
+                    taken = sc["j"] == n - 1
+                if taken:
+                    if pend_ds:
+                        self.fail("branch taken with LDS reads outstanding (the waits assume drained blocks)", cur)
+                    pc = self.labels[cur.target]
+            elif op == "item_end":
+                break
+            else:
+                self.fail(f"unknown semantic {sem}", cur)
+            self.hist.append(cur)
+            if len(self.hist) > 64:
+                del self.hist[:32]
+        # ---- end-of-item checks ----
+        for rb in range(RB):
+            for t in range(n):
+                if exps.get((t, rb), 0) != 32 or sums.get((t, rb), 0) != 32:
+                    self.fail(f"item {item}: tile {t} row block {rb}: {exps.get((t, rb), 0)} exps, {sums.get((t, rb), 0)} sums (32 each expected)")
+            for d in range(DB):
+                if len(o_done[(rb, d)]) != 4 * n:
+                    self.fail(f"item {item}: O[{rb}][{d}] got {len(o_done[(rb, d)])} of {4 * n} slabs")
+        if pend_ds:
+            self.fail("LDS reads outstanding at the end of the item")
+        if not ksel_done or not vsel_done:
+            self.fail("the DMA streams did not pass to the next item")
+        want = {0} | {t for t in self.rebase_at if 0 < t < n} | ({n - 1} if self.has_tail else set())
+        if rebased_tiles != want:
+            self.fail(f"rebased tiles {sorted(rebased_tiles)} != {sorted(want)}")
+        return sc["kptr"], sc["vptr"]
+
+    # -- manual wait states (cdna4 ISA 4.5; LLVM GCNHazardRecognizer gfx940 rows), conservative: every instruction = 1 state --
+    def check_wait_states(self, cur):
+        if cur.kind in ("label", "pseudo"):
+            return
+        dist = 0
+        for prev in reversed(self.hist):
+            if prev.kind == "pseudo":
+                continue
+            need = 0
+            if prev.kind == "mfma" and cur.kind != "mfma":
+                if set(prev.wr) & (set(cur.rd) | set(cur.wr)):
+                    need = 12                                    # XDL (8 pass) write -> VALU / LDS read or write (ISA: 11)
+            elif prev.kind == "mfma" and cur.kind == "mfma":
+                ov = set(prev.wr) & set(cur.rd)
+                if ov and not (set(prev.wr) == set(cur.wr) and ov == set(prev.wr)):
+                    need = 12                                    # XDL write -> XDL read as A / B (or a different C)
+            elif prev.kind in ("valu", "trans", "perm") and cur.kind == "mfma":
+                if set(prev.wr) & set(cur.rd):
+                    need = 2                                     # VALU write -> XDL read
+            elif prev.kind == "trans" and cur.kind in ("valu", "perm"):
+                if set(prev.wr) & set(cur.rd):
+                    need = 1                                     # transcendental forwarding
+            elif prev.kind in ("valu", "trans") and cur.kind == "perm":
+                if set(prev.wr) & set(cur.rd):
+                    need = 2
+            elif prev.kind == "salu" and cur.kind == "dma":
+                if "m0" in prev.wr:
+                    need = 1
+            if need and dist < need:
+                raise CheckError(f"wait states: '{cur.text}' needs {need} states after '{prev.text}', has {dist}")
+            dist += prev.sem[1] if (prev.kind == "nop") else 1
+            if dist > 20:
+                break
+
+
+def stats_of(gen, prog):
+    """static listing: instructions per MFMA gap of the steady-state step copies"""
+    lines = []
+    in_step = None
+    cnt = {}
+    for ins in prog:
+        if ins.kind == "label":
+            nm = ins.label
+            in_step = nm if nm.startswith("L_step") else None
+            if in_step:
+                cnt[in_step] = {"mfma": 0, "other": 0, "valu": 0, "trans": 0, "ds": 0, "dma": 0, "salu": 0, "wait": 0}
+            continue
+        if in_step and ins.kind != "pseudo":
+            c = cnt[in_step]
+            if ins.kind == "mfma":
+                c["mfma"] += 1
+            else:
+                c["other"] += 1
+                kk = ins.kind if ins.kind in c else "salu"
+                c[kk] += 1
+    for k, c in cnt.items():
+        if c["mfma"]:
+            lines.append(f"{k}: {c['mfma']} MFMA, {c['other']} other ({c['other'] / c['mfma']:.2f} per gap): " +
+                         ", ".join(f"{n} {v}" for v, n in c.items() if v not in ("mfma", "other")))
+    return lines
+
+
+def emit(progs, path):
+    """progs: {macro name: program}.  Also the clobber list of the statement (every register the stream names literally)."""
+    with open(path, "w") as f:
+        f.write("// generated by gen_attn64.py (python3 gen_attn64.py --out gta_attn64_loop.inc) -- do not edit\n")
+        for name, prog in progs.items():
+            f.write(f"#define {name} \\\n")
+            for ins in prog:
+                if ins.kind == "pseudo":
+                    continue
+                f.write(f'    "{ins.text}\\n\\t" \\\n')
+            f.write('    ""\n')
+        regs = [f"v{i}" for i in range(32, 256)] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in range(84, 97)]
+        f.write("#define GTA_ATTN64_CLOBBERS \\\n    " + ", ".join(f'"{r}"' for r in regs) + ', "vcc", "scc", "memory"\n')
+
+
+def check_all(gen, prog, verbose=False):
+    R = gen.R
+    cases = [(R, (), False), (2 * R, (), False), (5 * R, (), False), (2 * R, (1,), False), (3 * R, (2, 5, 2 * R + 1), True),
+             (2 * R, (R - 1, R, 2 * R - 1), False), (R, (), True), (3 * R, tuple(range(1, 3 * R)), True)]
+    for n, reb, tail in cases:
+        st = Sim(gen, prog, n, reb, tail).run()
+        if verbose:
+            print(f"  ok: n_tiles {n:2d} rebase at {reb} tail {tail}: {st['instr']} instructions, {st['mfma']} MFMAs (two items)")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--ring", type=int, default=4)
+    ap.add_argument("--no-early-k", action="store_true")
+    ap.add_argument("--plain", action="store_true", help="no interleaving: every phase's fillers in front of its MFMAs")
+    ap.add_argument("--verbose", action="store_true")
+    a = ap.parse_args()
+    progs = {}
+    for name, kw in (("GTA_ATTN64_LOOP", dict(sched=not a.plain)), ("GTA_ATTN64_LOOP_PLAIN", dict(sched=False))):
+        gen = Gen(R=a.ring, kread_early=not a.no_early_k, **kw)
+        prog = gen.program()
+        check_all(gen, prog, a.verbose)
+        if a.verbose:
+            print(name)
+            print("\n".join(stats_of(gen, prog)))
+        progs[name] = prog
+    if a.out:
+        emit(progs, a.out)

@@ -43,6 +43,8 @@ extern "C" {
                                          /* chosen automatically for launches of 1..2 rounds of resident workgroups (short sequences) */
 #define GTA_FLAG_FP32_PRODUCTS (1u << 10) /* fp32 inputs: split-bf16 (hi+lo) operands, three MFMAs per product: fp32-class */
                                          /* results for the reference's mixed_prec: False configs, single-kernel plan, 3x the MFMAs */
+#define GTA_FLAG_ROWS32        (1u << 11) /* tuning: keep the 32-rows-per-wave attention kernel (gta_fwd2.hip) where the     */
+                                          /* 64-rows-per-wave one (gta_fwd64.hip: dh = 96, whole ring turns of key tiles) would run */
 #define GTA_FLAG_NO_DMA        (1u << 8) /* debug: stage K/V tiles through VGPRs, not LDS-DMA  */
 
 /* error codes */

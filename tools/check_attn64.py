@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""GPU check of the 64-rows-per-wave attention kernel (gta_fwd64.hip) against the 32-rows-per-wave one (GTA_FLAG_ROWS32)
+and the oracle, with error localisation, plus an alternating A/B timing.  Developer tool.
+usage: python tools/check_attn64.py [tiny|parity|time|all]"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import gta_amd                      # noqa: E402
+from gta_amd import native          # noqa: E402
+from tests import _hip_cases as C   # noqa: E402
+
+MS = {"triv": 0, "se3": 48, "so3": 24, "so2": 24}
+ROWS32 = 1 << 11
+
+
+def build(B, H, Nq, Pq, Nk, Pk, dtype, seed=2, qmul=None):
+    q, k, v, ex, ak, cross = C.synth_inputs(B, H, Nq, Pq, Nk, Pk, MS, 6, 2, dtype, seed=seed)
+    if qmul is not None:
+        q = q.clone()
+        q[B - 1] *= qmul              # hot logits in the last scene: the lazy softmax must rebase
+        q[0, :, 40:90] *= qmul
+    exd = {kk: vv.cuda() for kk, vv in ex.items()}
+    gta_amd.pre_compute_reps_encoder(ak, exd)
+    if cross:
+        gta_amd.pre_compute_reps_decoder(ak, exd)
+    packed = gta_amd.pack_reps(exd, MS)
+    lay = lambda t: t.to(dtype).cuda().permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
+    return (q, k, v, ex, ak, cross), (lay(q), lay(k), lay(v), packed, exd.get("gta_so3_degree", 0))
+
+
+def run(dev, flags, ws=None, want_lse=False):
+    q, k, v, packed, L = dev
+    B, H, Tq, dh = q.shape
+    out = torch.zeros(B, Tq, H, dh, device=q.device, dtype=q.dtype).permute(0, 2, 1, 3)
+    lse = torch.zeros(B, H, Tq, device=q.device, dtype=torch.float32)
+    Nq, Nk = packed["vrep_q"].shape[1], packed["vrep_k"].shape[1]
+    desc = native.make_desc(q, k, v, out, MS, L, Nq, Nk, dh ** -0.5, native.FLAG_V_TRANSFORM | flags)
+    tc = torch.tensor([0.01], device=q.device)
+    if ws is None:
+        ws = torch.empty(native.attn_fwd_workspace_bytes(desc), device=q.device, dtype=torch.uint8)
+    fn = lambda: native.attn_fwd(desc, q, k, v, packed.get("vrep_q"), packed.get("vrep_k"), packed.get("cs_q"), packed.get("cs_k"), tc,
+                                 None, out, lse, ws)
+    return fn, out, lse, ws
+
+
+def localise(a, b, tag):
+    d = (a.float() - b.float()).abs()          # [B,H,T,dh]
+    B, H, T, dh = d.shape
+    print(f"    {tag}: max {d.max().item():.3e}  (|ref| max {b.float().abs().max().item():.3e})")
+    if d.max().item() == 0:
+        return
+    per_b = d.amax(dim=(1, 2, 3)).tolist()
+    per_h = d.amax(dim=(0, 2, 3)).tolist()
+    print("      per scene  ", " ".join(f"{x:.1e}" for x in per_b))
+    print("      per head   ", " ".join(f"{x:.1e}" for x in per_h))
+    rows = d.amax(dim=(0, 1, 3))               # [T]
+    nb = (T + 31) // 32
+    blk = [rows[32 * i:32 * i + 32].max().item() for i in range(nb)]
+    print("      per 32-row block (first 16):", " ".join(f"{x:.1e}" for x in blk[:16]))
+    it = [max(blk[8 * i:8 * i + 8]) for i in range((nb + 7) // 8)]
+    print("      per 256-row item:", " ".join(f"{x:.1e}" for x in it))
+    ch = d.amax(dim=(0, 1, 2))
+    print("      per 8-channel chunk:", " ".join(f"{ch[8 * i:8 * i + 8].max().item():.1e}" for i in range(dh // 8)))
+    print("      nan/inf in a:", int((~torch.isfinite(a.float())).sum().item()))
+
+
+def parity_case(name, B, H, Nq, Pq, Nk, Pk, dtype, qmul=None, oracle=True):
+    host, dev = build(B, H, Nq, Pq, Nk, Pk, dtype, qmul=qmul)
+    os.environ.pop("GTA_ATTN64_PLAIN", None)
+    fn_new, o_new, l_new, ws = run(dev, 0)
+    fn_new()
+    torch.cuda.synchronize()
+    fn_old, o_old, l_old, _ = run(dev, ROWS32, ws=None)
+    fn_old()
+    torch.cuda.synchronize()
+    os.environ["GTA_ATTN64_PLAIN"] = "1"
+    fn_pl, o_pl, l_pl, _ = run(dev, 0)
+    fn_pl()
+    torch.cuda.synchronize()
+    os.environ.pop("GTA_ATTN64_PLAIN", None)
+    print(f"== {name}: B={B} H={H} Tq={Nq * Pq} Tk={Nk * Pk} {dtype}")
+    ok = True
+    e_no = (o_new.float() - o_old.float()).abs().max().item()
+    e_po = (o_pl.float() - o_old.float()).abs().max().item()
+    e_l = (l_new - l_old).abs().max().item()
+    refmax = o_old.float().abs().max().item()
+    print(f"    new vs rows32: {e_no:.3e}   plain vs rows32: {e_po:.3e}   lse new vs rows32: {e_l:.3e}   |out| max {refmax:.3e}")
+    tol = 3e-2 * refmax
+    if not (e_no <= tol) or not torch.isfinite(o_new.float()).all():
+        ok = False
+        localise(o_new, o_old, "new - rows32")
+    if not (e_po <= tol) or not torch.isfinite(o_pl.float()).all():
+        ok = False
+        localise(o_pl, o_old, "plain - rows32")
+    if oracle:
+        q, k, v, ex, ak, cross = host
+        ref = C.oracle_forward(q, k, v, ex, ak, cross, 0.01)
+        for nm, o in (("new", o_new), ("rows32", o_old)):
+            st = C.err_stats(o.float().cpu(), ref)
+            print(f"    {nm} vs oracle: max_abs {st['max_abs']:.3e} rel_rms {st['rel_rms']:.3e} ref_max {st['ref_max']:.3e}")
+            if st["max_abs"] > 2.5e-2 * st["ref_max"] or st["rel_rms"] > 1.2e-2:
+                ok = False
+                if nm == "new":
+                    localise(o_new.cpu(), ref, "new - oracle")
+    print("    ->", "OK" if ok else "MISMATCH")
+    return ok
+
+
+def time_ab(name, B, H, Nq, Pq, Nk, Pk):
+    _, dev = build(B, H, Nq, Pq, Nk, Pk, torch.bfloat16)
+    fn_fill, _, _, ws = run(dev, 0)
+    fn_fill()
+    fns = {"attn64": run(dev, native.FLAG_KV_READY, ws=ws)[0], "rows32": run(dev, native.FLAG_KV_READY | ROWS32, ws=ws)[0]}
+    os.environ["GTA_ATTN64_PLAIN"] = "1"
+    plain = run(dev, native.FLAG_KV_READY, ws=ws)[0]
+    res = {n: [] for n in list(fns) + ["plain"]}
+
+    def t(fn, n=10, warm=2):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+    for _ in range(7):
+        os.environ.pop("GTA_ATTN64_PLAIN", None)
+        for n, fn in fns.items():
+            res[n].append(t(fn))
+        os.environ["GTA_ATTN64_PLAIN"] = "1"
+        res["plain"].append(t(plain, n=4, warm=1))
+    os.environ.pop("GTA_ATTN64_PLAIN", None)
+    flops = 4.0 * B * H * Nq * Pq * Nk * Pk * 96
+    print(f"== time {name}: " + "   ".join(f"{n}: median {sorted(r)[3] * 1e3:7.1f} us min {min(r) * 1e3:7.1f} ({flops / sorted(r)[3] / 1e9:6.1f} TF)"
+                                            for n, r in res.items()), flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    ok = True
+    if which in ("tiny", "all"):
+        ok &= parity_case("tiny", 1, 1, 1, 256, 1, 256, torch.bfloat16)
+        ok &= parity_case("tiny-2items", 1, 2, 2, 256, 2, 256, torch.bfloat16)
+    if which in ("parity", "all"):
+        ok &= parity_case("ms-enc", 2, 8, 5, 256, 5, 256, torch.bfloat16)
+        ok &= parity_case("ms-enc-tail", 2, 8, 5, 250, 5, 250, torch.bfloat16)
+        ok &= parity_case("ms-dec", 1, 8, 5, 512, 5, 256, torch.bfloat16)
+        ok &= parity_case("ms-enc-f32", 1, 8, 5, 256, 5, 256, torch.float32)
+        ok &= parity_case("ms-enc-hot", 2, 8, 5, 256, 5, 256, torch.bfloat16, qmul=12.0)
+        ok &= parity_case("ms-enc-hot-tail", 2, 4, 5, 250, 5, 250, torch.bfloat16, qmul=12.0)
+        ok &= parity_case("ms-b32 (many items per workgroup)", 32, 8, 5, 256, 5, 256, torch.bfloat16, oracle=False)
+    if which in ("time", "all"):
+        time_ab("MS-enc B32", 32, 8, 5, 256, 5, 256)
+        time_ab("MS-dec B32", 32, 8, 5, 512, 5, 256)
+    print("ALL OK" if ok else "FAILURES")
+    sys.exit(0 if ok else 1)
