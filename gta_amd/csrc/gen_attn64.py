@@ -158,6 +158,12 @@ def barrier():
     return Ins("s_barrier", "barrier", sem=("barrier",))
 
 
+def ready(regs):
+    """scheduling hint for insert_waits: all of `regs` must have landed here (one counted wait for a group of fragments
+    instead of one in front of each MFMA that first uses one of them)"""
+    return Ins("", "ready", regs, (), None)
+
+
 def label(name):
     return Ins(f"{name}:", "label", label=name)
 
@@ -171,9 +177,13 @@ def branch(text, target, sem):
 
 
 class Gen:
-    def __init__(self, R=4, kread_early=True, sched=True, boundary_in_a=False):
+    def __init__(self, R=4, kread_early=True, sched=True, boundary_in_a=False, ablate=(), carry=False, dma_spread=False, fast_ends=False):
         assert R in (2, 4)
         self.R, self.early, self.sched, self.bina = R, kread_early and R == 4, sched, boundary_in_a
+        self.ablate = set(ablate)          # timing-only builds (wrong results): novalu, nods, nodma, nobar
+        self.carry = carry                 # K' reads stay in flight across the step labels
+        self.dma_spread = dma_spread       # boundary in phase A: one LDS-DMA piece per gap instead of three back to back
+        self.fast_ends = fast_ends         # O zeroed inside the head's MFMA gaps; the last step's softmax inside its P V MFMAs
         self.KRING, self.VRING = 0, R * IMG            # LDS byte offsets of the two rings
 
     # ---- primitive emitters --------------------------------------------------------------------------------------
@@ -289,7 +299,7 @@ class Gen:
         return out, [branch("s_cbranch_vccnz", slow_label, ("br_need",))] + tail
 
     # ---- phase A of step copy c: S'(j+1) = K'(j+1) Q'^T - m   ||  softmax of the hh = 1 half of tile j -------------
-    def phase_a(self, c, slow_label):
+    def phase_a(self, c, slow_label, with_boundary=False):
         R, p, pn = self.R, c & 1, (c + 1) & 1
         # g -> (ks, hh, rb): the two row blocks of a K' fragment back to back; the hh = 0 accumulators finish first (phase B
         # exponentiates them right away: an XDL result needs 12 states before the VALU may read it)
@@ -310,11 +320,30 @@ class Gen:
         # V' reads of slabs 0, 1: one per gap from gap 10 on (they only have to be there for phase B)
         for i, vr in enumerate(vreads):
             gaps[10 + i].append(vr)
+        d0 = 2
+        if with_boundary:
+            # the step's boundary inside the first gaps: nothing this phase reads depends on it (K'(j+1) fragments are in
+            # registers, V'(j) was complete one boundary ago); the requests overwrite slots whose readers are behind the barrier
+            assert self.early
+            bnd = self.boundary(c)
+            cut = [i for i, x in enumerate(bnd) if x.kind == "salu" and "m0" in x.wr]
+            if self.dma_spread:         # one piece per gap (a piece costs more issue time among other VMEM / LDS requests)
+                a0, b0 = cut[0], cut[1]
+                groups = [bnd[:a0], bnd[a0:a0 + 3], bnd[a0 + 3:a0 + 4], bnd[a0 + 4:b0], bnd[b0:b0 + 3], bnd[b0 + 3:b0 + 4], bnd[b0 + 4:b0 + 5],
+                          bnd[b0 + 5:]]
+            else:
+                groups = [bnd[:cut[0]], bnd[cut[0]:cut[1]], bnd[cut[1]:cut[1] + 5], bnd[cut[1] + 5:]]
+            for gi, grp in enumerate(groups):
+                gaps[gi] += grp
+            d0 = len(groups)
         # decision: needs nothing but scalars; early enough that the branch is resolved at the phase's end
         for i, di in enumerate(dec):
-            gaps[2 + i].append(di)
-        # (gap 0 stays free of softmax work: the S' accumulators of phase A's last MFMAs need 12 states before the VALU reads them)
-        self.deal(valu, gaps, range(1, len(mf)))
+            gaps[d0 + i].append(di)
+        self.deal(valu, gaps, range(0, len(mf)))
+        if self.early:
+            pre.append(ready([r for hh in range(2) for r in Kregs(0, hh) + Kregs(1, hh)]))
+            for ks in (2, 4):
+                gaps[4 * ks - 1].append(ready([r for hh in range(2) for r in Kregs(ks, hh) + Kregs(ks + 1, hh)]))
         return self.weave(pre, mf, gaps) + dec_br
 
     # ---- phase B of step copy c: O += V'(j) P(j)   ||  softmax of the hh = 0 half of tile j + 1 -------------------
@@ -335,40 +364,40 @@ class Gen:
         # K' reads of tile j + 2: one per gap in the second half
         for i, kr in enumerate(kreads):
             gaps[12 + i].append(kr)
-        # (gap 0 stays free of softmax work: the S' accumulators of phase A's last MFMAs need 12 states before the VALU reads them)
-        self.deal(valu, gaps, range(1, len(mf)))
+        # (gaps 0, 1 stay free of softmax work: the S' accumulators of phase A's last MFMAs need 12 states before the VALU reads them)
+        self.deal(valu, gaps, range(2, len(mf)))
+        pre.append(ready([r for d in range(DB) for r in Vregs(0, d)]))
+        for sl in (1, 2, 3):
+            gaps[2 * DB * sl - 1].append(ready([r for d in range(DB) for r in Vregs(sl, d)]))
         return self.weave(pre, mf, gaps)
 
-    def deal(self, valu, gaps, grange, pack_earliest=None):
-        """deal the ordered VALU list into the gaps so that every gap carries about the same issue cost; a pack whose
-        destination is still being read is held back (with everything behind it that depends on nothing it blocks)."""
-        cost = lambda x: 5 if x.kind == "trans" else 3
+    def deal(self, valu, gaps, grange):
+        """deal the ordered VALU list into the gaps so that the issue cost runs evenly along the phase: item k goes into the first
+        gap at which the cost dealt so far (with what the gaps already carry) stays within that gap's share."""
+        # issue cost of a filler in cycles, one wave per SIMD (r01 probes: v_mul 4.9, v_exp 8.9, v_cvt_pk 5.1; an LDS-DMA piece 25-60)
+        W = {"trans": 9, "valu": 5, "ds": 6, "dma": 20, "salu": 4, "wait": 4, "nop": 4, "barrier": 8, "perm": 5, "ready": 2}
+        cost = lambda x: W.get(x.kind, 4)
         grange = list(grange)
-        load = [sum(cost(x) for x in gaps[g]) for g in range(len(gaps))]
-        total = sum(cost(x) for x in valu) + sum(load[g] for g in grange)
-        target = total / len(grange)
-        held = []
+        pre = [sum(cost(x) for x in gaps[g]) for g in grange]
+        total = sum(cost(x) for x in valu) + sum(pre)
+        share = total / len(grange)
+        cum = 0.0                  # cost dealt into gaps grange[0..gi] so far
         gi = 0
-        cum = 0.0
+        cum += pre[0]
         for x in valu:
-            while gi < len(grange) - 1 and load[grange[gi]] >= target:
+            c = cost(x)
+            while gi < len(grange) - 1 and cum + c / 2 > share * (gi + 1):
                 gi += 1
-            g = grange[gi]
-            if pack_earliest and x.sem[0] == "pack" and g < pack_earliest[x.sem[4]]:
-                held.append(x)
-                continue
-            # release held packs as soon as their gap is reached
-            if held:
-                rel = [h for h in held if g >= pack_earliest[h.sem[4]]]
-                for h in rel:
-                    gaps[g].append(h)
-                    load[g] += cost(h)
-                    held.remove(h)
-            gaps[g].append(x)
-            load[g] += cost(x)
-        for h in held:
-            g = max(pack_earliest[h.sem[4]], grange[gi])
-            gaps[g].append(h)
+                cum += pre[gi]
+            gaps[grange[gi]].append(x)
+            cum += c
+
+    def steady(self, lst):
+        """timing-only ablations of the steady-state steps (development: what each part of the stream costs)"""
+        drop = lambda x: (("novalu" in self.ablate and x.sem and x.sem[0] in ("exp", "add", "pack")) or
+                          ("nods" in self.ablate and x.kind == "ds") or ("nodma" in self.ablate and x.kind == "dma") or
+                          ("nobar" in self.ablate and x.kind == "barrier") or ("nomfma" in self.ablate and x.kind == "mfma"))
+        return [x for x in lst if not drop(x)]
 
     def weave(self, pre, mf, gaps):
         """pre, then MFMA g followed by the fillers of gap g; lgkmcnt waits are inserted later (insert_waits)."""
@@ -383,12 +412,24 @@ class Gen:
         c, p = self.R - 1, (self.R - 1) & 1
         out = self.boundary(c)
         vreads = [self.ds_v(c, sl, d, h) for sl in (0, 1) for d in range(DB) for h in range(2)]
-        out += vreads + self.softmax_items(p, 1, 0, "A")
-        out += self.phase_b(c, plain=True, last=True)
-        return out
+        if not self.fast_ends:
+            out += vreads + self.softmax_items(p, 1, 0, "A")
+            out += self.phase_b(c, plain=True, last=True)
+            return out
+        # the softmax of the last tile's hh = 1 half inside the gaps of the P V MFMAs of its hh = 0 half (slabs 0, 1)
+        mf = [self.pv(c & 1, g // (2 * DB), (g % (2 * DB)) >> 1, g & 1) for g in range(4 * 2 * DB)]
+        gaps = [[] for _ in mf]
+        v23 = [self.ds_v(c, sl, d, h) for sl in (2, 3) for d in range(DB) for h in range(2)]
+        for i, vr in enumerate(v23):
+            gaps[i].append(vr)
+        self.deal(self.softmax_items(p, 1, 0, "A"), gaps, range(0, 2 * 2 * DB - 1))
+        pre = vreads + [ready([r for d in range(DB) for r in Vregs(0, d)])]
+        for sl in (1, 2, 3):
+            gaps[2 * DB * sl - 1].append(ready([r for d in range(DB) for r in Vregs(sl, d)]))
+        return out + self.weave(pre, mf, gaps)
 
     # ---- rebase (the lazy softmax's full path) on the S' buffer of parity p ----------------------------------------
-    def rebase(self, p, first, tile_rel, uid=""):
+    def rebase(self, p, first, tile_rel, uid="", zero_o=True):
         """true row max of S' (relative to m), m += delta, l and O rescaled, S' and the -m splat re-based.
         first: tile 0 of an item (m = 0, O and l are set to zero instead of rescaled).  The masked tail tile
         (keys >= Tk) is handled in front of the max when s_J1-or-0 == %[tailj]."""
@@ -443,7 +484,7 @@ class Gen:
                 for e in range(2):
                     out.append(Ins(f"v_mov_b32 {LA[rb][e]}, 0", "valu", [], [LA[rb][e]]))
                     out.append(Ins(f"v_mov_b32 {LB[rb][e]}, 0", "valu", [], [LB[rb][e]]))
-                for d in range(DB):
+                for d in range(DB if zero_o else 0):
                     for i in range(16):
                         out.append(Ins(f"v_accvgpr_write_b32 {O(rb, d, i)}, 0", "valu", [], [O(rb, d, i)]))
             else:
@@ -507,8 +548,12 @@ class Gen:
                     g_free = 4 * ks + 2 * hh + 1             # last MFMA reading fragment (ks, hh)
                     tgt = min(g_free + 1, len(mf) - 1)
                     (gaps[tgt] if g_free + 1 <= len(mf) - 1 else k1).append(self.ds_k(1 % R, ks, hh, 1))
+        if self.fast_ends:                   # O = 0 inside the gaps of the first tile's QK^T (nothing else to do there)
+            zero = [Ins(f"v_accvgpr_write_b32 {O(rb, d, i)}, 0", "valu", [], [O(rb, d, i)]) for rb in range(RB) for d in range(DB) for i in range(16)]
+            for i, z in enumerate(zero):
+                gaps[i // 4].append(z)
         out += self.weave([], mf, gaps) + k1
-        out += self.rebase(0, True, 0)
+        out += self.rebase(0, True, 0, zero_o=not self.fast_ends)
         out += self.exph0_plain(0, 0)
         # ---- the unrolled steps ----
         for c in range(R):
@@ -516,15 +561,19 @@ class Gen:
             if c == R - 1:
                 out.append(salu(f"s_cmp_eq_u32 {S_J}, {S_NM1}", [S_J, S_NM1], ["scc"]))
                 out.append(branch("s_cbranch_scc1", L("tail"), ("br_tailstep",)))
-            out += self.boundary(c)
-            out += self.phase_a(c, L(f"slow{c}"))
-            out += self.phase_b(c)
+            if self.bina:
+                out += self.steady(self.phase_a(c, L(f"slow{c}"), with_boundary=True))
+            else:
+                out += self.steady(self.boundary(c))
+                out += self.steady(self.phase_a(c, L(f"slow{c}")))
+            out += self.steady(self.phase_b(c))
             out.append(salu(f"s_add_u32 {S_J}, {S_J}, 1", [S_J], [S_J, "scc"], ("jinc",)))
             if c == R - 1:
                 out.append(branch("s_branch", L("step0"), ("br_always",)))
         # ---- slow continuations: O += V'(j) P(j) alone, rebase for tile j + 1, its hh = 0 half, on to the next step ----
         for c in range(R):
             out.append(label(L(f"slow{c}")))
+            out.append(lgkm(0))
             out += self.phase_b(c, plain=True)
             out += self.rebase((c + 1) & 1, False, 1, uid=f"_c{c}")
             out += self.exph0_plain((c + 1) & 1, 1)
@@ -532,6 +581,7 @@ class Gen:
             out.append(branch("s_branch", L(f"step{(c + 1) % R}"), ("br_always",)))
         # ---- last step ----
         out.append(label(L("tail")))
+        out.append(lgkm(0))
         out += self.tail_step()
         out.append(nop(16))                   # the last XDL writes of O retire before the epilogue's v_accvgpr_read
         for rb in range(RB):
@@ -540,17 +590,24 @@ class Gen:
             out.append(Ins(f"v_add_f32 %[lr{rb}], {LA[rb][0]}, {LB[rb][0]}", "valu", [LA[rb][0], LB[rb][0]], []))
             out.append(Ins(f"v_mov_b32 %[mr{rb}], {MRUN[rb]}", "valu", [MRUN[rb]], []))
         out.append(Ins("", "pseudo", sem=("item_end",)))
-        return insert_waits(out)
+        if not self.carry:
+            return insert_waits(out, carry=False)
+        # the state every phase B ends in (the K' reads of its last gaps): from a dry run of one phase B
+        return insert_waits(out, carry=True)
 
 
 # ------------------------------------------------------------------------------------------------------------------
 # lgkmcnt waits: LDS reads return in order; a use of a read's destination needs lgkmcnt(<= reads issued after it)
 # ------------------------------------------------------------------------------------------------------------------
-def insert_waits(prog):
-    """straight-line pass per basic block (labels / branches end a block; every block starts and ends drained so that
-    the counts are path-independent)."""
+def insert_waits(prog, carry=True, seed_state=None):
+    """lgkmcnt waits by a straight-line pass.  Conditional branches keep the outstanding reads (their taken targets -- the rare
+    paths -- start drained: the program puts an explicit lgkmcnt(0) there).  The step labels are merge points: the K' fragment
+    reads that phase B requests in its last gaps stay in flight across them (carry), which is consistent on every path because
+    each phase B ends in the same state and every other way into a step label (the item's head, the slow continuations) arrives
+    with nothing outstanding -- a counted wait then simply does not wait.  The simulation checks the dynamic order."""
     out = []
     pend = []                    # outstanding reads, oldest first: sets of destination registers
+    step_state = seed_state      # outstanding reads at a step label (the state every phase B ends in)
 
     def need(regs):
         idx = -1
@@ -559,17 +616,45 @@ def insert_waits(prog):
                 idx = i
         return idx
 
+    prev = None
     for ins in prog:
-        if ins.kind in ("label", "branch"):
-            if pend:
-                out.append(lgkm(0))
-                pend.clear()
+        if ins.kind == "label":
+            is_step = ins.label.startswith("L_step")
+            fallthrough = not (prev is not None and prev.kind == "branch" and prev.text.startswith("s_branch"))
+            if is_step and carry:
+                if fallthrough and step_state is not None and pend and [sorted(x) for x in pend] != [sorted(x) for x in step_state]:
+                    raise CheckError(f"outstanding LDS reads at {ins.label} differ between paths")
+                if fallthrough and pend:
+                    step_state = [set(x) for x in pend]
+                elif step_state is not None:
+                    pend = [set(x) for x in step_state]
+            else:
+                if pend and fallthrough:
+                    out.append(lgkm(0))
+                pend = []
             out.append(ins)
+            prev = ins
+            continue
+        if ins.kind == "branch":
+            uncond = ins.text.startswith("s_branch")
+            to_step = ins.target.startswith("L_step")
+            rare = ins.target.startswith("L_slow") or ins.target.startswith("L_tail")     # (those blocks start with lgkmcnt(0))
+            if pend and ((uncond and not (to_step and carry)) or (not uncond and not rare)):
+                out.append(lgkm(0))
+                pend = []
+            if uncond and to_step and carry and pend:
+                if step_state is None:
+                    step_state = [set(x) for x in pend]
+                elif [sorted(x) for x in pend] != [sorted(x) for x in step_state]:
+                    raise CheckError(f"outstanding LDS reads at the jump to {ins.target} differ from the step label's state")
+            out.append(ins)
+            prev = ins
             continue
         if ins.kind == "wait" and ins.sem[0] == "lgkm":
             n = ins.sem[1]
             del pend[:max(0, len(pend) - n)]
             out.append(ins)
+            prev = ins
             continue
         touched = list(ins.rd) + list(ins.wr)
         i = need(touched)
@@ -577,11 +662,16 @@ def insert_waits(prog):
             left = min(len(pend) - 1 - i, 15)            # (the counter has four bits)
             out.append(lgkm(left))
             del pend[:len(pend) - left]
+        if ins.kind == "ready":
+            continue
         out.append(ins)
         if ins.kind == "ds":
             pend.append(set(ins.wr))
+        prev = ins
     if pend:
         out.append(lgkm(0))
+    if carry and seed_state is None and step_state is not None:
+        return insert_waits(prog, carry=True, seed_state=step_state)      # second pass: the head's way into step 0 knows the state too
     return out
 
 
@@ -877,8 +967,6 @@ class Sim:
                 elif op == "br_tailstep":
                     taken = sc["j"] == n - 1
                 if taken:
-                    if pend_ds:
-                        self.fail("branch taken with LDS reads outstanding (the waits assume drained blocks)", cur)
                     pc = self.labels[cur.target]
             elif op == "item_end":
                 break
@@ -998,14 +1086,26 @@ if __name__ == "__main__":
     ap.add_argument("--no-early-k", action="store_true")
     ap.add_argument("--plain", action="store_true", help="no interleaving: every phase's fillers in front of its MFMAs")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--dev", action="store_true", help="also emit the development variants")
     a = ap.parse_args()
     progs = {}
-    for name, kw in (("GTA_ATTN64_LOOP", dict(sched=not a.plain)), ("GTA_ATTN64_LOOP_PLAIN", dict(sched=False))):
+    best = dict(boundary_in_a=True, carry=True, fast_ends=True, dma_spread=True)      # measured r03: profiles/r03/README.md
+    variants = [("GTA_ATTN64_LOOP_V0", dict(best, sched=not a.plain) if not a.plain else dict(sched=False)), ("GTA_ATTN64_LOOP_V1", dict(sched=False))]
+    if a.dev:     # development variants (gta_fwd64.hip -DGTA_ATTN64_DEV, GTA_ATTN64_VARIANT=n): schedules and timing-only ablations
+        variants += [("GTA_ATTN64_LOOP_V2", dict(carry=True)),
+                     ("GTA_ATTN64_LOOP_V3", dict(boundary_in_a=True, carry=True)),
+                     ("GTA_ATTN64_LOOP_V4", dict(boundary_in_a=True, carry=True, dma_spread=True)),
+                     ("GTA_ATTN64_LOOP_V5", dict(boundary_in_a=True, carry=True, fast_ends=True)),
+                     ("GTA_ATTN64_LOOP_V6", dict(best)),
+                     ("GTA_ATTN64_LOOP_V7", dict(best, ablate=("nomfma",))),
+                     ("GTA_ATTN64_LOOP_V8", dict(best, ablate=("novalu", "nods", "nodma", "nobar")))]
+    for name, kw in variants:
         gen = Gen(R=a.ring, kread_early=not a.no_early_k, **kw)
         prog = gen.program()
-        check_all(gen, prog, a.verbose)
+        if not kw.get("ablate"):
+            check_all(gen, prog, a.verbose)
         if a.verbose:
-            print(name)
+            print(name, kw)
             print("\n".join(stats_of(gen, prog)))
         progs[name] = prog
     if a.out:

@@ -70,18 +70,18 @@ def localise(a, b, tag):
 
 def parity_case(name, B, H, Nq, Pq, Nk, Pk, dtype, qmul=None, oracle=True):
     host, dev = build(B, H, Nq, Pq, Nk, Pk, dtype, qmul=qmul)
-    os.environ.pop("GTA_ATTN64_PLAIN", None)
+    os.environ.pop("GTA_ATTN64_VARIANT", None)
     fn_new, o_new, l_new, ws = run(dev, 0)
     fn_new()
     torch.cuda.synchronize()
     fn_old, o_old, l_old, _ = run(dev, ROWS32, ws=None)
     fn_old()
     torch.cuda.synchronize()
-    os.environ["GTA_ATTN64_PLAIN"] = "1"
+    os.environ["GTA_ATTN64_VARIANT"] = "1"
     fn_pl, o_pl, l_pl, _ = run(dev, 0)
     fn_pl()
     torch.cuda.synchronize()
-    os.environ.pop("GTA_ATTN64_PLAIN", None)
+    os.environ.pop("GTA_ATTN64_VARIANT", None)
     print(f"== {name}: B={B} H={H} Tq={Nq * Pq} Tk={Nk * Pk} {dtype}")
     ok = True
     e_no = (o_new.float() - o_old.float()).abs().max().item()
@@ -115,7 +115,7 @@ def time_ab(name, B, H, Nq, Pq, Nk, Pk):
     fn_fill, _, _, ws = run(dev, 0)
     fn_fill()
     fns = {"attn64": run(dev, native.FLAG_KV_READY, ws=ws)[0], "rows32": run(dev, native.FLAG_KV_READY | ROWS32, ws=ws)[0]}
-    os.environ["GTA_ATTN64_PLAIN"] = "1"
+    os.environ["GTA_ATTN64_VARIANT"] = "1"
     plain = run(dev, native.FLAG_KV_READY, ws=ws)[0]
     res = {n: [] for n in list(fns) + ["plain"]}
 
@@ -131,15 +131,117 @@ def time_ab(name, B, H, Nq, Pq, Nk, Pk):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n
     for _ in range(7):
-        os.environ.pop("GTA_ATTN64_PLAIN", None)
+        os.environ.pop("GTA_ATTN64_VARIANT", None)
         for n, fn in fns.items():
             res[n].append(t(fn))
-        os.environ["GTA_ATTN64_PLAIN"] = "1"
+        os.environ["GTA_ATTN64_VARIANT"] = "1"
         res["plain"].append(t(plain, n=4, warm=1))
-    os.environ.pop("GTA_ATTN64_PLAIN", None)
+    os.environ.pop("GTA_ATTN64_VARIANT", None)
     flops = 4.0 * B * H * Nq * Pq * Nk * Pk * 96
     print(f"== time {name}: " + "   ".join(f"{n}: median {sorted(r)[3] * 1e3:7.1f} us min {min(r) * 1e3:7.1f} ({flops / sorted(r)[3] / 1e9:6.1f} TF)"
                                             for n, r in res.items()), flush=True)
+
+
+def timeline(B=32):
+    """per-item s_memtime stamps (instrumented build: GTA_HIP_LIB=.../libgta_hip_ablate.so)"""
+    import ctypes
+    _, dev = build(B, 8, 5, 256, 5, 256, torch.bfloat16)
+    fn_fill, _, _, ws = run(dev, 0)
+    fn_fill()
+    for label, flags, rows in (("attn64", 0, 256), ("rows32", ROWS32, 128)):
+        fn = run(dev, native.FLAG_KV_READY | flags, ws=ws)[0]
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        nwg = B * 8 * (1280 // rows)
+        prof = torch.zeros(nwg, 8, dtype=torch.int64, device="cuda")
+        native.lib().gta_debug_set_profile_buffer(ctypes.c_void_p(prof.data_ptr()))
+        torch.cuda.synchronize()
+        fn()
+        torch.cuda.synchronize()
+        native.lib().gta_debug_set_profile_buffer(None)
+        P = prof.cpu().double()
+        if P.abs().sum() == 0:
+            print(f"== {label}: no stamps (not an instrumented build)")
+            continue
+        real = P[:, 6] - P[:, 5]
+        ok = real > 0
+        ghz = ((P[:, 4] - P[:, 0])[ok] / real[ok]).mean() * 0.1
+        span_us = (P[:, 6].max() - P[:, 5].min()) / 100.0
+        print(f"== {label}: span {span_us:.1f} us; shader clock {ghz:.3f} GHz; KERNEL CYCLES {span_us * ghz:.1f}k; items {nwg}")
+        for nm, a_, b_ in (("start -> records staged, loads landed, barrier", 0, 1), ("rho_q", 1, 2), ("tile loop", 2, 3), ("epilogue", 3, 4), ("whole item", 0, 4)):
+            d = P[:, b_] - P[:, a_]
+            print(f"   {nm:48s} mean {d.mean():9.0f}  min {d.min():9.0f}  max {d.max():9.0f}")
+        t0 = P[:, 5].min()
+        order = torch.argsort(P[:, 5])
+        nslot = 256 if rows == 256 else 512
+        for r0 in range(0, nwg, nslot):
+            Q = P[order[r0:r0 + nslot]]
+            print(f"   round {r0 // nslot}: start {((Q[:, 5] - t0) / 100).mean():7.1f} us  end {((Q[:, 6] - t0) / 100).mean():7.1f} us  "
+                  f"prologue {(Q[:, 2] - Q[:, 0]).mean():7.0f}  loop {(Q[:, 3] - Q[:, 2]).mean():7.0f}  epilogue {(Q[:, 4] - Q[:, 3]).mean():7.0f}  total {(Q[:, 4] - Q[:, 0]).mean():7.0f}")
+
+
+def variants(which, B=32):
+    """development library (tools/build_attn64_dev.sh, GTA_HIP_LIB=.../libgta_hip_dev.so): event time and per-item cycle stamps per
+    variant at 20 and 40 key tiles: the slope is the steady-state step, the intercept everything else of an item"""
+    import ctypes
+    devs = {}
+    for nk in (5, 10):
+        _, dev = build(B, 8, 5, 256, nk, 256, torch.bfloat16)
+        fn_fill, _, _, ws = run(dev, 0)
+        fn_fill()
+        torch.cuda.synchronize()
+        devs[nk] = (run(dev, native.FLAG_KV_READY, ws=ws)[0], run(dev, native.FLAG_KV_READY | ROWS32, ws=ws)[0])
+    nwg = B * 8 * 5
+
+    def t(f, n=10, warm=2):
+        for _ in range(warm):
+            f()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e3
+
+    def stamps(f, rows):
+        n = B * 8 * (1280 // rows)
+        prof = torch.zeros(n, 8, dtype=torch.int64, device="cuda")
+        native.lib().gta_debug_set_profile_buffer(ctypes.c_void_p(prof.data_ptr()))
+        torch.cuda.synchronize()
+        f()
+        torch.cuda.synchronize()
+        native.lib().gta_debug_set_profile_buffer(None)
+        P = prof.cpu().double()
+        real = P[:, 6] - P[:, 5]
+        ok = real > 0
+        ghz = ((P[:, 4] - P[:, 0])[ok] / real[ok]).mean().item() * 0.1 if ok.any() else 0.0
+        span_us = ((P[:, 6].max() - P[:, 5].min()) / 100.0).item()
+        ph = [(P[:, b_] - P[:, a_]).mean().item() for a_, b_ in ((0, 1), (1, 2), (2, 3), (3, 4), (0, 4))]
+        return ghz, span_us, ph
+    times = {v: [] for v in which}
+    times["rows32"] = []
+    for _ in range(5):
+        for v in which:
+            os.environ["GTA_ATTN64_VARIANT"] = str(v)
+            times[v].append(t(devs[5][0]))
+        times["rows32"].append(t(devs[5][1]))
+    for v in which:
+        os.environ["GTA_ATTN64_VARIANT"] = str(v)
+        ghz, span_us, ph = stamps(devs[5][0], 256)
+        _, _, ph2 = stamps(devs[10][0], 256)
+        r = sorted(times[v])
+        slope = (ph2[2] - ph[2]) / 20
+        print(f"variant {v}: {r[2]:7.1f} us median ({r[0]:.1f} min) | {span_us:6.1f} us x {ghz:.3f} GHz = {span_us * ghz:6.1f}k cyc | item: "
+              f"load {ph[0]:5.0f} rho_q {ph[1]:5.0f} loop {ph[2]:6.0f} epi {ph[3]:5.0f} total {ph[4]:6.0f} | STEP {slope:5.0f} cyc/tile, head+tail {ph[2] - 20 * slope:5.0f}", flush=True)
+    os.environ.pop("GTA_ATTN64_VARIANT", None)
+    ghz, span_us, ph = stamps(devs[5][1], 128)
+    _, _, ph2 = stamps(devs[10][1], 128)
+    r = sorted(times["rows32"])
+    print(f"rows32   : {r[2]:7.1f} us median ({r[0]:.1f} min) | {span_us:6.1f} us x {ghz:.3f} GHz = {span_us * ghz:6.1f}k cyc | item(128 rows): "
+          f"load {ph[0]:5.0f} rho_q {ph[1]:5.0f} loop {ph[2]:6.0f} epi {ph[3]:5.0f} total {ph[4]:6.0f} | STEP {(ph2[2] - ph[2]) / 20:5.0f} cyc/tile")
 
 
 if __name__ == "__main__":
@@ -159,5 +261,9 @@ if __name__ == "__main__":
     if which in ("time", "all"):
         time_ab("MS-enc B32", 32, 8, 5, 256, 5, 256)
         time_ab("MS-dec B32", 32, 8, 5, 512, 5, 256)
+    if which == "timeline":
+        timeline()
+    if which == "variants":
+        variants([int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "0,2,3,4,5,6,7,8").split(",")])
     print("ALL OK" if ok else "FAILURES")
     sys.exit(0 if ok else 1)
