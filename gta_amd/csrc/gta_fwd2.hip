@@ -35,8 +35,8 @@
 #include "gta_flash_common.h"
 
 int gta_prep_dispatch(const GtaFwdParams& p, int dhp, int esz, hipStream_t stream);                  // gta_prep.hip
-bool gta_attn64_takes(const GtaFwdParams& p, int dhp);                                              // gta_fwd64.hip
-int gta_attn64_dispatch(const GtaFwdParams& p, int esz, int layout, hipStream_t stream);
+bool gta_attn64_takes(const GtaFwdParams& p, int dhp, int layout);                                  // gta_fwd64.hip
+int gta_attn64_dispatch(const GtaFwdParams& p, int esz, hipStream_t stream);
 
 // profiling hook (not part of the product ABI, see gta_hip.h): events for the NEXT attention-kernel launch of this thread
 thread_local void* gta_dbg_fwd_ev_start = nullptr;      // (also read by gta_fwd64.hip)
@@ -793,7 +793,7 @@ static int layout_of(const GtaFwdParams& p, int dhp) {
 // Compile-time layouts exist for the shipped configs; others read the chunk table.
 template <int DHP, int ESZ>
 static int launch_flash(const GtaFwdParams& p, hipStream_t stream) {
-    if (gta_attn64_takes(p, DHP)) return gta_attn64_dispatch(p, ESZ, layout_of(p, DHP), stream);   // 64 rows per wave (gta_fwd64.hip)
+    if (gta_attn64_takes(p, DHP, layout_of(p, DHP))) return gta_attn64_dispatch(p, ESZ, stream);   // 64 rows per wave (gta_fwd64.hip)
     switch (layout_of(p, DHP)) {
         case GTA_LAYOUT_MS:  if (DHP == 96) return launch_fwd2<DHP, ESZ, (DHP == 96 ? GTA_LAYOUT_MS : GTA_LAYOUT_GENERIC)>(p, stream); break;
         case GTA_LAYOUT_CL:  if (DHP == 64) return launch_fwd2<DHP, ESZ, (DHP == 64 ? GTA_LAYOUT_CL : GTA_LAYOUT_GENERIC)>(p, stream); break;
