@@ -1079,6 +1079,14 @@ def check_all(gen, prog, verbose=False):
             print(f"  ok: n_tiles {n:2d} rebase at {reb} tail {tail}: {st['instr']} instructions, {st['mfma']} MFMAs (two items)")
 
 
+BEST = dict(boundary_in_a=True, carry=True, fast_ends=True, dma_spread=True)      # measured r03: profiles/r03/attn64_dev_log.md
+
+
+def production_variants():
+    """what gta_attn64_loop.inc holds: V0 = the shipped schedule, V1 = the same instructions un-interleaved (GTA_ATTN64_VARIANT=1)"""
+    return [("GTA_ATTN64_LOOP_V0", dict(BEST)), ("GTA_ATTN64_LOOP_V1", dict(sched=False))]
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
@@ -1089,8 +1097,8 @@ if __name__ == "__main__":
     ap.add_argument("--dev", action="store_true", help="also emit the development variants")
     a = ap.parse_args()
     progs = {}
-    best = dict(boundary_in_a=True, carry=True, fast_ends=True, dma_spread=True)      # measured r03: profiles/r03/README.md
-    variants = [("GTA_ATTN64_LOOP_V0", dict(best, sched=not a.plain) if not a.plain else dict(sched=False)), ("GTA_ATTN64_LOOP_V1", dict(sched=False))]
+    best = BEST
+    variants = production_variants() if not a.plain else [("GTA_ATTN64_LOOP_V0", dict(sched=False)), ("GTA_ATTN64_LOOP_V1", dict(sched=False))]
     if a.dev:     # development variants (gta_fwd64.hip -DGTA_ATTN64_DEV, GTA_ATTN64_VARIANT=n): schedules and timing-only ablations
         variants += [("GTA_ATTN64_LOOP_V2", dict(carry=True)),
                      ("GTA_ATTN64_LOOP_V3", dict(boundary_in_a=True, carry=True)),

@@ -403,7 +403,8 @@ def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: 
                   kv_mode: str = "auto", kv_cache: Optional[dict] = None, precise: Optional[bool] = None) -> torch.Tensor:
     """Fused GTA attention on packed reps.  q [B,H,Tq,dh], k/v [B,H,Tk,dh] -> out [B,H,Tq,dh].
 
-    kv_mode: 'prepass' = K/V rep pre-pass + lean attention kernel (two launches);
+    kv_mode: 'prepass' = K/V rep pre-pass + lean attention kernel (two launches; at dh = 96 in the MSN layout the attention kernel is
+                         the 64-rows-per-wave one of gta_fwd64.hip, 'prepass_rows32' keeps gta_fwd2.hip's);
              'fused'   = one kernel, rho_k applied inside the attention loop;
              'auto'    = 'prepass' when several query tiles share each key tile, else 'fused'.
     precise: float32 inputs only.  False (default unless ``gta.PRECISE_FP32``): operands are rounded to bf16 once, after
@@ -426,6 +427,9 @@ def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: 
         flags |= native.FLAG_NO_DMA
     if kv_mode == "prepass_pg":        # tuning knob: persistent grid instead of one workgroup per query tile
         flags |= native.FLAG_PERSIST
+        kv_mode = "prepass"
+    if kv_mode == "prepass_rows32":    # tuning knob: keep the 32-rows-per-wave attention kernel where the 64-rows one would run
+        flags |= native.FLAG_ROWS32
         kv_mode = "prepass"
     if kv_mode not in ("auto", "prepass", "fused"):
         raise ValueError(f"kv_mode {kv_mode!r}")

@@ -207,6 +207,60 @@ def test_tuned_kernels_keep_their_register_budgets():
     assert not problems, problems
 
 
+def test_attn64_loop_generator_checks_and_is_current():
+    """gen_attn64.py emits the tile loop of gta_attn64_kernel and simulates it (typed dataflow of one wave over several tile
+    counts, with forced rebase steps and a masked tail; LDS / DMA counters; the ISA's manual wait states).  The committed
+    gta_attn64_loop.inc must be what the generator emits now."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "gta_amd", "csrc", "gen_attn64.py")
+    spec = importlib.util.spec_from_file_location("gen_attn64", path)
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    progs = {}
+    for name, kw in g.production_variants():
+        gen = g.Gen(**kw)
+        prog = gen.program()
+        g.check_all(gen, prog)
+        progs[name] = prog
+        n_mfma = sum(1 for x in prog if x.kind == "mfma")
+        assert n_mfma > 48 * 4
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "loop.inc")
+        g.emit(progs, out)
+        assert open(out).read() == open(os.path.join(root, "gta_amd", "csrc", "gta_attn64_loop.inc")).read(), \
+            "gta_attn64_loop.inc is stale: python3 gta_amd/csrc/gen_attn64.py --out gta_amd/csrc/gta_attn64_loop.inc"
+    # the simulation does catch what it is there for: a P.V MFMA moved in front of its fragment's wait, a dropped exp
+    gen = g.Gen(**dict(g.production_variants()[0][1]))
+    prog = gen.program()
+    i = next(i for i, x in enumerate(prog) if x.kind == "wait" and x.sem[0] == "lgkm" and prog[i + 1].kind == "mfma")
+    bad = prog[:i] + [prog[i + 1], prog[i]] + prog[i + 2:]
+    with pytest.raises(g.CheckError):
+        g.check_all(gen, bad)
+    j = next(i for i, x in enumerate(prog) if x.sem and x.sem[0] == "exp" and any(l.label and l.label.startswith("L_step1") for l in prog[:i]))
+    with pytest.raises(g.CheckError):
+        g.check_all(gen, prog[:j] + prog[j + 1:])
+
+
+def test_attn64_kernel_leaves_the_accumulator_file_to_the_loop_statement():
+    """tools/audit_spills.py audit_attn64: hipcc must not touch accumulator registers in gta_attn64_kernel (the loop statement and
+    the fragment writes / O reads around it own them by literal number), one loop statement, 256 + 256 register split."""
+    import importlib.util
+    import os
+    import shutil
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("audit_spills", os.path.join(root, "tools", "audit_spills.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    report, problems = mod.audit_attn64()
+    assert len(report) >= 4, report
+    assert not problems, problems
+
+
 def test_srt_wrapper_state_dict_is_reference_compatible():
     """gta_amd.srt.TransformingSRT takes the reference's cfg and loads the reference's own state dict
     (fixture srt_ms_tiny: parameters of the reference TransformingSRT) with strict=True."""

@@ -98,10 +98,54 @@ def audit_others():
     return report, problems
 
 
+def audit_attn64():
+    """gta_attn64_kernel (gta_fwd64.hip): the tile loop statement owns v32-v255 and the whole accumulator file by literal
+    register number, the Q' fragments are written into a[96:143] by separate statements in front of it and O is read out of
+    a[0:95] behind it.  hipcc does not know: what it must not do is touch an accumulator register itself (it parks values
+    there under VGPR pressure) anywhere in the kernel, and the loop statement must be the single long one.  Also: no scratch
+    access behind the kernel's set-up (a reload sits behind a vmcnt(0))."""
+    text = _asm("gta_fwd64.hip", ("-fno-slp-vectorize",))
+    report, problems = [], []
+    for m in re.finditer(r"^(_ZN\w*gta_attn64_kernelILi(\d+)ELi(\d+)ELi(\d+)E\w+):", text, re.M):
+        name, key = m.group(1), (int(m.group(2)), int(m.group(3)), int(m.group(4)))
+        body = text[m.start():text.index(".Lfunc_end", m.start())]
+        meta = text[text.index(".amdhsa_kernel " + name):][:4000]
+        vgpr = int(re.search(r"\.amdhsa_next_free_vgpr\s+(\d+)", meta).group(1))
+        accum = int(re.search(r"\.amdhsa_accum_offset\s+(\d+)", meta).group(1))
+        inasm, compiler_acc, n_stmt_lines, scratch_lines, long_stmts, cur_len = False, 0, 0, [], 0, 0
+        for i, line in enumerate(body.split("\n")):
+            if "#ASMSTART" in line:
+                inasm, cur_len = True, 0
+                continue
+            if "#ASMEND" in line:
+                inasm = False
+                long_stmts += cur_len > 1000
+                continue
+            if inasm:
+                cur_len += 1
+                continue
+            compiler_acc += "v_accvgpr" in line or bool(re.search(r"\ba\[?\d+", line.split(";")[0]))
+            if "scratch_" in line:
+                scratch_lines.append(i)
+        row = {"instance": key, "vgpr": vgpr, "accum_offset": accum, "compiler_agpr_uses": compiler_acc, "scratch": len(scratch_lines),
+               "loop_statements": long_stmts}
+        report.append(row)
+        if compiler_acc:
+            problems.append(f"gta_attn64_kernel<{key}>: hipcc touches accumulator registers itself ({compiler_acc} instructions)")
+        if long_stmts != 1:
+            problems.append(f"gta_attn64_kernel<{key}>: {long_stmts} loop statements (expected one)")
+        if vgpr != 512 or accum != 256:
+            problems.append(f"gta_attn64_kernel<{key}>: register file split {accum} / {vgpr} (expected 256 / 512)")
+        if len(scratch_lines) > 12:
+            problems.append(f"gta_attn64_kernel<{key}>: {len(scratch_lines)} scratch accesses")
+    return report, problems
+
+
 if __name__ == "__main__":
     rep, prob = audit()
     rep2, prob2 = audit_others()
-    for r in rep + rep2:
+    rep3, prob3 = audit_attn64()
+    for r in rep + rep2 + rep3:
         print(r)
-    print("problems:", (prob + prob2) or "none")
-    sys.exit(1 if prob or prob2 else 0)
+    print("problems:", (prob + prob2 + prob3) or "none")
+    sys.exit(1 if prob or prob2 or prob3 else 0)
