@@ -34,6 +34,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
+PEAK_CLOCK_MHZ = 2400.0         # the shader clock the 2.5 PFLOP/s figure assumes (MI355X_MICROARCH.md: max clock)
+MFMA_FLOP_PER_CYCLE = 1024.0 * 4 * 256   # v_mfma_f32_32x32x16_bf16: 32768 flop / 32 cycles per SIMD, 4 SIMDs x 256 CUs
 
 WORKLOADS = {
     # name: (H, Nq, Pq, Nk, Pk, f_dims, so2, so3, default per-GPU batch)
@@ -98,16 +100,30 @@ def parity_check(out, masters, ak, cross, scenes):
             "rel_rms": float(((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()))}
 
 
-def latest_traffic(workload, B, dtype):
-    """HBM bytes per launch of the dominant kernel from the newest committed PMC measurement of this workload."""
+def latest_traffic(workload, B, dtype, kernel):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC measurement of this workload AND this kernel
+    (a counter pass cannot share a run with the timed region; a measurement of another kernel is not quoted)."""
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")), reverse=True):
         try:
             t = json.load(open(f))
-            if (t["workload"], t["batch"], t["dtype"]) == (workload, B, dtype):
-                return t["bytes_per_launch"], os.path.relpath(f, ROOT) + " (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)"
+            if (t["workload"], t["batch"], t["dtype"]) == (workload, B, dtype) and t.get("kernel", "gta_fwd2_kernel") == kernel:
+                return t["bytes_per_launch"], t.get("mfma_busy_sq"), os.path.relpath(f, ROOT) + " (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)"
         except (OSError, KeyError, ValueError):
             pass
-    return None, None
+    return None, None, None
+
+
+def kernel_clock(prof):
+    """[n_items, 8] stamps of one launch (include/gta_hip.h: gta_debug_set_profile_buffer) -> (shader cycles of the launch, granted
+    shader clock in MHz): span of the 100-MHz stamps x the clock the items' own cycle counts give."""
+    P = prof.cpu().double()
+    real = P[:, 6] - P[:, 5]
+    ok = real > 0
+    if not bool(ok.any()):
+        return None, None
+    mhz = float(((P[:, 4] - P[:, 0])[ok] / real[ok]).mean()) * 100.0
+    span_us = float(P[ok][:, 6].max() - P[ok][:, 5].min()) / 100.0
+    return span_us * mhz, mhz
 
 
 def dry_run(args):
@@ -275,10 +291,14 @@ def main():
     reps_q = plan.RepPlan(B, Nq, Pq, so3_deg, so2, device=device) if (reps_k is not None and cross) else None
     fwd = plan.ForwardPlan(q, k, v, f_dims, so3_degree=so3_deg, Nq=Nq if need_view else 1, Nk=Nk if need_view else 1,
                            flags=native.FLAG_FUSED_KV if fused else 0)
+    n_it, rows_it = ctypes.c_int32(0), ctypes.c_int32(0)
+    kname = (L.gta_debug_attention_kernel(ctypes.byref(fwd.desc), ctypes.byref(n_it), ctypes.byref(rows_it)) or b"").decode()
     n_samp = args.steps if args.kernel_samples <= 0 else min(args.kernel_samples, args.steps)
     stride = max(1, args.steps // n_samp)
     sampled = {i: len(range(stride // 2, i, stride)) for i in range(stride // 2, args.steps, stride)}   # step -> event slot
     ev = [(L.gta_debug_event_create(), L.gta_debug_event_create()) for _ in sampled]
+    # the sampled launches also leave per-item start / end stamps (shader cycles + 100-MHz clock): kernel cycles and granted clock
+    profs = [torch.zeros(max(n_it.value, 1), 8, dtype=torch.int64, device=device) for _ in sampled]
 
     def build_reps():
         if reps_k is not None:
@@ -298,6 +318,11 @@ def main():
         if i in sampled and not fused:
             e = ev[sampled[i]]
             L.gta_debug_time_next_attention_kernel(ctypes.c_void_p(e[0]), ctypes.c_void_p(e[1]))
+            L.gta_debug_set_profile_buffer(ctypes.c_void_p(profs[sampled[i]].data_ptr()))
+            try:
+                return fwd(q, k, v, vq, vk, cq, ck, tc)
+            finally:
+                L.gta_debug_set_profile_buffer(None)
         return fwd(q, k, v, vq, vk, cq, ck, tc)
 
     for _ in range(args.warmup):
@@ -325,11 +350,16 @@ def main():
         dist.all_gather(g, torch.tensor([mine / args.steps * 1e3], device=device, dtype=torch.float64))
         per_rank = [float(u.item()) for u in g]
 
+    kern_cycles = sclk_mhz = None
     if fused:
         kern_ms = None
     else:
         ks = [L.gta_debug_event_elapsed_ms(ctypes.c_void_p(a), ctypes.c_void_p(b)) for a, b in ev]
         kern_ms = sum(ks) / len(ks)                         # attention kernel only (events of its own dispatch)
+        cyc = [kernel_clock(p_) for p_ in profs]
+        cyc = [c for c in cyc if c[0]]
+        kern_cycles = sum(c[0] for c in cyc) / len(cyc) if cyc else None
+        sclk_mhz = sum(c[1] for c in cyc) / len(cyc) if cyc else None
     for a, b in ev:
         L.gta_debug_event_destroy(ctypes.c_void_p(a)); L.gta_debug_event_destroy(ctypes.c_void_p(b))
 
@@ -420,7 +450,7 @@ def main():
     flops = 4.0 * B * H * Tq * Tk * dh                               # QK^T + PV, 2 flop/MAC
     alg_bytes = (2 * Tq + 2 * Tk) * H * dh * q.element_size() * B    # read Q,K,V once, write O once
     achieved = flops / (kern_ms * 1e-3) / 1e12 if kern_ms else None
-    traffic, traffic_src = latest_traffic(args.workload, B, args.dtype) if not fused else (None, None)
+    traffic, mfma_busy_sq, traffic_src = latest_traffic(args.workload, B, args.dtype, kname) if not fused else (None, None, None)
 
     if rank == 0:
         n = max(world, 1)
@@ -438,12 +468,20 @@ def main():
             "host_ms_per_step": t_host / args.steps * 1e3, "per_rank_ms_per_step": per_rank,
         }
         if achieved is not None:
-            line["roofline"] = {"bound": "mfma", "kernel": "gta_fwd2_kernel", "achieved": achieved,
+            line["roofline"] = {"bound": "mfma", "kernel": kname, "rows_per_item": rows_it.value, "achieved": achieved,
                                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
                                 "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                                 "kernel_ms": kern_ms, "kernel_samples": len(ev), "algorithmic_flops": flops, "algorithmic_bytes": alg_bytes,
                                 "hbm_frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                                "step_frac": flops / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS}
+                                "step_frac": flops / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                                # box-independent view of the same launches (per-item s_memtime / s_memrealtime stamps): a move in
+                                # kernel_cycles is the code, a move in sclk_mhz is the clock this box granted
+                                "kernel_cycles": kern_cycles, "sclk_mhz": sclk_mhz,
+                                "mfma_busy": (flops / MFMA_FLOP_PER_CYCLE / kern_cycles) if kern_cycles else None,
+                                "mfma_busy_note": "matrix-pipe cycles the launch's MFMAs need / kernel_cycles (derived); "
+                                                  "mfma_busy_sq = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CYCLES-per-SIMD) of the committed counter pass",
+                                "mfma_busy_sq": mfma_busy_sq,
+                                "frac_at_granted_clock": (achieved / (PEAK_BF16_TFLOPS * sclk_mhz / PEAK_CLOCK_MHZ)) if sclk_mhz else None}
         if parity is not None:
             line["parity"] = parity
         if fwd_bwd_ms is not None:

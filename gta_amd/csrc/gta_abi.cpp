@@ -17,6 +17,7 @@
 int gta_fwd_lds_bytes(int dhp, int esz);
 int gta_fwd_dispatch(const GtaFwdParams& p, int dhp, int esz, bool dma, int n_wg, hipStream_t stream);
 long gta_fwd2_workspace_bytes(int B, int H, int Tk, int dhp);
+int gta_fwd2_rows_per_item(const GtaFwdParams& p, int dhp);                   // 256: gta_attn64_kernel, 128: gta_fwd2_kernel
 long gta_fwd2_image_bytes(int B, int H, int Tk, int dhp);
 int gta_fwd2_lds_bytes(int dhp, int nq);
 int gta_fwd2_dispatch(GtaFwdParams& p, int dhp, int esz, bool run_prep, bool run_flash, hipStream_t stream);
@@ -140,6 +141,20 @@ extern "C" int gta_attn_fwd_launch_info(const GtaAttnDesc* desc, int32_t* lds_by
     return GTA_OK;
 }
 
+// which attention kernel gta_attn_fwd launches for desc when given a workspace (diagnostic; the names are the kernels' own)
+extern "C" const char* gta_debug_attention_kernel(const GtaAttnDesc* d, int32_t* n_items, int32_t* rows_per_item) {
+    if (gta_attn_fwd_supported(d)) return "";
+    GtaFwdParams p;
+    memset(&p, 0, sizeof p);
+    if (build_ctab(d, p.ctab)) return "";
+    p.Tq = d->Tq; p.Tk = d->Tk; p.dh = d->dh; p.flags = d->flags; p.kn = (float*)1;
+    const bool two_stage = !(d->flags & (GTA_FLAG_FUSED_KV | GTA_FLAG_FP32_PRODUCTS | GTA_FLAG_PRETRANSFORMED));
+    const int rows = !two_stage ? 128 : gta_fwd2_rows_per_item(p, padded_dh(d->dh));
+    if (n_items) *n_items = d->B * d->H * ((d->Tq + rows - 1) / rows);
+    if (rows_per_item) *rows_per_item = rows;
+    return !two_stage ? "gta_fwd_kernel" : rows == 256 ? "gta_attn64_kernel" : "gta_fwd2_kernel";
+}
+
 extern "C" int gta_attn_fwd(const GtaAttnDesc* d, const void* q, const void* k, const void* v,
                             const float* vrep_q, const float* vrep_k, const float* cs_q, const float* cs_k,
                             const float* trans_coeff, const float* tau, void* out, float* lse,
@@ -173,8 +188,8 @@ extern "C" int gta_attn_fwd(const GtaAttnDesc* d, const void* q, const void* k, 
     p.flags = d->flags; p.scale = d->scale;
 #ifdef GTA_ABLATE
     { const char* e = getenv("GTA_DBG"); p.dbg = e ? (uint32_t)atoi(e) : 0u; }
-    p.prof = g_prof;
 #endif
+    p.prof = g_prof;        // (start / end stamps of every work item when a buffer is set: gta_debug_set_profile_buffer)
     const long n_wg = (long)d->B * d->H * p.n_qtiles;
     if (n_wg > 0x7fffffffL) return fail(GTA_E_UNSUPPORTED, "grid too large");
     if ((d->flags & GTA_FLAG_FP32_PRODUCTS) && d->dtype != GTA_DTYPE_F32)

@@ -211,14 +211,15 @@ __global__ __launch_bounds__(256, (DHP <= 64 ? 3 : GTA_OCC96)) void gta_fwd2_ker
     const int ch_real = pp->dh >> 3;
     char* ring = smem + S::OFF_RING;
 
-#ifdef GTA_ABLATE
-    // per work item: [0] start, [1] Q loads + records landed, [2] rho_q done, [3] tile loop done, [4] epilogue done
-    // (s_memtime), [5]/[6] s_memrealtime (100 MHz) at start / end, [7] next item's loads issued
-#define GTA_STAMP(V_, k) do { if (pp->prof && tid == 0) pp->prof[(long)(V_) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+    // per work item, when a profile buffer is set (gta_debug_set_profile_buffer): [0] start, [4] end (s_memtime: shader cycles),
+    // [5] / [6] start / end by s_memrealtime (100 MHz) -- what bench.py turns into kernel cycles and the granted clock.
+    // Instrumented builds add [1] Q loads + records landed, [2] rho_q done, [3] tile loop done, [7] next item's loads issued.
+#define GTA_STAMP_ON(V_, k) do { if (pp->prof && tid == 0) pp->prof[(long)(V_) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define GTA_STAMPR(V_, k) do { if (pp->prof && tid == 0) pp->prof[(long)(V_) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#ifdef GTA_ABLATE
+#define GTA_STAMP(V_, k) GTA_STAMP_ON(V_, k)
 #else
-#define GTA_STAMP(V_, k) do { } while (0)
-#define GTA_STAMPR(V_, k) do { } while (0)
+#define GTA_STAMP(V_, k) do { if ((k) == 0 || (k) == 4) GTA_STAMP_ON(V_, k); } while (0)
 #endif
 
     const bool has_tail = (pp->Tk & (BN - 1)) != 0;
@@ -697,6 +698,7 @@ __global__ __launch_bounds__(256, (DHP <= 64 ? 3 : GTA_OCC96)) void gta_fwd2_ker
     par ^= 1;
     }
 #undef GTA_STAMP
+#undef GTA_STAMP_ON
 #undef GTA_STAMPR
 #undef GTA_DL
 #undef GTA_DESC
@@ -789,6 +791,8 @@ static int layout_of(const GtaFwdParams& p, int dhp) {
     }
     return GTA_LAYOUT_GENERIC;
 }
+
+int gta_fwd2_rows_per_item(const GtaFwdParams& p, int dhp) { return gta_attn64_takes(p, dhp, layout_of(p, dhp)) ? 256 : 128; }
 
 // Compile-time layouts exist for the shipped configs; others read the chunk table.
 template <int DHP, int ESZ>

@@ -39,7 +39,7 @@ ABI_SYMBOLS = (
     "gta_rep_apply", "gta_attn_fwd_plain",
     "gta_strerror", "gta_abi_version", "gta_sizeof_attn_desc",
     "gta_debug_time_next_attention_kernel", "gta_debug_event_create", "gta_debug_event_destroy", "gta_debug_event_elapsed_ms",
-    "gta_debug_set_profile_buffer",
+    "gta_debug_set_profile_buffer", "gta_debug_attention_kernel",
 )
 
 
@@ -108,6 +108,8 @@ def lib():
         L.gta_debug_event_elapsed_ms.restype = c_float
         L.gta_debug_set_profile_buffer.argtypes = [c_void_p]
         L.gta_debug_set_profile_buffer.restype = None
+        L.gta_debug_attention_kernel.argtypes = [ctypes.POINTER(GtaAttnDesc), ctypes.POINTER(c_int32), ctypes.POINTER(c_int32)]
+        L.gta_debug_attention_kernel.restype = ctypes.c_char_p
         _lib = L
     return _lib
 

@@ -207,12 +207,17 @@ int gta_attn_fwd_launch_info(const GtaAttnDesc* desc, int32_t* lds_bytes, int32_
  *     bracketed by the two events through the dispatch packet itself (hipExtLaunchKernelGGL), i.e. without the marker
  *     packets of hipEventRecord that push neighbouring kernels apart.  One-shot.
  *   gta_debug_event_*: thin wrappers so a ctypes caller needs no second HIP binding.
- *   gta_debug_set_profile_buffer: per-work-item s_memtime stamps (only -DGTA_ABLATE builds write them). */
+ *   gta_debug_set_profile_buffer: device buffer [n_items][8] of uint64 (or NULL): the two-stage plan's attention kernel writes, per
+ *       work item, [0] / [4] = s_memtime at its start / end (shader cycles) and [5] / [6] = s_memrealtime (100 MHz) -- kernel cycles
+ *       and the granted shader clock of a launch follow from them; -DGTA_ABLATE builds add per-phase stamps.
+ *   gta_debug_attention_kernel: name of the attention kernel a workspace call of gta_attn_fwd launches for desc, its number of
+ *       work items and query rows per item ("" if desc is not supported). */
 void gta_debug_time_next_attention_kernel(void* start_event, void* stop_event);
 void* gta_debug_event_create(void);
 void gta_debug_event_destroy(void* event);
 float gta_debug_event_elapsed_ms(void* start_event, void* stop_event);
 void gta_debug_set_profile_buffer(void* device_buffer);
+const char* gta_debug_attention_kernel(const GtaAttnDesc* desc, int32_t* n_items, int32_t* rows_per_item);
 
 const char* gta_strerror(int code);
 int gta_abi_version(void);
