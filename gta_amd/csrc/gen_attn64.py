@@ -18,10 +18,11 @@ What this file guarantees on the CPU (run by `make` and by tests/test_host_logic
 Numerical parity is the GPU tests' job (tests/test_gpu_forward.py runs every fixture through this kernel).
 
 Register map (dh = 96: KS = 6 k-steps, DB = 3 channel blocks, RB = 2 row blocks of 32 query rows per wave)
-  a[  0: 95]  O^T[rb][d]        16 each            v[ 64: 95]  S'[rb], key half 0           16 each
-  a[ 96:143]  Q' fragments      [rb][ks] 4 each    v[ 96:159]  S'[p][rb], key half 1        16 each (p = step parity)
-  a[144:191]  K' fragments      [ks][hh] 4 each    v[160:191]  P[p][rb][t], key half 0      4 each (bf16 pairs)
-  a[192:239]  V'^T fragments    [slab][d] 4 each   v[192:207]  P[rb][t], key half 1         4 each
+  a[ 28:123]  O^T[rb][d]        16 each            v[ 64: 95]  S'[rb], key half 0           16 each
+  a[124:171]  Q' fragments      [rb][ks] 4 each    v[ 96:159]  S'[p][rb], key half 1        16 each (p = step parity)
+  a[172:219]  K' fragments      [ks][hh] 4 each    v[160:191]  P[p][rb][t], key half 0      4 each (bf16 pairs)
+  a[220:255]  V'^T fragments    [slab % 3][d] 4 each   v[192:207]  P[rb][t], key half 1     4 each
+  a[  0: 27]  hipcc's (it parks values in the lowest accumulator registers under pressure)
                                                    v[208:239]  -m splat[rb]  16 each (C operand of a tile's first MFMAs)
                                                    v[ 32: 63]  addresses, row sums, m, temporaries
   v[0:31] and the SGPRs not named here belong to the compiler (operands of the statement).
@@ -80,40 +81,44 @@ def MSregs(rb):
     return [f"v{208 + 16 * rb + i}" for i in range(16)]
 
 
+AB = 28        # a[0:27] are left to hipcc: under VGPR pressure it parks values in the lowest accumulator registers (audit_spills.py)
+NVS = 3        # V'^T fragment buffers: slab 3 of a tile takes slab 0's registers (its reads sit behind slab 0's MFMAs)
+
+
 def O(rb, d, i=None):
-    b = 16 * (rb * DB + d)
+    b = AB + 16 * (rb * DB + d)
     return f"a[{b}:{b + 15}]" if i is None else f"a{b + i}"
 
 
 def Oregs(rb, d):
-    return [f"a{16 * (rb * DB + d) + i}" for i in range(16)]
+    return [f"a{AB + 16 * (rb * DB + d) + i}" for i in range(16)]
 
 
 def Q(rb, ks):
-    b = 96 + 4 * (rb * KS + ks)
+    b = AB + 96 + 4 * (rb * KS + ks)
     return f"a[{b}:{b + 3}]"
 
 
 def Qregs(rb, ks):
-    return [f"a{96 + 4 * (rb * KS + ks) + i}" for i in range(4)]
+    return [f"a{AB + 96 + 4 * (rb * KS + ks) + i}" for i in range(4)]
 
 
 def K(ks, hh):
-    b = 144 + 4 * (ks * 2 + hh)
+    b = AB + 144 + 4 * (ks * 2 + hh)
     return f"a[{b}:{b + 3}]"
 
 
 def Kregs(ks, hh):
-    return [f"a{144 + 4 * (ks * 2 + hh) + i}" for i in range(4)]
+    return [f"a{AB + 144 + 4 * (ks * 2 + hh) + i}" for i in range(4)]
 
 
 def V(sl, d, half=None):
-    b = 192 + 4 * (sl * DB + d)
+    b = AB + 192 + 4 * ((sl % NVS) * DB + d)
     return f"a[{b}:{b + 3}]" if half is None else f"a[{b + 2 * half}:{b + 2 * half + 1}]"
 
 
 def Vregs(sl, d, half=None):
-    b = 192 + 4 * (sl * DB + d)
+    b = AB + 192 + 4 * ((sl % NVS) * DB + d)
     return [f"a{b + i}" for i in range(4)] if half is None else [f"a{b + 2 * half}", f"a{b + 2 * half + 1}"]
 
 
@@ -355,7 +360,8 @@ class Gen:
         valu = [] if plain else self.softmax_items(pn, 0, 1, "B")
         pre, gaps = [], [[] for _ in mf]
         if not self.sched or plain:
-            pre = vreads + kreads + [x for x in valu if x.sem[0] != "pack"]
+            pre = vreads[:2 * DB] + kreads + [x for x in valu if x.sem[0] != "pack"]
+            gaps[2 * DB - 1] += vreads[2 * DB:]           # slab 3 takes slab 0's registers: behind slab 0's MFMAs
             packs = [x for x in valu if x.sem[0] == "pack"]
             return self.weave(pre, mf, gaps) + packs
         # V' reads of slabs 2 (needed by MFMA 12) and 3 (MFMA 18): one per gap from gap 0
@@ -1065,7 +1071,7 @@ def emit(progs, path):
                     continue
                 f.write(f'    "{ins.text}\\n\\t" \\\n')
             f.write('    ""\n')
-        regs = [f"v{i}" for i in range(32, 256)] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in range(84, 97)]
+        regs = [f"v{i}" for i in range(32, 256)] + [f"a{i}" for i in range(AB, 256)] + [f"s{i}" for i in range(84, 97)]
         f.write("#define GTA_ATTN64_CLOBBERS \\\n    " + ", ".join(f'"{r}"' for r in regs) + ', "vcc", "scc", "memory"\n')
 
 

@@ -16,7 +16,8 @@
 
 int gta_fwd_lds_bytes(int dhp, int esz);
 int gta_fwd_dispatch(const GtaFwdParams& p, int dhp, int esz, bool dma, int n_wg, hipStream_t stream);
-long gta_fwd2_workspace_bytes(int B, int H, int Tk, int dhp);
+long gta_fwd2_workspace_bytes(int B, int H, int Tk, int dhp, int Nq);
+long gta_fwd2_qtiles_offset(int B, int H, int Tk, int dhp);
 int gta_fwd2_rows_per_item(const GtaFwdParams& p, int dhp);                   // 256: gta_attn64_kernel, 128: gta_fwd2_kernel
 long gta_fwd2_image_bytes(int B, int H, int Tk, int dhp);
 int gta_fwd2_lds_bytes(int dhp, int nq);
@@ -127,7 +128,7 @@ extern "C" int gta_attn_fwd_supported(const GtaAttnDesc* desc) {
 
 extern "C" int64_t gta_attn_fwd_workspace_bytes(const GtaAttnDesc* desc) {
     if (gta_attn_fwd_supported(desc)) return 0;
-    return gta_fwd2_workspace_bytes(desc->B, desc->H, desc->Tk, padded_dh(desc->dh));
+    return gta_fwd2_workspace_bytes(desc->B, desc->H, desc->Tk, padded_dh(desc->dh), desc->Nq);
 }
 
 extern "C" int gta_attn_fwd_launch_info(const GtaAttnDesc* desc, int32_t* lds_bytes, int32_t* n_workgroups,
@@ -195,11 +196,12 @@ extern "C" int gta_attn_fwd(const GtaAttnDesc* d, const void* q, const void* k, 
     if ((d->flags & GTA_FLAG_FP32_PRODUCTS) && d->dtype != GTA_DTYPE_F32)
         return fail(GTA_E_BADARG, "GTA_FLAG_FP32_PRODUCTS is for fp32 inputs (bf16 inputs ask for bf16 arithmetic)");
     if (workspace && !(d->flags & (GTA_FLAG_FUSED_KV | GTA_FLAG_FP32_PRODUCTS)) && !pre) {
-        if (workspace_bytes < gta_fwd2_workspace_bytes(d->B, d->H, d->Tk, padded_dh(d->dh)))
+        if (workspace_bytes < gta_fwd2_workspace_bytes(d->B, d->H, d->Tk, padded_dh(d->dh), d->Nq))
             return fail(GTA_E_BADARG, "workspace smaller than gta_attn_fwd_workspace_bytes()");
         if (d->H > 65535 || d->B > 65535) return fail(GTA_E_UNSUPPORTED, "B or H above 65535");
         p.kp = workspace;
         p.kn = (float*)((char*)workspace + ((gta_fwd2_image_bytes(d->B, d->H, d->Tk, padded_dh(d->dh)) + 255) & ~255L));
+        if (padded_dh(d->dh) == 96 && need_view) p.qtiles = (char*)workspace + gta_fwd2_qtiles_offset(d->B, d->H, d->Tk, 96);
         rc = gta_fwd2_dispatch(p, padded_dh(d->dh), esz, !(d->flags & GTA_FLAG_KV_READY), !(d->flags & GTA_FLAG_PREP_ONLY),
                                (hipStream_t)stream);
         if (rc) return fail(rc, rc == GTA_E_LAUNCH ? hipGetErrorString(hipGetLastError()) : "no kernel instance");

@@ -193,6 +193,79 @@ GTA_DEV void stage_krec(float* krec, const float* vrep_k, int b, int Nk, float t
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// rho_q / rho_q^-1 on the matrix cores (gta_fwd64.hip, MSN layout dh = 96)
+// ------------------------------------------------------------------------------------------------
+// rho_q (gta.py:165,193) and rho_q^-1 (gta.py:255-271) are block-diagonal per-VIEW matrices on the se3 / so3 channels, so for
+// the 32 query rows of one MFMA block -- all of one view -- they are two small GEMMs: Q'^T = Aq Q^T and O^T = Cq O~^T, 32 x 32
+// output blocks that only see their own 32 input channels (no rep block straddles a multiple of 32).  The q-side matrices are
+// expanded ONCE per (scene, view) into bf16 A-operand tiles [32 rows][16 k] (hi + lo parts: the products are exact to 2^-17),
+// written by extra workgroups of the K/V pre-pass launch; the attention kernel's prologue / epilogue are then a few MFMAs and
+// the per-token so2 rotations.  Tile t of a view:  t = 12*type + 6*part + 2*d + kk   type 0: Aq (forward, carries
+// scale*log2e/tau), 1: Cq (inverse);  part 0: hi, 1: lo;  d: 32-channel output block;  kk: 16-channel k-step of that block.
+// Rows and k-slots are PERMUTED so that no data moves between lanes around the MFMAs:
+//   Aq tile: k-slot k  <-> input channel 32d + 16kk + k (the raw-Q B fragment as loaded);  row rho <-> output channel
+//            gta_qt_chan_q(d, rho): a lane's 16 result registers are its two B fragments (chunks 4d + lh and 4d + 2 + lh) of Q'.
+//   Cq tile: k-slot k  <-> input channel gta_qt_chan_o_in(d, kk, k): the O~ accumulator registers of a lane, packed pairwise, ARE
+//            the B fragments;  row rho <-> output channel gta_qt_chan_o_out(d, rho): a lane ends with 16 contiguous channels.
+// A tile is stored in fragment order: element (rho, k) at byte ((k >> 3) * 32 + rho) * 16 + (k & 7) * 2 (lane l of a wave reads
+// 16 bytes at l * 16).
+#define GTA_QT_TILES 24
+#define GTA_QT_BYTES 1024
+__host__ __device__ constexpr int gta_qt_chan_q(int d, int rho) {
+    const int lh = (rho >> 2) & 1, j = rho >> 3, i = rho & 3;
+    return j < 2 ? 32 * d + 8 * lh + 4 * j + i : 32 * d + 16 + 8 * lh + 4 * (j - 2) + i;
+}
+__host__ __device__ constexpr int gta_qt_chan_o_in(int d, int kk, int k) {
+    const int lh = k >> 3, i = k & 7;
+    return 32 * d + 16 * kk + (i & 3) + 8 * (i >> 2) + 4 * lh;
+}
+__host__ __device__ constexpr int gta_qt_chan_o_out(int d, int rho) {
+    const int lh = (rho >> 2) & 1, r = (rho & 3) + 4 * (rho >> 3);
+    return 32 * d + 16 * lh + r;
+}
+// entry (r, c) of the 96 x 96 q-side matrix of the MSN layout (se3 48 | so3 24 (L = 2) | so2 24) from a staged q-side
+// record (gta_common.h: Aq / D1q / D2q carry the score scale, Oq / D1q^T / D2q^T do not); so2 channels: the identity
+// (times the scale on the forward side) -- their per-token rotation stays on the VALU
+GTA_DEV float gta_qt_entry_ms(const float* rec, int inverse, int r, int c, float fwd_scale) {
+    if ((r >> 2) != (c >> 2) && (r < 48 || c < 48)) return 0.f;
+    if (r < 48) return rec[(inverse ? GTA_QREC_O : GTA_QREC_A) + 4 * (r & 3) + (c & 3)];
+    if (r >= 72 || c >= 72) return r == c ? (inverse ? 1.0f : fwd_scale) : 0.f;
+    if (((r - 48) >> 3) != ((c - 48) >> 3)) return 0.f;
+    const int er = (r - 48) & 7, ec = (c - 48) & 7;
+    if (er < 3 && ec < 3) return rec[(inverse ? GTA_QREC_D1T : GTA_QREC_D1) + 4 * er + ec];
+    if (er >= 3 && ec >= 3) return rec[(inverse ? GTA_QREC_D2T : GTA_QREC_D2) + 8 * (er - 3) + (ec - 3)];
+    return 0.f;
+}
+// one workgroup (256 threads) expands the record of view (b, n) into its 24 tiles
+GTA_DEV void gta_qt_build_view(char* tiles, const float* rec, float fwd_scale, int tid) {
+    // 2 types x 3 blocks x 2 k-steps x 32 rows = 384 rows of 16 entries; hi and lo rows go to tiles t and t + 6
+    for (int idx = tid; idx < 384; idx += 256) {
+        const int rho = idx & 31, kk = (idx >> 5) & 1, d = (idx >> 6) % 3, type = idx / 192;
+        const int r = type ? gta_qt_chan_o_out(d, rho) : gta_qt_chan_q(d, rho);
+        uint32_t hi[8], lo[8];
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) {
+            float x[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int k = 2 * k2 + e;
+                const int c = type ? gta_qt_chan_o_in(d, kk, k) : 32 * d + 16 * kk + k;
+                x[e] = gta_qt_entry_ms(rec, type, r, c, fwd_scale);
+            }
+            hi[k2] = pack_bf16x2(x[0], x[1]);
+            lo[k2] = pack_bf16x2(x[0] - bf16_lo(hi[k2]), x[1] - bf16_hi(hi[k2]));
+        }
+        char* t_hi = tiles + (12 * type + 2 * d + kk) * GTA_QT_BYTES;
+        char* t_lo = t_hi + 6 * GTA_QT_BYTES;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            *reinterpret_cast<u32x4_t*>(t_hi + (half * 32 + rho) * 16) = u32x4_t{hi[4 * half], hi[4 * half + 1], hi[4 * half + 2], hi[4 * half + 3]};
+            *reinterpret_cast<u32x4_t*>(t_lo + (half * 32 + rho) * 16) = u32x4_t{lo[4 * half], lo[4 * half + 1], lo[4 * half + 2], lo[4 * half + 3]};
+        }
+    }
+}
+
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{})
 template <class F, int... Is>
 GTA_DEV void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }

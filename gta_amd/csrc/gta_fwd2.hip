@@ -36,6 +36,7 @@
 
 int gta_prep_dispatch(const GtaFwdParams& p, int dhp, int esz, hipStream_t stream);                  // gta_prep.hip
 bool gta_attn64_takes(const GtaFwdParams& p, int dhp, int layout);                                  // gta_fwd64.hip
+int gta_qtiles_dispatch(const GtaFwdParams& p, hipStream_t stream);
 int gta_attn64_dispatch(const GtaFwdParams& p, int esz, hipStream_t stream);
 
 // profiling hook (not part of the product ABI, see gta_hip.h): events for the NEXT attention-kernel launch of this thread
@@ -759,15 +760,18 @@ int launch_fwd2(const GtaFwdParams& p, hipStream_t stream) {
 
 }  // namespace
 
-// workspace = [K'/V' tile images | per-tile key norms (float, 256-byte aligned start)]
 long gta_fwd2_image_bytes(int B, int H, int Tk, int dhp) {
     const long n_tiles = (Tk + BN - 1) / BN;
     return (long)B * H * n_tiles * 2L * BN * dhp * 2;
 }
-long gta_fwd2_workspace_bytes(int B, int H, int Tk, int dhp) {
+// workspace = [K'/V' tile images | per-tile key norms | q-side rep tiles (dh = 96: gta_flash_common.h, 24 KiB per (scene, view))]
+long gta_fwd2_qtiles_offset(int B, int H, int Tk, int dhp) {
     const long n_tiles = (Tk + BN - 1) / BN;
     const long img = (gta_fwd2_image_bytes(B, H, Tk, dhp) + 255) & ~255L;
     return img + (((long)B * H * n_tiles * 4 + 255) & ~255L);
+}
+long gta_fwd2_workspace_bytes(int B, int H, int Tk, int dhp, int Nq) {
+    return gta_fwd2_qtiles_offset(B, H, Tk, dhp) + (dhp == 96 ? (long)B * Nq * GTA_QT_TILES * GTA_QT_BYTES : 0L);
 }
 int gta_fwd2_lds_bytes(int dhp, int nrec) {
     switch (dhp) {
@@ -813,7 +817,10 @@ int gta_fwd2_dispatch(GtaFwdParams& p, int dhp, int esz, bool run_prep, bool run
     // view records a 128-row query tile can touch (staged per item, two buffers)
     p.nrec = 128 / p.Pq + 2 < p.Nq ? 128 / p.Pq + 2 : p.Nq;
     int rc = GTA_OK;
+    // the q-side rep tiles (rho_q / rho_q^-1 on the matrix cores) only where the 64-rows-per-wave kernel will use them
+    if (!(p.qtiles && esz == 2 && run_flash && gta_attn64_takes(p, dhp, layout_of(p, dhp)))) p.qtiles = nullptr;
     if (run_prep) rc = gta_prep_dispatch(p, dhp, esz, stream);
+    else if (p.qtiles) rc = gta_qtiles_dispatch(p, stream);
     if (rc != GTA_OK || !run_flash) return rc;
     switch (dhp) {
         case 32: return esz == 2 ? launch_flash<32, 2>(p, stream) : launch_flash<32, 4>(p, stream);

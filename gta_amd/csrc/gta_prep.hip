@@ -50,6 +50,25 @@ __global__ __launch_bounds__(256) void gta_kv_prep_kernel(const GtaFwdParams p) 
     // neighbouring heads share lines: the H workgroups of one 64-token row tile are made consecutive on ONE XCD, whose L2
     // then serves the shared lines (r01 measured 1.40x over-fetch with heads spread over the XCDs).
     const int n_tiles = (p.Tk + BN - 1) / BN;
+    // The launch's LAST B * Nq workgroups (when the attention kernel of this call wants them: p.qtiles) expand the q-side view
+    // records into MFMA operand tiles (gta_flash_common.h) -- one view each, beside the K/V tiles' memory traffic.
+    {
+        const int n_kv = ((p.B * n_tiles + 7) / 8) * 8 * p.H;
+        if ((int)blockIdx.x >= n_kv) {
+            const int vw = blockIdx.x - n_kv, bq = vw / p.Nq, nq = vw - bq * p.Nq;
+            float* rec = reinterpret_cast<float*>(smem);
+            const float tc = p.trans_coeff ? *p.trans_coeff : 1.0f;
+            const float fs = p.scale * LOG2E / (p.tau ? *p.tau : 1.0f);
+            for (int idx = lane; idx < qrec_seg_count(wave, 1); idx += 64) {
+                QrecItem it;
+                qrec_seg_load(it, p.vrep_q, bq, p.Nq, nq, 1, wave, idx);
+                qrec_seg_store(it, rec, tc, fs);
+            }
+            __syncthreads();
+            gta_qt_build_view((char*)p.qtiles + (long)vw * GTA_QT_TILES * GTA_QT_BYTES, rec, fs, tid);
+            return;
+        }
+    }
     int j, h, b;
     {
         const int L = blockIdx.x, x = L & 7, i = L >> 3;
@@ -244,7 +263,8 @@ int launch_prep(const GtaFwdParams& p, hipStream_t stream) {
     if (int rc = gta_lds_optin<&gta_kv_prep_kernel<DHP, ESZ>>(S::total(GTA_MAX_VIEWS))) return rc;
     const int n_tiles = (p.Tk + BN - 1) / BN;
     const long rows = (long)p.B * n_tiles;
-    const long grid = (rows + 7) / 8 * 8 * p.H;
+    long grid = (rows + 7) / 8 * 8 * p.H;
+    if (p.qtiles && p.vrep_q) grid += (long)p.B * p.Nq;          // the q-side tile builders (see the kernel's head)
     if (grid > 0x7fffffffL) return GTA_E_UNSUPPORTED;
     hipLaunchKernelGGL((gta_kv_prep_kernel<DHP, ESZ>), dim3((unsigned)grid), dim3(256), S::total(p.vrep_k ? p.Nk : 0), stream, p);
     return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH;

@@ -101,8 +101,8 @@ def audit_others():
 def audit_attn64():
     """gta_attn64_kernel (gta_fwd64.hip): the tile loop statement owns v32-v255 and the whole accumulator file by literal
     register number, the Q' fragments are written into a[96:143] by separate statements in front of it and O is read out of
-    a[0:95] behind it.  hipcc does not know: what it must not do is touch an accumulator register itself (it parks values
-    there under VGPR pressure) anywhere in the kernel, and the loop statement must be the single long one.  Also: no scratch
+    a[0:95] behind it.  hipcc does not know: what it must not do is touch an accumulator register above a27 itself (it parks values in the
+    lowest ones under VGPR pressure: a[0:27] are left to it) anywhere in the kernel, and the loop statement must be the single long one.  Also: no scratch
     access behind the kernel's set-up (a reload sits behind a vmcnt(0))."""
     text = _asm("gta_fwd64.hip", ("-fno-slp-vectorize",))
     report, problems = [], []
@@ -124,14 +124,15 @@ def audit_attn64():
             if inasm:
                 cur_len += 1
                 continue
-            compiler_acc += "v_accvgpr" in line or bool(re.search(r"\ba\[?\d+", line.split(";")[0]))
+            for m2 in re.finditer(r"\ba\[?(\d+)(?::(\d+))?", line.split(";")[0]):
+                compiler_acc += int(m2.group(2) or m2.group(1)) >= 28          # (a[0:27] are left to hipcc: gen_attn64.py)
             if "scratch_" in line:
                 scratch_lines.append(i)
         row = {"instance": key, "vgpr": vgpr, "accum_offset": accum, "compiler_agpr_uses": compiler_acc, "scratch": len(scratch_lines),
                "loop_statements": long_stmts}
         report.append(row)
         if compiler_acc:
-            problems.append(f"gta_attn64_kernel<{key}>: hipcc touches accumulator registers itself ({compiler_acc} instructions)")
+            problems.append(f"gta_attn64_kernel<{key}>: hipcc touches accumulator registers above a27 itself ({compiler_acc} operands)")
         if long_stmts != 1:
             problems.append(f"gta_attn64_kernel<{key}>: {long_stmts} loop statements (expected one)")
         if vgpr != 512 or accum != 256:

@@ -219,7 +219,7 @@ def variants(which, B=32):
         ok = real > 0
         ghz = ((P[:, 4] - P[:, 0])[ok] / real[ok]).mean().item() * 0.1 if ok.any() else 0.0
         span_us = ((P[:, 6].max() - P[:, 5].min()) / 100.0).item()
-        ph = [(P[:, b_] - P[:, a_]).mean().item() for a_, b_ in ((0, 1), (1, 2), (2, 3), (3, 4), (0, 4))]
+        ph = [(P[:, b_] - P[:, a_]).mean().item() for a_, b_ in ((0, 1), (1, 2), (2, 3), (3, 4), (0, 4), (3, 7))]
         return ghz, span_us, ph
     times = {v: [] for v in which}
     times["rows32"] = []
@@ -235,7 +235,7 @@ def variants(which, B=32):
         r = sorted(times[v])
         slope = (ph2[2] - ph[2]) / 20
         print(f"variant {v}: {r[2]:7.1f} us median ({r[0]:.1f} min) | {span_us:6.1f} us x {ghz:.3f} GHz = {span_us * ghz:6.1f}k cyc | item: "
-              f"load {ph[0]:5.0f} rho_q {ph[1]:5.0f} loop {ph[2]:6.0f} epi {ph[3]:5.0f} total {ph[4]:6.0f} | STEP {slope:5.0f} cyc/tile, head+tail {ph[2] - 20 * slope:5.0f}", flush=True)
+              f"load {ph[0]:5.0f} rho_q {ph[1]:5.0f} loop {ph[2]:6.0f} epi {ph[3]:5.0f} (request issued at +{ph[5]:5.0f}) total {ph[4]:6.0f} | STEP {slope:5.0f} cyc/tile, head+tail {ph[2] - 20 * slope:5.0f}", flush=True)
     os.environ.pop("GTA_ATTN64_VARIANT", None)
     ghz, span_us, ph = stamps(devs[5][1], 128)
     _, _, ph2 = stamps(devs[10][1], 128)
