@@ -50,12 +50,15 @@ __global__ __launch_bounds__(256) void gta_kv_prep_kernel(const GtaFwdParams p) 
     // neighbouring heads share lines: the H workgroups of one 64-token row tile are made consecutive on ONE XCD, whose L2
     // then serves the shared lines (r01 measured 1.40x over-fetch with heads spread over the XCDs).
     const int n_tiles = (p.Tk + BN - 1) / BN;
-    // The launch's LAST B * Nq workgroups (when the attention kernel of this call wants them: p.qtiles) expand the q-side view
-    // records into MFMA operand tiles (gta_flash_common.h) -- one view each, beside the K/V tiles' memory traffic.
+    // The launch's FIRST workgroups (when the attention kernel of this call wants them: p.qtiles; B * Nq of them, rounded up to a
+    // multiple of 8 so that the XCD map below is unchanged) expand the q-side view records into MFMA operand tiles
+    // (gta_flash_common.h) -- one view each, under the K/V tiles' memory traffic from the start (at the grid's end they were a 3.6 us tail).
+    const int n_qt_wgs = (p.qtiles && p.vrep_q) ? (p.B * p.Nq + 7) / 8 * 8 : 0;
     {
-        const int n_kv = ((p.B * n_tiles + 7) / 8) * 8 * p.H;
-        if ((int)blockIdx.x >= n_kv) {
-            const int vw = blockIdx.x - n_kv, bq = vw / p.Nq, nq = vw - bq * p.Nq;
+        if ((int)blockIdx.x < n_qt_wgs) {
+            const int vw = blockIdx.x;
+            if (vw >= p.B * p.Nq) return;
+            const int bq = vw / p.Nq, nq = vw - bq * p.Nq;
             float* rec = reinterpret_cast<float*>(smem);
             const float tc = p.trans_coeff ? *p.trans_coeff : 1.0f;
             const float fs = p.scale * LOG2E / (p.tau ? *p.tau : 1.0f);
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(256) void gta_kv_prep_kernel(const GtaFwdParams p) 
     }
     int j, h, b;
     {
-        const int L = blockIdx.x, x = L & 7, i = L >> 3;
+        const int L = blockIdx.x - n_qt_wgs, x = L & 7, i = L >> 3;
         const int r = x + 8 * (i / p.H);                 // row tile = (b, j)
         h = i - (i / p.H) * p.H;
         if (r >= p.B * n_tiles) return;
@@ -264,7 +267,7 @@ int launch_prep(const GtaFwdParams& p, hipStream_t stream) {
     const int n_tiles = (p.Tk + BN - 1) / BN;
     const long rows = (long)p.B * n_tiles;
     long grid = (rows + 7) / 8 * 8 * p.H;
-    if (p.qtiles && p.vrep_q) grid += (long)p.B * p.Nq;          // the q-side tile builders (see the kernel's head)
+    if (p.qtiles && p.vrep_q) grid += ((long)p.B * p.Nq + 7) / 8 * 8;        // the q-side tile builders (see the kernel's head)
     if (grid > 0x7fffffffL) return GTA_E_UNSUPPORTED;
     hipLaunchKernelGGL((gta_kv_prep_kernel<DHP, ESZ>), dim3((unsigned)grid), dim3(256), S::total(p.vrep_k ? p.Nk : 0), stream, p);
     return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH;
