@@ -404,9 +404,9 @@ def main():
         from gta_amd import srt, ddp
         torch.manual_seed(1234 + rank)
         model = srt.TransformingSRT(srt.msn_gta_so3_cfg()).to(device)
-        bucket_log = None
         if dist is not None:
-            model, bucket_log = ddp.wrap_ddp_logged(model, local_rank)
+            # the reference's structure (train.py:182-188): encoder and decoder in their own DistributedDataParallel
+            model, _ = ddp.wrap_srt_ddp(model, local_rank, logged=False)
         opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
         batch = srt.synthetic_batch(args.model_batch, device=device, seed=99 + rank)
 
@@ -420,8 +420,6 @@ def main():
         for _ in range(2):
             model_step()
         torch.cuda.synchronize()
-        if bucket_log is not None:
-            bucket_log.reset()
         if dist is not None:
             dist.barrier()
         tm0 = time.perf_counter()
@@ -444,8 +442,18 @@ def main():
                                f"views, 1280 scene tokens, 2560 query rays), {args.model_batch} scenes/GPU, "
                                f"AdamW, {args.dtype} autocast, dp{n_}",
                      "note": "whole-model optimizer step on synthetic batches (SURVEY 8 f2); not part of `value`"}
-        if bucket_log is not None:
-            srt_train["grad_allreduce"] = bucket_log.summary(args.model_train_steps)
+        if dist is not None:
+            # the bucket timeline on two EXTRA steps (the Python hook replaces DDP's C++ all-reduce: not inside the timed steps)
+            logs = []
+            for sub in (model.encoder, model.decoder):
+                lg = ddp.BucketLog()
+                sub.register_comm_hook(None, lg.hook)
+                logs.append(lg)
+            for _ in range(2):
+                model_step()
+            torch.cuda.synchronize()
+            srt_train["grad_allreduce"] = {nm: lg.summary(2) for nm, lg in zip(("encoder", "decoder"), logs)}
+        srt_train["ddp"] = "two DistributedDataParallel instances (encoder, decoder) as train.py:182-188" if dist is not None else None
         del model, opt, batch
     flops = 4.0 * B * H * Tq * Tk * dh                               # QK^T + PV, 2 flop/MAC
     alg_bytes = (2 * Tq + 2 * Tk) * H * dh * q.element_size() * B    # read Q,K,V once, write O once
@@ -466,6 +474,7 @@ def main():
                                    f"B={B}/GPU, H={H}, Tq={Tq}, Tk={Tk}, dh={dh}, f_dims={f_dims}, "
                                    f"views q/k={Nq}/{Nk}", "global_batch": n * B, "parallelism": f"dp{n}"},
             "host_ms_per_step": t_host / args.steps * 1e3, "per_rank_ms_per_step": per_rank,
+            "dist": __import__("gta_amd.ddp", fromlist=["backend_info"]).backend_info(),
         }
         if achieved is not None:
             line["roofline"] = {"bound": "mfma", "kernel": kname, "rows_per_item": rows_it.value, "achieved": achieved,

@@ -346,18 +346,7 @@ struct DqSmem {
 
 template <int BYTES>
 GTA_DEV void dma_linear4(char* dst, const char* src, int wave, int lane) {     // 4 waves, 1 KiB pieces
-#ifdef GTA_DMA_BUILTIN
-    constexpr int PER_WAVE = BYTES / 1024 / 4;
-    static_assert(BYTES % 4096 == 0, "piece split");
-#pragma unroll
-    for (int i = 0; i < PER_WAVE; ++i) {
-        const int piece = wave * PER_WAVE + i;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024 + lane * 16),
-                                         (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
-    }
-#else
     dma_linear_4waves<BYTES>(dst, src, wave, lane);      // scalar-base asm form (gta_common.h): no per-piece vector arithmetic
-#endif
 }
 
 template <int DHP, int ESZ>
@@ -615,7 +604,8 @@ struct DkvSmem {
 };
 
 template <int DHP, int ESZ>
-__global__ __launch_bounds__(256, 2) void gta_bwd_dkv_kernel(const GtaBwdParams p) {
+// (dh = 128: one workgroup per CU -- with two, the 256-register budget left 117 dwords of scratch in the tile loop)
+__global__ __launch_bounds__(256, (DHP > 96 ? 1 : 2)) void gta_bwd_dkv_kernel(const GtaBwdParams p) {
     using S = DkvSmem<DHP>;
     constexpr int CHP = S::CHP, KS = DHP / 16, DB = DHP / 32, BK = 128;
     constexpr int DMA_PER_WAVE = S::STAGE / 1024 / 4;

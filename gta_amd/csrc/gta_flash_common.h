@@ -272,21 +272,15 @@ GTA_DEV void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std:
 template <int N, class F>
 GTA_DEV void static_for(F&& f) { static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
 
-#ifndef GTA_NSTAGE
-#define GTA_NSTAGE 3
-#endif
-constexpr int NSTAGE = GTA_NSTAGE;       // ring stages (K' + V' tile images each); the skewed loop needs 3, the plain loop 2 or 3
+constexpr int NSTAGE = 3;                // ring stages (K' + V' tile images each); the skewed loop needs 3, the plain loop 2 or 3
 // Skewed tile loop in the 128-row kernel (QK^T of tile j+1 beside the softmax of tile j), used at dh = 96.
 // Measured on MI355X by CYCLE counts (tools/bench_kernels.py timeline on an instrumented build; MSN encoder, B=32):
 // 362-366k shader cycles per launch against 396-406k un-skewed (tile loop 48.5k vs 52.7k cycles per workgroup), -9 %.
 // In microseconds it first looked neutral (214 vs 212 us): the more efficient loop draws more power and is granted a
 // lower clock (1.88 vs 1.92 GHz), and timings from separate launches differ by more than that anyway (the clock moves
-// between 1.69 and 2.13 GHz, profiles/r01/README.md).  7 VGPRs spill outside the loop.  -DGTA_PIPE1=0 selects the
-// plain loop.
-#ifndef GTA_PIPE1
-#define GTA_PIPE1 1
-#endif
-constexpr bool PIPE1 = GTA_PIPE1 != 0;
+// between 1.69 and 2.13 GHz, profiles/r01/README.md).  7 VGPRs spill outside the loop.  The dh <= 64 instances keep the
+// plain loop (three workgroups per CU).
+constexpr bool PIPE1 = true;
 constexpr float BOUND_THR = 96.0f;     // exp2 arguments stay below this without looking at the scores
 
 }  // namespace

@@ -30,6 +30,7 @@
 // Measured dead ends (r01, profiles/r01/README.md): an explicit ping-pong of an 8-wave kernel, 64 query rows per wave
 // with an asm-owned accumulator file (one wave per SIMD), 8-wave workgroups sharing one ring -- none beat two 4-wave
 // workgroups per CU; the sources of those variants are in the history (gta_fwd3.hip, removed in r02).
+#include <atomic>
 #include <cstdlib>
 #include <hip/hip_ext.h>
 #include "gta_flash_common.h"
@@ -86,17 +87,10 @@ GTA_DEV void dma_stage(char* ring, int st, const char* img, int wave, int lane) 
     const unsigned voff = (unsigned)lane * 16u;
     const char* base = img + wave * (PER_WAVE * 1024);
     const uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(ring + st * S::STAGE + wave * (PER_WAVE * 1024));
-#ifdef GTA_DMA_BUILTIN
-#pragma unroll
-    for (int i = 0; i < PER_WAVE; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + i * 1024 + voff),
-                                         (__attribute__((address_space(3))) void*)(ring + st * S::STAGE + (wave * PER_WAVE + i) * 1024), 16, 0, 0);
-#else
     static_for<(PER_WAVE + 3) / 4>([&](auto GC) {
         constexpr int g = decltype(GC)::value, np = PER_WAVE - 4 * g < 4 ? PER_WAVE - 4 * g : 4;
         dma_group<np>(lds + g * 4096, base + g * 4096, voff);
     });
-#endif
 }
 
 // Full path of the lazy softmax (tile 0, masked tail, violated bound): true row max of S' (= S - m_run), move
@@ -188,11 +182,8 @@ GTA_DEV KArgs kargs() {
     return a;
 }
 
-#ifndef GTA_OCC96
-#define GTA_OCC96 2
-#endif
 template <int DHP, int ESZ, int LAYOUT>
-__global__ __launch_bounds__(256, (DHP <= 64 ? 3 : GTA_OCC96)) void gta_fwd2_kernel(const GtaFwdParams p_kernarg) {
+__global__ __launch_bounds__(256, (DHP <= 64 ? 3 : 2)) void gta_fwd2_kernel(const GtaFwdParams p_kernarg) {
     using S = Smem2<DHP>;
     // chunk descriptor: a compile-time constant for the shipped layouts (c is constant per unrolled item)
 #define GTA_DESC(c) (LAYOUT == GTA_LAYOUT_GENERIC ? pp->ctab[c] : gta_layout_desc(LAYOUT, c))
@@ -433,10 +424,7 @@ __global__ __launch_bounds__(256, (DHP <= 64 ? 3 : GTA_OCC96)) void gta_fwd2_ker
     float rs0 = 0.f, rs1 = 0.f;                       // row-sum halves (even / odd values)
     constexpr int NEV = 32;                           // P values per lane and tile: e -> (half = e >> 4, r = e & 15)
     constexpr int GA = 2 * KS;                        // MFMAs of A: g -> (ks = g >> 1, half = g & 1)
-#ifndef GTA_KLA
-#define GTA_KLA 2
-#endif
-    constexpr int KLA = GTA_KLA;                      // K' fragment reads run this many k steps ahead of their MFMAs
+    constexpr int KLA = 2;                      // K' fragment reads run this many k steps ahead of their MFMAs
     auto e_first = [](int g) constexpr { return g * NEV / GA; };
     auto s_fence1 = [&](f32x16_t (&s)[2]) { asm volatile("" : "+v"(s[0])); asm volatile("" : "+v"(s[1])); };
     auto step = [&](f32x16_t (&sc)[2], f32x16_t (&sn)[2], int j, auto LASTC) {
@@ -718,19 +706,22 @@ int launch_fwd2(const GtaFwdParams& p, hipStream_t stream) {
     long grid = p.n_items;
     pl.per_cu = 0;
     {
-        // resident workgroups of this instance on this device (queried once per device and LDS size)
-        static int slots_dev[64], slots_lds[64], slots_percu[64];
+        // resident workgroups of this instance on this device: queried once per (device, LDS size) and published as ONE word
+        // (lds << 32 | slots << 8 | per_cu), so a racing thread sees a consistent triple or none
+        static std::atomic<uint64_t> cache[64];
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) return GTA_E_NODEVICE;
         int cus = 0, per_cu = 0;
         long g = 0;
-        if (dev >= 0 && dev < 64 && slots_dev[dev] > 0 && slots_lds[dev] == lds) { g = slots_dev[dev]; per_cu = slots_percu[dev]; }
+        const uint64_t c = (dev >= 0 && dev < 64) ? cache[dev].load(std::memory_order_acquire) : 0;
+        if (c && (int)(c >> 32) == lds) { g = (long)((c >> 8) & 0xffffff); per_cu = (int)(c & 0xff); }
         else {
             if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
             g = (long)cus * per_cu;
             g -= g % 8;
-            if (dev >= 0 && dev < 64) { slots_dev[dev] = (int)g; slots_lds[dev] = lds; slots_percu[dev] = per_cu; }
+            if (dev >= 0 && dev < 64 && g > 0 && g < (1 << 24))
+                cache[dev].store(((uint64_t)(uint32_t)lds << 32) | ((uint64_t)g << 8) | (uint64_t)(per_cu & 0xff), std::memory_order_release);
         }
         // Persistent grid on request, and by default for launches of more than one but at most two rounds of resident
         // workgroups (the 600-token CLEVR-TR encoder: 960 items on 768 slots): there the second round runs a quarter

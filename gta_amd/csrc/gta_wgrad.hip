@@ -18,7 +18,7 @@
 // A ring of four 32-KiB stages keeps three steps of DMA in flight under the MFMAs; the ring turns in the MIDDLE of a step,
 // between its two 16-token MFMA blocks, so every fragment read flies under an MFMA block.  Each wave owns 128 x 128 of the
 // tile: 16 accumulators of 32 x 32 (256 registers: the AGPR half of the wave's file), 32 MFMAs against 32 transpose-reads and
-// 8 DMA instructions per step.  (GTA_WGRAD_WAVES=8 builds the earlier tiling: 128 x 64 per wave, two waves per SIMD.)
+// 8 DMA instructions per step.  (WG_WAVES = 8 is the earlier tiling: 128 x 64 per wave, two waves per SIMD.)
 //
 // What bounds it (profiles/r02/README.md).  The steady-state step keeps everything that is not an MFMA BETWEEN the MFMAs of
 // its two blocks (one fragment's two transpose-reads or one DMA request per gap, pinned by scheduling barriers), runs on a
@@ -47,15 +47,9 @@ constexpr int WG_TILE = 256;                       // dW tile edge (both ways)
 constexpr int WG_BT = 32;                          // tokens per step (two 16-token groups)
 constexpr int WG_OPER = WG_BT * WG_TILE * 2;       // one operand tile [32][256] bf16, bytes (16 KiB)
 constexpr int WG_STAGE = 2 * WG_OPER;              // G tile + X tile (32 KiB)
-#ifndef GTA_WGRAD_STAGES
-#define GTA_WGRAD_STAGES 4
-#endif
-constexpr int WG_NSTAGE = GTA_WGRAD_STAGES;        // ring depth: NSTAGE - 1 steps of DMA in flight under the MFMAs
+constexpr int WG_NSTAGE = 4;        // ring depth: NSTAGE - 1 steps of DMA in flight under the MFMAs
 constexpr int WG_LDS = WG_NSTAGE * WG_STAGE;
-#ifndef GTA_WGRAD_WAVES
-#define GTA_WGRAD_WAVES 4
-#endif
-constexpr int WG_WAVES = GTA_WGRAD_WAVES;          // 4: 2 (n) x 2 (k), 128 x 128 of the tile per wave, one wave per SIMD, accumulators
+constexpr int WG_WAVES = 4;          // 4: 2 (n) x 2 (k), 128 x 128 of the tile per wave, one wave per SIMD, accumulators
                                                    //    in AGPRs;  8: 2 x 4, 128 x 64 per wave, two waves per SIMD
 static_assert(WG_WAVES == 4 || WG_WAVES == 8, "wave tilings of the 256 x 256 workgroup tile");
 constexpr int WG_WK = WG_WAVES / 2;                // waves along k

@@ -99,9 +99,12 @@ def wrap_ddp(model: torch.nn.Module, local_rank: int = 0, bucket_mb: int = XGMI_
 
 class BucketLog:
     """DDP communication hook that does what the default hook does (all-reduce the bucket, divide by the world size)
-    and keeps a timeline: per bucket its bytes and -- on CUDA -- events around the collective on the stream it runs on.
-    ``summary()`` after a synchronise gives bytes, bucket count and the summed all-reduce time of the logged steps, so
-    ``bench.py --model-train-steps`` can report the collective beside the step."""
+    and keeps a timeline: per bucket its bytes and -- on CUDA -- two events: one recorded on the compute stream when the
+    bucket is handed over, one in the future's callback when the reduced bucket has been scaled.  Their distance is the
+    bucket's ISSUE-TO-RESULT latency: it contains the wait for backward kernels queued in front of the collective and the
+    callback's own latency, not the collective alone (RCCL's own kernels show up in a rocprofv3 kernel trace).  The Python hook
+    also replaces DDP's built-in C++ all-reduce, so a step timed with it is slightly perturbed: bench.py times the
+    optimizer steps WITHOUT the hook and logs buckets on a few extra steps."""
 
     def __init__(self):
         self.rows = []
@@ -133,18 +136,57 @@ class BucketLog:
             return None
         ms = [r["events"][0].elapsed_time(r["events"][1]) for r in self.rows if r["events"] is not None]
         return {"buckets_per_step": len(self.rows) / max(steps, 1), "bytes_per_step": sum(r["bytes"] for r in self.rows) / max(steps, 1),
-                "allreduce_ms_per_step": (sum(ms) / max(steps, 1)) if ms else None,
-                "note": "events around each bucket's all-reduce (issue -> result scaled); buckets overlap the backward"}
+                "bucket_issue_to_result_ms_per_step": (sum(ms) / max(steps, 1)) if ms else None,
+                "note": "per bucket: handed to the hook on the compute stream -> reduced and scaled (includes queued backward kernels "
+                        "and callback latency; not the collective alone); buckets overlap the backward"}
 
 
-def wrap_ddp_logged(model: torch.nn.Module, local_rank: int = 0, bucket_mb: int = XGMI_BUCKET_MB):
-    """wrap_ddp + a BucketLog registered as the communication hook: (model, log); (model, None) when single process."""
-    m = wrap_ddp(model, local_rank, bucket_mb)
+def wrap_ddp_logged(model: torch.nn.Module, local_rank: int = 0, bucket_mb: int = XGMI_BUCKET_MB, force: bool = False):
+    """wrap_ddp + a BucketLog registered as the communication hook: (model, log); (model, None) when single process
+    (``force``: wrap also in a world of one -- the reducer, its bucket views and the hook then run for real on one rank)."""
+    if force and dist.is_available() and dist.is_initialized() and world()[1] == 1:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        cuda = next(model.parameters()).is_cuda
+        m = DDP(model, device_ids=[local_rank] if cuda else None, bucket_cap_mb=bucket_mb, gradient_as_bucket_view=cuda)
+    else:
+        m = wrap_ddp(model, local_rank, bucket_mb)
     if m is model:
         return m, None
     log = BucketLog()
     m.register_comm_hook(None, log.hook)
     return m, log
+
+
+def wrap_srt_ddp(model: torch.nn.Module, local_rank: int = 0, logged: bool = False, bucket_mb: int = XGMI_BUCKET_MB,
+                 force: bool = False):
+    """The reference's data-parallel structure (train.py:182-188): ``model.encoder`` and ``model.decoder`` each in their OWN
+    DistributedDataParallel -- two reducers, two bucket streams.  Returns (model, [logs]) with the sub-modules replaced in place;
+    the logs are BucketLog hooks when ``logged`` (else empty)."""
+    logs = []
+    for name in ("encoder", "decoder"):
+        sub = getattr(model, name)
+        if logged:
+            w, log = wrap_ddp_logged(sub, local_rank, bucket_mb, force=force)
+            if log is not None:
+                logs.append(log)
+        else:
+            w = wrap_ddp(sub, local_rank, bucket_mb)
+        setattr(model, name, w)
+    return model, logs
+
+
+def backend_info() -> dict:
+    """what the process group runs on, for the bench line: backend, world size, RCCL version (torch's nccl IS RCCL on ROCm)"""
+    info = {"backend": None, "world": 1, "rccl_version": None}
+    if dist.is_available() and dist.is_initialized():
+        info["backend"] = dist.get_backend()
+        info["world"] = dist.get_world_size()
+    try:
+        v = torch.cuda.nccl.version()
+        info["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:
+        pass
+    return info
 
 
 def max_over_ranks(seconds: float, device=None) -> float:

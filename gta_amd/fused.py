@@ -48,11 +48,27 @@ def compute_dtype(x: torch.Tensor) -> Optional[torch.dtype]:
     return x.dtype if x.dtype in (torch.float32, torch.bfloat16) else None
 
 
+# Keep the bf16 copy of an fp32 weight on the parameter between calls (opt-in).  Off by default: the copy can only be tied to the
+# parameter's version counter and storage address, and an update THROUGH ``.data`` (``p.data.mul_()``, an EMA's
+# ``ema_p.data.mul_(d).add_(p.data)``, ``p.data.copy_(w)``) changes neither -- the fused path would keep multiplying by stale
+# weights.  A cast is a few microseconds per weight (four per layer); the backward gets the forward's copy through the autograd context.
+CACHE_WEIGHT_CASTS = False
+
+
+def clear_weight_casts(module: torch.nn.Module) -> None:
+    """Drop every cached weight copy under ``module`` (only meaningful with ``CACHE_WEIGHT_CASTS``)."""
+    for p in module.parameters():
+        if hasattr(p, "_gta_cast"):
+            del p._gta_cast
+
+
 def _cast_param(p: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
-    """p in the compute dtype; the copy is kept on the parameter until the parameter changes -- an in-place update (an
-    optimizer step, load_state_dict) bumps its version counter, an assignment to ``.data`` moves its storage."""
+    """p in the compute dtype: a fresh cast per call (safe under any way of updating the parameter), or -- with
+    ``CACHE_WEIGHT_CASTS`` -- a copy kept on the parameter until its version counter or storage address changes."""
     if p.dtype == dt:
         return p.detach()
+    if not CACHE_WEIGHT_CASTS:
+        return p.detach().to(dt)
     key = (p._version, p.data_ptr())
     tag = getattr(p, "_gta_cast", None)
     if tag is not None and tag[0] == key and tag[1].dtype == dt and tag[1].device == p.device:

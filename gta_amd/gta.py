@@ -14,6 +14,8 @@ import math
 from typing import Dict, Optional, Tuple
 
 import numpy as np
+import weakref
+
 import torch
 
 from . import native
@@ -75,6 +77,17 @@ def _src_key(*tensors):
     return tuple(out)
 
 
+def _flat(sources):
+    """the tensors among a table's sources (lists of tensors flattened, None dropped)"""
+    out = []
+    for t in sources:
+        if torch.is_tensor(t):
+            out.append(t)
+        elif isinstance(t, (list, tuple)):
+            out.extend(u for u in t if torch.is_tensor(u))
+    return out
+
+
 def pack_reps(reps: dict, f_dims: dict) -> dict:
     """Return (and cache in ``reps``) the packed tables for a reference-style ``reps`` dict.
 
@@ -93,9 +106,15 @@ def pack_reps(reps: dict, f_dims: dict) -> dict:
         if key in reps and (key + "_src") not in reps:
             return reps[key]
         src = _src_key(*sources)
-        if key not in reps or reps.get(key + "_src") != src:
+        # (address, shape, version) alone can alias: the caching allocator hands a freed block to the next tensor of the same
+        # shape, at version 0.  The table therefore also holds WEAK references to its source tensors -- a dead one, or one that
+        # is not the tensor now in the dict, forces a rebuild.
+        alive = reps.get(key + "_ref")
+        same = alive is not None and len(alive) == len(_flat(sources)) and all(r() is t for r, t in zip(alive, _flat(sources)))
+        if key not in reps or reps.get(key + "_src") != src or not same:
             reps[key] = build()
             reps[key + "_src"] = src
+            reps[key + "_ref"] = tuple(weakref.ref(t) for t in _flat(sources))
         return reps[key]
 
     if need_view:

@@ -185,6 +185,15 @@ class Attention(nn.Module):
         return (out, attn) if return_attmap else out
 
 
+_PLAIN_LINEARS = (nn.Linear, JaxLinear, ViTLinear)       # Linear classes whose forward is F.linear(x, weight, bias) and nothing else
+
+
+def _global_forward_hooks() -> bool:
+    """module-wide hooks registered through torch.nn.modules.module.register_module_forward(_pre)_hook"""
+    import torch.nn.modules.module as M
+    return bool(getattr(M, "_global_forward_hooks", None)) or bool(getattr(M, "_global_forward_pre_hooks", None))
+
+
 class Transformer(nn.Module):
     """Pre-LN Transformer (layers.py:447-488)."""
 
@@ -213,6 +222,15 @@ class Transformer(nn.Module):
             return None
         lins = [a.to_qkv if a.selfatt else a.to_q, a.to_out[0], net[0], net[3]]
         if any(l.weight.dtype != torch.float32 or l.in_features % 4 or l.out_features % 4 for l in lins):
+            return None
+        # The fused block reads the sub-modules' parameters and never calls their forward: anything hung on those calls -- forward /
+        # pre-forward hooks (weight_norm's, activation capture, observers), wrappers that override forward (per-module FSDP,
+        # checkpointing) -- would be skipped silently.  Such layers take the module-by-module path.
+        mods = [attn, attn.norm, a, a.to_out, a.to_out[1], ff, ff.norm, ff.fn, net, net[1], net[2], net[4]] + lins
+        if any(m._forward_hooks or m._forward_pre_hooks for m in mods) or _global_forward_hooks():
+            return None
+        if any(type(l) not in _PLAIN_LINEARS for l in lins) or type(attn.norm).forward is not nn.LayerNorm.forward \
+                or type(ff.norm).forward is not nn.LayerNorm.forward:
             return None
         if (x.shape[0] * x.shape[1]) % 2:                  # the elementwise kernels work on multiples of 8 elements
             return None

@@ -80,6 +80,13 @@ class ForwardPlan:
         if self._need_cs:
             native.check_table("cs_q", cs_q, self._shapes[2], q.device)
             native.check_table("cs_k", cs_k, self._shapes[3], q.device)
+        # everything else that reaches the kernels as a raw pointer: the scalars, the tensors' device (the launch goes to the
+        # CURRENT device's stream)
+        native._require_cuda(q, k, v)
+        native.check_scalar("trans_coeff", trans_coeff, q.device)
+        native.check_scalar("tau", tau, q.device)
+        if q.device != self.out.device or torch.cuda.current_device() != q.device.index:
+            raise native.GtaError("ForwardPlan: call under the device the plan was built on (torch.cuda.set_device)")
         p = native._ptr
         d = self.desc
         base = d.flags

@@ -242,13 +242,35 @@ def test_inference_gelu_epilogue_close_to_exact():
 
 
 def test_weight_cast_cache_follows_updates():
+    """The bf16 copies of fp32 weights follow every kind of update -- also one made through ``.data`` (EMA, clamp, copy_), which
+    changes neither the parameter's version counter nor its storage address (the default: a fresh cast per call)."""
+    from gta_amd import fused
     tr, ex, x, z = _transformer(False)
+    assert fused.CACHE_WEIGHT_CASTS is False
     with torch.no_grad(), torch.autocast("cuda", dtype=BF):
         y0 = tr(x, z, ex).float()
         w = tr.layers[0][1].fn.net[0].weight
-        w.mul_(1.5)                                   # in-place update bumps the version: the bf16 copy must be redone
+        w.mul_(1.5)                                   # in-place update of the parameter
         y1 = tr(x, z, ex).float()
+        w.data.mul_(1.0 / 1.5)                        # update through .data: no version bump, same storage
+        y2 = tr(x, z, ex).float()
     assert (y1 - y0).abs().max() > 1e-3
+    assert (y2 - y0).abs().max() < 1e-6 * (1 + y0.abs().max())
+    # the opt-in cache keeps its documented contract (version counter / storage address) and can be dropped by hand
+    fused.CACHE_WEIGHT_CASTS = True
+    try:
+        with torch.no_grad(), torch.autocast("cuda", dtype=BF):
+            tr(x, z, ex)
+            w.mul_(1.5)
+            y3 = tr(x, z, ex).float()
+            assert (y3 - y1).abs().max() < 1e-6 * (1 + y1.abs().max())
+            w.data.mul_(1.0 / 1.5)
+            fused.clear_weight_casts(tr)
+            y4 = tr(x, z, ex).float()
+            assert (y4 - y0).abs().max() < 1e-6 * (1 + y0.abs().max())
+    finally:
+        fused.CACHE_WEIGHT_CASTS = False
+        fused.clear_weight_casts(tr)
 
 
 def test_packed_projection_gradient_matches_separate_tensors():
