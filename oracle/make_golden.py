@@ -232,9 +232,11 @@ def module_case(name, f_dims, so2, so3, dim, depth, H, dh, B, Nq, Pq, Nk, Pk, se
     np.savez_compressed(os.path.join(OUT, f"mod_{name}.npz"), **rec)
 
 
-def srt_case(name, seed):
+def srt_case(name, seed, P=5):
     """Reference TransformingSRT (models_nvs.py:37-91) on a tiny gta_so3-style config: forward, loss of
-    trainer.py:85-134 and every parameter gradient, with the reference's own initialisation."""
+    trainer.py:85-134 and every parameter gradient, with the reference's own initialisation.  P = rays per target view
+    (ms_tiny: 2 x 5 rays per scene; ms_rays: 2 x 128 -- enough rays that single LeakyReLU sign flips of a bf16 run average
+    out of the parameter gradients, so the mixed-precision leg of the model test can carry a real bound)."""
     torch.manual_seed(seed)
     g = gen(seed)
     dtype = torch.float64
@@ -247,7 +249,7 @@ def srt_case(name, seed):
            "decoder_kwargs": dict(dim=20, num_att_blocks=1, z_dim=48, heads=2, dropout=0.0, emb="const", rmlp_dim=32,
                                   attn_args=aa)}
     model = ref_nvs.TransformingSRT(cfg).double()
-    B, N, Nt, HW, P = 2, 2, 2, 32, 5
+    B, N, Nt, HW = 2, 2, 2, 32
     images = torch.rand(B, N, 3, HW, HW, generator=g, dtype=dtype)
     h = HW // 8
     coord_in = O.patch_coords(HW, HW, 8).to(dtype)[None, None].expand(B, N, h * h, 2).contiguous()
@@ -424,6 +426,7 @@ if __name__ == "__main__":
     operator_case("euclid_tau", {"se3": 6, "so2": 8}, 2, 0, H=2, B=2, Nq=2, Pq=5, Nk=2, Pk=5, seed=13,
                   cross=False, euclid=True, tau=1.3)
     srt_case("ms_tiny", seed=30)
+    srt_case("ms_rays", seed=31, P=128)
     vecrep_case("vecrep_attn", seed=40)
     module_case("enc_cl", CL, 2, 0, dim=32, depth=2, H=2, dh=16, B=2, Nq=2, Pq=6, Nk=2, Pk=6, seed=20,
                 cross=False)

@@ -78,12 +78,12 @@ def test_autocast_bf16_module():
     assert st["finite"] and st["rel_rms"] < 3e-2, st
 
 
-def _srt(dtype=torch.float32):
+def _srt(dtype=torch.float32, fixture="srt_ms_tiny"):
     import ast
     import numpy as np
     from gta_amd import srt
-    d, _ = G.load("srt_ms_tiny")
-    cfg = ast.literal_eval(str(np.load(G.GOLDEN + "/srt_ms_tiny.npz")["meta"]))
+    d, _ = G.load(fixture)
+    cfg = ast.literal_eval(str(np.load(G.GOLDEN + f"/{fixture}.npz")["meta"]))
     model = srt.TransformingSRT(cfg)
     model.load_state_dict({k[len("param."):]: torch.from_numpy(v).float() for k, v in d.items() if k.startswith("param.")},
                           strict=True)
@@ -95,19 +95,8 @@ def _srt(dtype=torch.float32):
     return d, model.cuda(), data
 
 
-@pytest.mark.parametrize("mixed", [False, True])
-def test_srt_model_matches_reference(mixed):
-    """Whole TransformingSRT forward + loss + backward on the HIP path under the reference's weights (fixture
-    srt_ms_tiny): rendered pixels, per-sample MSE, PSNR parity and parameter gradients."""
-    from gta_amd import srt
-    d, model, data = _srt()
-    loss, terms = srt.compute_loss(model, data, mixed_prec=mixed)
-    loss.sum().backward()
-    torch.cuda.synchronize()
-    ref_loss = torch.from_numpy(d["loss"]).float()
-    ref_psnr = torch.from_numpy(d["psnr"]).float()
-    assert (loss.cpu() - ref_loss).abs().max() <= (4e-2 if mixed else 1e-2) * ref_loss.abs().max()
-    assert (terms["psnr"].detach().cpu() - ref_psnr).abs().max() <= (0.2 if mixed else 0.05)       # dB
+def _srt_grad_check(model, d, mixed):
+    """parameter gradients of the model against the reference's (fixture); returns the worst relative RMS"""
     worst = 0.0
     for n, p in model.named_parameters():
         ref = torch.from_numpy(d["grad." + n]).float()
@@ -115,18 +104,53 @@ def test_srt_model_matches_reference(mixed):
         assert st["finite"], (n, st)
         if n.endswith("trans_coeff"):
             continue                                  # cancellation-dominated scalar, checked at operator level
-        tol = (1.0 if mixed else 5e-2) * max(st["ref_max"], 1e-4) + 1e-6
+        tol = (2e-1 if mixed else 5e-2) * max(st["ref_max"], 1e-4) + 1e-6
         assert st["max_abs"] <= tol, (n, st)
         worst = max(worst, st["rel_rms"])
-    # mixed: this model renders 2 x 10 rays through LeakyReLU layers of 32 units.  A pre-activation near zero whose sign
-    # differs from the fp32 reference's changes that unit's gradient by the 1/slope = 100x of the activation, and with it
-    # every gradient upstream.  Measured (profiles/r02/README.md, "SRT fixture under bf16"): between the module-by-module and
-    # the fused run the gradient entering render_mlp[3] (a LeakyReLU) agrees to 0.5 %, the gradient leaving it differs by
-    # 13 % -- forward activations agree to 0.5 % everywhere; worst rel-RMS against the reference 0.07 vs 0.42.  The bound
-    # below only guards against garbage; bf16 gradient parity of the blocks is pinned by
-    # test_srt_encoder_blocks_bf16_stream below (same upstream gradient, no activation masks) and by
-    # tests/test_gpu_block.py, fp32 parity by the mixed=False leg.
-    assert worst < (0.6 if mixed else 0.1)
+    assert worst < (0.4 if mixed else 0.1), worst
+    return worst
+
+
+@pytest.mark.parametrize("fixture,mixed", [("srt_ms_tiny", False), ("srt_ms_rays", False), ("srt_ms_rays", True)])
+def test_srt_model_matches_reference(fixture, mixed):
+    """Whole TransformingSRT forward + loss + backward on the HIP path under the reference's weights: rendered pixels,
+    per-sample MSE, PSNR parity and every parameter gradient.  fp32 on both fixtures (2 x 5 and 2 x 128 rays per scene);
+    bf16 autocast on the 256-ray one with FOUR TIMES the fp32 bounds.  (On the 10-ray fixture a bf16 run has no meaningful
+    gradient bound: the render MLP's LeakyReLU units whose near-zero pre-activation changes sign against the fp32 reference
+    change their gradient by 1 / slope = 100x, and with 10 rays one flip moves every gradient upstream by tens of percent --
+    profiles/r02/README.md, "SRT fixture under bf16"; with 256 rays the flips average out.)"""
+    from gta_amd import srt
+    d, model, data = _srt(fixture=fixture)
+    loss, terms = srt.compute_loss(model, data, mixed_prec=mixed)
+    loss.sum().backward()
+    torch.cuda.synchronize()
+    ref_loss = torch.from_numpy(d["loss"]).float()
+    ref_psnr = torch.from_numpy(d["psnr"]).float()
+    assert (loss.cpu() - ref_loss).abs().max() <= (4e-2 if mixed else 1e-2) * ref_loss.abs().max()
+    assert (terms["psnr"].detach().cpu() - ref_psnr).abs().max() <= (0.2 if mixed else 0.05)       # dB
+    _srt_grad_check(model, d, mixed)
+
+
+def test_srt_bf16_gradient_bound_is_not_vacuous():
+    """The mixed-precision bounds above reject a wrong decoder gradient: zeroed, doubled or sign-flipped by hand."""
+    from gta_amd import srt
+    d, model, data = _srt(fixture="srt_ms_rays")
+    loss, _ = srt.compute_loss(model, data, mixed_prec=True)
+    loss.sum().backward()
+    torch.cuda.synchronize()
+    _srt_grad_check(model, d, True)
+    names = [n for n, p in model.named_parameters() if n.startswith("decoder.") and n.endswith("weight") and p.grad.abs().max() > 0]
+    victims = [n for n in names if "transformer" in n][:1] + [n for n in names if "render_mlp" in n][:1]
+    assert len(victims) == 2, names
+    params = dict(model.named_parameters())
+    for n in victims:
+        keep = params[n].grad.clone()
+        for bad in (torch.zeros_like(keep), 2.0 * keep, -keep):
+            params[n].grad = bad
+            with pytest.raises(AssertionError):
+                _srt_grad_check(model, d, True)
+        params[n].grad = keep
+    _srt_grad_check(model, d, True)
 
 
 def test_srt_encoder_blocks_bf16_stream():

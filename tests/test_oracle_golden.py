@@ -140,13 +140,14 @@ def test_known_answer_properties():
     assert (out2 - ref).abs().max() < 1e-12
 
 
-def test_srt_wrapper_matches_reference():
-    """OracleSRT (encoder / decoder wrappers, gta path) against the reference TransformingSRT fixture: its own
-    weights, rendered pixels, per-sample loss, PSNR and every parameter gradient."""
+@pytest.mark.parametrize("fixture", ["srt_ms_tiny", "srt_ms_rays"])
+def test_srt_wrapper_matches_reference(fixture):
+    """OracleSRT (encoder / decoder wrappers, gta path) against the reference TransformingSRT fixtures (2 x 5 and 2 x 128 rays
+    per scene): its own weights, rendered pixels, per-sample loss, PSNR and every parameter gradient."""
     import ast
     import numpy as np
-    d, _ = G.load("srt_ms_tiny")
-    cfg = ast.literal_eval(str(np.load(G.GOLDEN + "/srt_ms_tiny.npz")["meta"]))
+    d, _ = G.load(fixture)
+    cfg = ast.literal_eval(str(np.load(G.GOLDEN + f"/{fixture}.npz")["meta"]))
     om = O.OracleSRT(cfg).double()
     sd = {k[len("param."):]: torch.from_numpy(v) for k, v in d.items() if k.startswith("param.")}
     om.load_state_dict(sd, strict=True)
