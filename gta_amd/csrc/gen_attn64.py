@@ -182,12 +182,13 @@ def branch(text, target, sem):
 
 
 class Gen:
-    def __init__(self, R=4, kread_early=True, sched=True, boundary_in_a=False, ablate=(), carry=False, dma_spread=False, fast_ends=False):
+    def __init__(self, R=4, kread_early=True, sched=True, boundary_in_a=False, ablate=(), carry=False, dma_spread=False, fast_ends=False, pk_sum=False):
         assert R in (2, 4)
         self.R, self.early, self.sched, self.bina = R, kread_early and R == 4, sched, boundary_in_a
         self.ablate = set(ablate)          # timing-only builds (wrong results): novalu, nods, nodma, nobar
         self.carry = carry                 # K' reads stay in flight across the step labels
         self.dma_spread = dma_spread       # boundary in phase A: one LDS-DMA piece per gap instead of three back to back
+        self.pk_sum = pk_sum               # row sums as v_pk_add_f32 on (even, odd) value pairs
         self.fast_ends = fast_ends         # O zeroed inside the head's MFMA gaps; the last step's softmax inside its P V MFMAs
         self.KRING, self.VRING = 0, R * IMG            # LDS byte offsets of the two rings
 
@@ -221,6 +222,15 @@ class Gen:
         x = S(p, rb, hh, r)
         return Ins(f"v_add_f32 {acc}, {acc}, {x}", "valu", [acc, x], [acc], ("add", p, rb, hh, r))
 
+    def add2(self, p, rb, hh, e2, acc):
+        """both row-sum adds of a pair of values as one packed add (the accumulators of a row block are a register pair)"""
+        b0 = int(S(p, rb, hh, 2 * e2)[1:])
+        a0 = int(acc[0][1:])
+        assert b0 % 2 == 0 and a0 % 2 == 0 and acc[1] == f"v{a0 + 1}"
+        x0, x1 = S(p, rb, hh, 2 * e2), S(p, rb, hh, 2 * e2 + 1)
+        return Ins(f"v_pk_add_f32 v[{a0}:{a0 + 1}], v[{a0}:{a0 + 1}], v[{b0}:{b0 + 1}]", "valu", [acc[0], acc[1], x0, x1], [acc[0], acc[1]],
+                   ("add2", p, rb, hh, 2 * e2))
+
     def pack(self, p, rb, hh, e2):
         # packed word k = e2 of half hh: values r = 2 e2, 2 e2 + 1 -> P[rb][hh][r >> 3][(r & 7) >> 1]
         r = 2 * e2
@@ -240,15 +250,18 @@ class Gen:
             out.append(self.exp(p, rb, hh, 2 * e2 + 1, tile_rel))
             if prev is not None:
                 prb, pe2 = prev
-                out.append(self.add(p, prb, hh, 2 * pe2, acc[prb][0]))
-                out.append(self.add(p, prb, hh, 2 * pe2 + 1, acc[prb][1]))
+                out += self.sums(p, prb, hh, pe2, acc[prb])
                 out.append(self.pack(p, prb, hh, pe2))
             prev = (rb, e2)
         prb, pe2 = prev
-        out.append(self.add(p, prb, hh, 2 * pe2, acc[prb][0]))
-        out.append(self.add(p, prb, hh, 2 * pe2 + 1, acc[prb][1]))
+        out += self.sums(p, prb, hh, pe2, acc[prb])
         out.append(self.pack(p, prb, hh, pe2))
         return out
+
+    def sums(self, p, rb, hh, e2, acc):
+        if self.pk_sum:
+            return [self.add2(p, rb, hh, e2, acc)]
+        return [self.add(p, rb, hh, 2 * e2, acc[0]), self.add(p, rb, hh, 2 * e2 + 1, acc[1])]
 
     # ---- the boundary of step copy c: tiles landed, everyone past the previous step, next DMA requests ------------
     def boundary(self, c, first_of_item=False):
@@ -400,7 +413,7 @@ class Gen:
 
     def steady(self, lst):
         """timing-only ablations of the steady-state steps (development: what each part of the stream costs)"""
-        drop = lambda x: (("novalu" in self.ablate and x.sem and x.sem[0] in ("exp", "add", "pack")) or
+        drop = lambda x: (("novalu" in self.ablate and x.sem and x.sem[0] in ("exp", "add", "add2", "pack")) or
                           ("nods" in self.ablate and x.kind == "ds") or ("nodma" in self.ablate and x.kind == "dma") or
                           ("nobar" in self.ablate and x.kind == "barrier") or ("nomfma" in self.ablate and x.kind == "mfma"))
         return [x for x in lst if not drop(x)]
@@ -916,6 +929,19 @@ class Sim:
                 sums[("sum", x, t)] = 1
                 sums[(t, rb)] = sums.get((t, rb), 0) + 1
                 v[1] -= 1
+            elif op == "add2":
+                p, rb, hh, r_ = sem[1:]
+                for rr in (r_, r_ + 1):
+                    x = S(p, rb, hh, rr)
+                    v = regs.get(x)
+                    if v is None or v[0][5] != "exp":
+                        self.fail(f"{x} summed before its exp", cur)
+                    t = v[0][1]
+                    if ("sum", x, t) in sums:
+                        self.fail(f"{x} of tile {t} summed twice", cur)
+                    sums[("sum", x, t)] = 1
+                    sums[(t, rb)] = sums.get((t, rb), 0) + 1
+                    v[1] -= 1
             elif op == "pack":
                 p, rb, hh, tt, w = sem[1:]
                 r0 = 8 * tt + 2 * w
@@ -1106,13 +1132,13 @@ if __name__ == "__main__":
     best = BEST
     variants = production_variants() if not a.plain else [("GTA_ATTN64_LOOP_V0", dict(sched=False)), ("GTA_ATTN64_LOOP_V1", dict(sched=False))]
     if a.dev:     # development variants (gta_fwd64.hip -DGTA_ATTN64_DEV, GTA_ATTN64_VARIANT=n): schedules and timing-only ablations
-        variants += [("GTA_ATTN64_LOOP_V2", dict(carry=True)),
-                     ("GTA_ATTN64_LOOP_V3", dict(boundary_in_a=True, carry=True)),
-                     ("GTA_ATTN64_LOOP_V4", dict(boundary_in_a=True, carry=True, dma_spread=True)),
-                     ("GTA_ATTN64_LOOP_V5", dict(boundary_in_a=True, carry=True, fast_ends=True)),
-                     ("GTA_ATTN64_LOOP_V6", dict(best)),
+        variants += [("GTA_ATTN64_LOOP_V2", dict(best, pk_sum=True)),
+                     ("GTA_ATTN64_LOOP_V3", dict(best, ablate=("novalu",))),
+                     ("GTA_ATTN64_LOOP_V4", dict(best, ablate=("nods",))),
+                     ("GTA_ATTN64_LOOP_V5", dict(best, ablate=("nodma", "nobar"))),
+                     ("GTA_ATTN64_LOOP_V6", dict(best, ablate=("novalu", "nods", "nodma", "nobar"))),
                      ("GTA_ATTN64_LOOP_V7", dict(best, ablate=("nomfma",))),
-                     ("GTA_ATTN64_LOOP_V8", dict(best, ablate=("novalu", "nods", "nodma", "nobar")))]
+                     ("GTA_ATTN64_LOOP_V8", dict(best, boundary_in_a=False))]
     for name, kw in variants:
         gen = Gen(R=a.ring, kread_early=not a.no_early_k, **kw)
         prog = gen.program()
