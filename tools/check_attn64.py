@@ -71,6 +71,7 @@ def localise(a, b, tag):
 def parity_case(name, B, H, Nq, Pq, Nk, Pk, dtype, qmul=None, oracle=True):
     host, dev = build(B, H, Nq, Pq, Nk, Pk, dtype, qmul=qmul)
     os.environ.pop("GTA_ATTN64_VARIANT", None)
+    os.environ.pop("GTA_ATTN64_COAL", None)
     fn_new, o_new, l_new, ws = run(dev, 0)
     fn_new()
     torch.cuda.synchronize()
@@ -82,6 +83,7 @@ def parity_case(name, B, H, Nq, Pq, Nk, Pk, dtype, qmul=None, oracle=True):
     fn_pl()
     torch.cuda.synchronize()
     os.environ.pop("GTA_ATTN64_VARIANT", None)
+    os.environ.pop("GTA_ATTN64_COAL", None)
     print(f"== {name}: B={B} H={H} Tq={Nq * Pq} Tk={Nk * Pk} {dtype}")
     ok = True
     e_no = (o_new.float() - o_old.float()).abs().max().item()
@@ -137,6 +139,7 @@ def time_ab(name, B, H, Nq, Pq, Nk, Pk):
         os.environ["GTA_ATTN64_VARIANT"] = "1"
         res["plain"].append(t(plain, n=4, warm=1))
     os.environ.pop("GTA_ATTN64_VARIANT", None)
+    os.environ.pop("GTA_ATTN64_COAL", None)
     flops = 4.0 * B * H * Nq * Pq * Nk * Pk * 96
     print(f"== time {name}: " + "   ".join(f"{n}: median {sorted(r)[3] * 1e3:7.1f} us min {min(r) * 1e3:7.1f} ({flops / sorted(r)[3] / 1e9:6.1f} TF)"
                                             for n, r in res.items()), flush=True)
@@ -221,15 +224,22 @@ def variants(which, B=32):
         span_us = ((P[:, 6].max() - P[:, 5].min()) / 100.0).item()
         ph = [(P[:, b_] - P[:, a_]).mean().item() for a_, b_ in ((0, 1), (1, 2), (2, 3), (3, 4), (0, 4), (3, 7))]
         return ghz, span_us, ph
+    def setvar(v):                  # "3" = generated variant 3; "0:0" = variant 0 without the coalesced item I/O (dev builds)
+        a, b = (str(v).split(":") + [""])[:2]      # variant : coalesced item I/O (0 / 1; development builds)
+        os.environ["GTA_ATTN64_VARIANT"] = a
+        if b:
+            os.environ["GTA_ATTN64_COAL"] = b
+        else:
+            os.environ.pop("GTA_ATTN64_COAL", None)
     times = {v: [] for v in which}
     times["rows32"] = []
     for _ in range(5):
         for v in which:
-            os.environ["GTA_ATTN64_VARIANT"] = str(v)
+            setvar(v)
             times[v].append(t(devs[5][0]))
         times["rows32"].append(t(devs[5][1]))
     for v in which:
-        os.environ["GTA_ATTN64_VARIANT"] = str(v)
+        setvar(v)
         ghz, span_us, ph = stamps(devs[5][0], 256)
         _, _, ph2 = stamps(devs[10][0], 256)
         r = sorted(times[v])
@@ -237,6 +247,7 @@ def variants(which, B=32):
         print(f"variant {v}: {r[2]:7.1f} us median ({r[0]:.1f} min) | {span_us:6.1f} us x {ghz:.3f} GHz = {span_us * ghz:6.1f}k cyc | item: "
               f"load {ph[0]:5.0f} rho_q {ph[1]:5.0f} loop {ph[2]:6.0f} epi {ph[3]:5.0f} (request issued at +{ph[5]:5.0f}) total {ph[4]:6.0f} | STEP {slope:5.0f} cyc/tile, head+tail {ph[2] - 20 * slope:5.0f}", flush=True)
     os.environ.pop("GTA_ATTN64_VARIANT", None)
+    os.environ.pop("GTA_ATTN64_COAL", None)
     ghz, span_us, ph = stamps(devs[5][1], 128)
     _, _, ph2 = stamps(devs[10][1], 128)
     r = sorted(times["rows32"])
@@ -264,6 +275,6 @@ if __name__ == "__main__":
     if which == "timeline":
         timeline()
     if which == "variants":
-        variants([int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "0,2,3,4,5,6,7,8").split(",")])
+        variants((sys.argv[2] if len(sys.argv) > 2 else "0,2,3,4,5,6,7,8").split(","))
     print("ALL OK" if ok else "FAILURES")
     sys.exit(0 if ok else 1)
