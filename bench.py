@@ -246,8 +246,9 @@ def main():
                     help="also time one whole pre-LN layer around the operator (SURVEY 8 f1: the fused block of libgta_block.so "
                          "against the module-by-module path), forward and forward+backward; reported as `block_layer`, not "
                          "part of `value`; 0 = skip")
-    ap.add_argument("--kv-mode", dest="kv_mode", default="prepass", choices=["prepass", "fused"],
-                    help="execution plan of gta_attn_fwd (see include/gta_hip.h)")
+    ap.add_argument("--kv-mode", dest="kv_mode", default="prepass", choices=["prepass", "fused", "prepass_rows32"],
+                    help="execution plan of gta_attn_fwd (see include/gta_hip.h); prepass_rows32 = GTA_FLAG_ROWS32: the 32-rows-per-wave "
+                         "attention kernel where the 64-rows one would run (A/B)")
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing check without a GPU: same launch contract, rendezvous (gloo), barriers, MAX-over-ranks and "
                          "JSON line, the step itself replaced by a host no-op (tests/test_ddp_gloo.py runs this at world size 2)")
@@ -290,7 +291,7 @@ def main():
     reps_k = plan.RepPlan(B, Nk, Pk, so3_deg, so2, device=device) if (need_view and f_dims.get("so2", 0) > 0) else None
     reps_q = plan.RepPlan(B, Nq, Pq, so3_deg, so2, device=device) if (reps_k is not None and cross) else None
     fwd = plan.ForwardPlan(q, k, v, f_dims, so3_degree=so3_deg, Nq=Nq if need_view else 1, Nk=Nk if need_view else 1,
-                           flags=native.FLAG_FUSED_KV if fused else 0)
+                           flags=native.FLAG_FUSED_KV if fused else native.FLAG_ROWS32 if args.kv_mode == "prepass_rows32" else 0)
     n_it, rows_it = ctypes.c_int32(0), ctypes.c_int32(0)
     kname = (L.gta_debug_attention_kernel(ctypes.byref(fwd.desc), ctypes.byref(n_it), ctypes.byref(rows_it)) or b"").decode()
     n_samp = args.steps if args.kernel_samples <= 0 else min(args.kernel_samples, args.steps)

@@ -30,11 +30,11 @@ Register map (dh = 96: KS = 6 k-steps, DB = 3 channel blocks, RB = 2 row blocks 
 import argparse
 import sys
 
-KS, DB, RB = 6, 3, 2
-CHP = 12
-IMG = 64 * CHP * 16          # one K' or V' tile image (12288 B)
+RB = 2
+KS, DB, CHP = 6, 3, 12       # dh = 96 (configure() below: dh = 64 -> 4, 2, 8)
+IMG = 64 * CHP * 16          # one K' or V' tile image (12288 B at dh = 96, 8192 B at dh = 64)
 TILE = 2 * IMG               # [K' image | V' image] of one key tile in HBM
-WSHARE = IMG // 4            # a wave's share of an image (3 pieces of 1 KiB)
+NP = IMG // 4096             # 1-KiB LDS-DMA pieces of an image per wave (four waves)
 THR_BITS = 0x42c00000        # BOUND_THR = 96.0f (gta_flash_common.h)
 
 
@@ -94,37 +94,63 @@ def Oregs(rb, d):
     return [f"a{AB + 16 * (rb * DB + d) + i}" for i in range(16)]
 
 
+def _qb():
+    return AB + 16 * RB * DB             # Q' fragments behind the O accumulators
+
+
+def _kb():
+    return _qb() + 4 * RB * KS
+
+
+def _vb():
+    return _kb() + 8 * KS
+
+
 def Q(rb, ks):
-    b = AB + 96 + 4 * (rb * KS + ks)
+    b = _qb() + 4 * (rb * KS + ks)
     return f"a[{b}:{b + 3}]"
 
 
 def Qregs(rb, ks):
-    return [f"a{AB + 96 + 4 * (rb * KS + ks) + i}" for i in range(4)]
+    return [f"a{_qb() + 4 * (rb * KS + ks) + i}" for i in range(4)]
 
 
 def K(ks, hh):
-    b = AB + 144 + 4 * (ks * 2 + hh)
+    b = _kb() + 4 * (ks * 2 + hh)
     return f"a[{b}:{b + 3}]"
 
 
 def Kregs(ks, hh):
-    return [f"a{AB + 144 + 4 * (ks * 2 + hh) + i}" for i in range(4)]
+    return [f"a{_kb() + 4 * (ks * 2 + hh) + i}" for i in range(4)]
 
 
 def V(sl, d, half=None):
-    b = AB + 192 + 4 * ((sl % NVS) * DB + d)
+    b = _vb() + 4 * ((sl % NVS) * DB + d)
     return f"a[{b}:{b + 3}]" if half is None else f"a[{b + 2 * half}:{b + 2 * half + 1}]"
 
 
 def Vregs(sl, d, half=None):
-    b = AB + 192 + 4 * ((sl % NVS) * DB + d)
+    b = _vb() + 4 * ((sl % NVS) * DB + d)
     return [f"a{b + i}" for i in range(4)] if half is None else [f"a{b + 2 * half}", f"a{b + 2 * half + 1}"]
 
 
 # low literal VGPRs
 KOFF = [f"v{32 + i}" for i in range(KS)]             # K' fragment byte offsets (ring base 0)
 VOFF = [[f"v{38 + 2 * d + h}" for h in range(2)] for d in range(DB)]   # V' transpose-read offsets (V ring base folded in)
+
+
+def configure(dh):
+    """head dimension of the stream: 96 (MSN) or 64 (CLEVR-TR, the 2-D DiT branch).  The accumulator-file map is laid out from the
+    counts (O | Q' | K' | V'^T); the vector half does not depend on dh."""
+    global KS, DB, CHP, IMG, TILE, NP, KOFF, VOFF
+    assert dh in (64, 96)
+    KS, DB, CHP = dh // 16, dh // 32, dh // 8
+    IMG = 64 * CHP * 16
+    TILE = 2 * IMG
+    NP = IMG // 4096
+    KOFF = [f"v{32 + i}" for i in range(KS)]
+    VOFF = [[f"v{38 + 2 * d + h}" for h in range(2)] for d in range(DB)]
+    assert _vb() + 4 * NVS * DB <= 256
 LA = [[f"v{44 + 2 * rb + e}" for e in range(2)] for rb in range(RB)]   # row sums of the hh = 1 halves (phase A), even / odd
 LB = [[f"v{48 + 2 * rb + e}" for e in range(2)] for rb in range(RB)]   # row sums of the hh = 0 halves (phase B)
 MRUN = [f"v{52 + rb}" for rb in range(RB)]
@@ -182,13 +208,15 @@ def branch(text, target, sem):
 
 
 class Gen:
-    def __init__(self, R=4, kread_early=True, sched=True, boundary_in_a=False, ablate=(), carry=False, dma_spread=False, fast_ends=False, pk_sum=False):
+    def __init__(self, R=4, kread_early=True, sched=True, boundary_in_a=False, ablate=(), carry=False, dma_spread=False, fast_ends=False, pk_sum=False,
+                 dot_sum=False):
         assert R in (2, 4)
         self.R, self.early, self.sched, self.bina = R, kread_early and R == 4, sched, boundary_in_a
         self.ablate = set(ablate)          # timing-only builds (wrong results): novalu, nods, nodma, nobar
         self.carry = carry                 # K' reads stay in flight across the step labels
         self.dma_spread = dma_spread       # boundary in phase A: one LDS-DMA piece per gap instead of three back to back
         self.pk_sum = pk_sum               # row sums as v_pk_add_f32 on (even, odd) value pairs
+        self.dot_sum = dot_sum             # row sums from the PACKED words: one v_dot2c_f32_bf16 (x 1.0, 1.0) per pair of scores
         self.fast_ends = fast_ends         # O zeroed inside the head's MFMA gaps; the last step's softmax inside its P V MFMAs
         self.KRING, self.VRING = 0, R * IMG            # LDS byte offsets of the two rings
 
@@ -244,7 +272,7 @@ class Gen:
         acc = LA if phase == "A" else LB
         out = []
         pairs = [(rb, e2) for e2 in range(8) for rb in range(RB)]      # interleave the row blocks
-        prev = None
+        prev = prev2 = None
         for rb, e2 in pairs:
             out.append(self.exp(p, rb, hh, 2 * e2, tile_rel))
             out.append(self.exp(p, rb, hh, 2 * e2 + 1, tile_rel))
@@ -252,13 +280,28 @@ class Gen:
                 prb, pe2 = prev
                 out += self.sums(p, prb, hh, pe2, acc[prb])
                 out.append(self.pack(p, prb, hh, pe2))
-            prev = (rb, e2)
+            if self.dot_sum and prev2 is not None:
+                out.append(self.dotsum(p, prev2[0], hh, prev2[1], acc[prev2[0]]))
+            prev2, prev = prev, (rb, e2)
         prb, pe2 = prev
         out += self.sums(p, prb, hh, pe2, acc[prb])
         out.append(self.pack(p, prb, hh, pe2))
+        if self.dot_sum:
+            out.append(self.dotsum(p, prev2[0], hh, prev2[1], acc[prev2[0]]))
+            out.append(self.dotsum(p, prb, hh, pe2, acc[prb]))
         return out
 
+    def dotsum(self, p, rb, hh, e2, acc):
+        """l += lo + hi of packed word e2 (bf16 pair x (1.0, 1.0) as a literal): the row sum counts exactly the P the matrix core
+        multiplies with V', in one instruction per two scores"""
+        r = 2 * e2
+        w = P(p, rb, hh, r >> 3, (r & 7) >> 1)
+        a = acc[e2 & 1]
+        return Ins(f"v_dot2c_f32_bf16 {a}, 0x3f803f80, {w}", "valu", [a, w], [a], ("dotsum", p, rb, hh, r >> 3, (r & 7) >> 1))
+
     def sums(self, p, rb, hh, e2, acc):
+        if self.dot_sum:
+            return []
         if self.pk_sum:
             return [self.add2(p, rb, hh, e2, acc)]
         return [self.add(p, rb, hh, 2 * e2, acc[0]), self.add(p, rb, hh, 2 * e2 + 1, acc[1])]
@@ -269,7 +312,7 @@ class Gen:
         out = []
         # landed before this step: with R = 4 everything but the last two boundaries' requests (K'(j+2), V'(j+1) and older);
         # with R = 2 everything (K'(j+1), V'(j) were requested one boundary ago)
-        out.append(vmw(6 if R == 4 else 0))
+        out.append(vmw(2 * NP if R == 4 else 0))
         out.append(barrier())
         out += self.dma_requests(c)
         return out
@@ -288,12 +331,12 @@ class Gen:
         kslot, vslot = c, (c - 1) % R
         out.append(salu(f"s_add_u32 m0, {S_WOFF}, {self.KRING + kslot * IMG}", [S_WOFF], ["m0"]))
         out.append(nop(1))
-        for i in range(3):
+        for i in range(NP):
             out.append(Ins(f"global_load_lds_dwordx4 %[lane16], {S_KPTR} offset:{1024 * i}", "dma", ["m0", S_KPTR], [],
                            ("dma", "K", kslot, i)))
         out.append(salu(f"s_add_u32 m0, {S_WOFF}, {self.VRING + vslot * IMG}", [S_WOFF], ["m0"]))
         out.append(nop(1))
-        for i in range(3):
+        for i in range(NP):
             out.append(Ins(f"global_load_lds_dwordx4 %[lane16], {S_VPTR} offset:{1024 * i}", "dma", ["m0", S_VPTR], [],
                            ("dma", "V", vslot, i)))
         out.append(salu(f"s_add_u32 {S_KPTR_LO}, {S_KPTR_LO}, {TILE}", [S_KPTR_LO], [S_KPTR_LO, "scc"], ("kadv", 0)))
@@ -337,7 +380,7 @@ class Gen:
                 gaps[2 * i].append(kr)           # fragment (ks, hh), ks >= 2, is requested in gap 2 i and used from MFMA 4 ks + 2 hh >= 8
         # V' reads of slabs 0, 1: one per gap from gap 10 on (they only have to be there for phase B)
         for i, vr in enumerate(vreads):
-            gaps[10 + i].append(vr)
+            gaps[len(mf) - len(vreads) - 2 + i].append(vr)
         d0 = 2
         if with_boundary:
             # the step's boundary inside the first gaps: nothing this phase reads depends on it (K'(j+1) fragments are in
@@ -347,8 +390,8 @@ class Gen:
             cut = [i for i, x in enumerate(bnd) if x.kind == "salu" and "m0" in x.wr]
             if self.dma_spread:         # one piece per gap (a piece costs more issue time among other VMEM / LDS requests)
                 a0, b0 = cut[0], cut[1]
-                groups = [bnd[:a0], bnd[a0:a0 + 3], bnd[a0 + 3:a0 + 4], bnd[a0 + 4:b0], bnd[b0:b0 + 3], bnd[b0 + 3:b0 + 4], bnd[b0 + 4:b0 + 5],
-                          bnd[b0 + 5:]]
+                groups = [bnd[:a0], bnd[a0:a0 + 3]] + [bnd[a0 + 2 + i:a0 + 3 + i] for i in range(1, NP - 1)] + [bnd[a0 + 1 + NP:b0], bnd[b0:b0 + 3]] + \
+                         [bnd[b0 + 2 + i:b0 + 3 + i] for i in range(1, NP)] + [bnd[b0 + 2 + NP:]]
             else:
                 groups = [bnd[:cut[0]], bnd[cut[0]:cut[1]], bnd[cut[1]:cut[1] + 5], bnd[cut[1] + 5:]]
             for gi, grp in enumerate(groups):
@@ -360,7 +403,7 @@ class Gen:
         self.deal(valu, gaps, range(0, len(mf)))
         if self.early:
             pre.append(ready([r for hh in range(2) for r in Kregs(0, hh) + Kregs(1, hh)]))
-            for ks in (2, 4):
+            for ks in range(2, KS, 2):
                 gaps[4 * ks - 1].append(ready([r for hh in range(2) for r in Kregs(ks, hh) + Kregs(ks + 1, hh)]))
         return self.weave(pre, mf, gaps) + dec_br
 
@@ -382,7 +425,7 @@ class Gen:
             gaps[i].append(vr)
         # K' reads of tile j + 2: one per gap in the second half
         for i, kr in enumerate(kreads):
-            gaps[12 + i].append(kr)
+            gaps[len(mf) - len(kreads) + i].append(kr)
         # (gaps 0, 1 stay free of softmax work: the S' accumulators of phase A's last MFMAs need 12 states before the VALU reads them)
         self.deal(valu, gaps, range(2, len(mf)))
         pre.append(ready([r for d in range(DB) for r in Vregs(0, d)]))
@@ -413,7 +456,7 @@ class Gen:
 
     def steady(self, lst):
         """timing-only ablations of the steady-state steps (development: what each part of the stream costs)"""
-        drop = lambda x: (("novalu" in self.ablate and x.sem and x.sem[0] in ("exp", "add", "add2", "pack")) or
+        drop = lambda x: (("novalu" in self.ablate and x.sem and x.sem[0] in ("exp", "add", "add2", "pack", "dotsum")) or
                           ("nods" in self.ablate and x.kind == "ds") or ("nodma" in self.ablate and x.kind == "dma") or
                           ("nobar" in self.ablate and x.kind == "barrier") or ("nomfma" in self.ablate and x.kind == "mfma"))
         return [x for x in lst if not drop(x)]
@@ -721,10 +764,10 @@ class Sim:
         stats = {"instr": 0, "mfma": 0}
         # kernel prologue's requests of the first item: K'(0..R-1), V'(0..R-2)
         for t in range(R):
-            for i in range(3):
+            for i in range(NP):
                 self.vmq.append(("K", t % R, i, (0, t)))
         for t in range(R - 1):
-            for i in range(3):
+            for i in range(NP):
                 self.vmq.append(("V", t % R, i, (0, t)))
         kptr, vptr = (0, R), (0, R - 1)
         for item in range(self.items):
@@ -750,6 +793,7 @@ class Sim:
         msver = [0, 0]
         o_done = {(rb, d): set() for rb in range(RB) for d in range(DB)}
         sums = {}
+        packed_from = {}
         exps = {}
         flags = {"scc": 0, "vcc": 0}
         ksel_done = vsel_done = False
@@ -811,7 +855,7 @@ class Sim:
                 # every wave has waited for its share of the same tiles: a tile whose three pieces of THIS wave have landed
                 # is complete; the slots named by the requests that follow are free (checked at the request)
                 for key, (tile, pieces) in list(self.pending_tile.items()):
-                    if len(pieces) == 3:
+                    if len(pieces) == NP:
                         (self.kslot if key[0] == "K" else self.vslot)[key[1]] = tile
                         del self.pending_tile[key]
             elif op == "item_begin":
@@ -915,7 +959,7 @@ class Sim:
                 v = usereg(x, ("S", t, rb, hh, r_, "raw"), cur)
                 if v[6] != msver[rb]:
                     self.fail(f"{x}: score relative to an old running max (version {v[6]} vs {msver[rb]})", cur)
-                regs[x] = [("S", t, rb, hh, r_, "exp"), 2]         # one add, one pack
+                regs[x] = [("S", t, rb, hh, r_, "exp"), 1 if g.dot_sum else 2]         # one add (or none: summed as a packed word), one pack
                 exps[(t, rb)] = exps.get((t, rb), 0) + 1
             elif op == "add":
                 p, rb, hh, r_ = sem[1:]
@@ -952,7 +996,19 @@ class Sim:
                     self.fail(f"pack of {a}, {b} before both exps", cur)
                 ta[1] -= 1
                 tb[1] -= 1
-                setreg(P(p, rb, hh, tt, w), ("P", ta[0][1], rb, hh, tt, w), DB)
+                setreg(P(p, rb, hh, tt, w), ("P", ta[0][1], rb, hh, tt, w), DB + (1 if g.dot_sum else 0))
+                if g.dot_sum:
+                    packed_from[P(p, rb, hh, tt, w)] = (a, b, ta[0][1])
+            elif op == "dotsum":
+                p, rb, hh, tt, w = sem[1:]
+                wreg = P(p, rb, hh, tt, w)
+                a, b, t = packed_from.get(wreg, (None, None, None))
+                usereg(wreg, ("P", t, rb, hh, tt, w), cur)
+                for x in (a, b):
+                    if ("sum", x, t) in sums:
+                        self.fail(f"{x} of tile {t} summed twice", cur)
+                    sums[("sum", x, t)] = 1
+                    sums[(t, rb)] = sums.get((t, rb), 0) + 1
             elif op == "pv":
                 p, sl, d, rb = sem[1:]
                 t = sc["j"]
@@ -1115,8 +1171,20 @@ BEST = dict(boundary_in_a=True, carry=True, fast_ends=True, dma_spread=True)    
 
 
 def production_variants():
-    """what gta_attn64_loop.inc holds: V0 = the shipped schedule, V1 = the same instructions un-interleaved (GTA_ATTN64_VARIANT=1)"""
-    return [("GTA_ATTN64_LOOP_V0", dict(BEST)), ("GTA_ATTN64_LOOP_V1", dict(sched=False))]
+    """what gta_attn64_loop.inc holds, as (macro, dh, options): V0 = the shipped schedule, V1 = the same instructions un-interleaved
+    (GTA_ATTN64_VARIANT=1), for dh = 96 and for dh = 64"""
+    return [("GTA_ATTN64_LOOP_V0", 96, dict(BEST)), ("GTA_ATTN64_LOOP_V1", 96, dict(sched=False)),
+            ("GTA_ATTN64_LOOP64_V0", 64, dict(BEST)), ("GTA_ATTN64_LOOP64_V1", 64, dict(sched=False))]
+
+
+def build_program(dh, kw, R=4, kread_early=True, check=True, verbose=False):
+    """the stream for head dimension dh (the module's layout constants are set for it while it is built and simulated)"""
+    configure(dh)
+    gen = Gen(R=R, kread_early=kread_early, **kw)
+    prog = gen.program()
+    if check and not kw.get("ablate"):
+        check_all(gen, prog, verbose)
+    return gen, prog
 
 
 if __name__ == "__main__":
@@ -1130,20 +1198,18 @@ if __name__ == "__main__":
     a = ap.parse_args()
     progs = {}
     best = BEST
-    variants = production_variants() if not a.plain else [("GTA_ATTN64_LOOP_V0", dict(sched=False)), ("GTA_ATTN64_LOOP_V1", dict(sched=False))]
+    variants = production_variants() if not a.plain else [(n, dh, dict(sched=False)) for n, dh, _ in production_variants()]
     if a.dev:     # development variants (gta_fwd64.hip -DGTA_ATTN64_DEV, GTA_ATTN64_VARIANT=n): schedules and timing-only ablations
-        variants += [("GTA_ATTN64_LOOP_V2", dict(best, pk_sum=True)),
-                     ("GTA_ATTN64_LOOP_V3", dict(best, ablate=("novalu",))),
-                     ("GTA_ATTN64_LOOP_V4", dict(best, ablate=("nods",))),
-                     ("GTA_ATTN64_LOOP_V5", dict(best, ablate=("nodma", "nobar"))),
-                     ("GTA_ATTN64_LOOP_V6", dict(best, ablate=("novalu", "nods", "nodma", "nobar"))),
-                     ("GTA_ATTN64_LOOP_V7", dict(best, ablate=("nomfma",))),
-                     ("GTA_ATTN64_LOOP_V8", dict(best, boundary_in_a=False))]
-    for name, kw in variants:
-        gen = Gen(R=a.ring, kread_early=not a.no_early_k, **kw)
-        prog = gen.program()
-        if not kw.get("ablate"):
-            check_all(gen, prog, a.verbose)
+        for dh, pre in ((96, "GTA_ATTN64_LOOP"), (64, "GTA_ATTN64_LOOP64")):
+            variants += [(f"{pre}_V2", dh, dict(best, dot_sum=True)),
+                         (f"{pre}_V3", dh, dict(best, ablate=("novalu",))),
+                         (f"{pre}_V4", dh, dict(best, ablate=("nods",))),
+                         (f"{pre}_V5", dh, dict(best, ablate=("nodma", "nobar"))),
+                         (f"{pre}_V6", dh, dict(best, ablate=("novalu", "nods", "nodma", "nobar"))),
+                         (f"{pre}_V7", dh, dict(best, ablate=("nomfma",))),
+                         (f"{pre}_V8", dh, dict(best, boundary_in_a=False))]
+    for name, dh, kw in variants:
+        gen, prog = build_program(dh, kw, R=a.ring, kread_early=not a.no_early_k, verbose=a.verbose)
         if a.verbose:
             print(name, kw)
             print("\n".join(stats_of(gen, prog)))

@@ -18,7 +18,7 @@ int gta_fwd_lds_bytes(int dhp, int esz);
 int gta_fwd_dispatch(const GtaFwdParams& p, int dhp, int esz, bool dma, int n_wg, hipStream_t stream);
 long gta_fwd2_workspace_bytes(int B, int H, int Tk, int dhp, int Nq);
 long gta_fwd2_qtiles_offset(int B, int H, int Tk, int dhp);
-int gta_fwd2_rows_per_item(const GtaFwdParams& p, int dhp);                   // 256: gta_attn64_kernel, 128: gta_fwd2_kernel
+int gta_fwd2_rows_per_item(const GtaFwdParams& p, int dhp, int esz);                   // 256: gta_attn64_kernel, 128: gta_fwd2_kernel
 long gta_fwd2_image_bytes(int B, int H, int Tk, int dhp);
 int gta_fwd2_lds_bytes(int dhp, int nq);
 int gta_fwd2_dispatch(GtaFwdParams& p, int dhp, int esz, bool run_prep, bool run_flash, hipStream_t stream);
@@ -148,9 +148,9 @@ extern "C" const char* gta_debug_attention_kernel(const GtaAttnDesc* d, int32_t*
     GtaFwdParams p;
     memset(&p, 0, sizeof p);
     if (build_ctab(d, p.ctab)) return "";
-    p.Tq = d->Tq; p.Tk = d->Tk; p.dh = d->dh; p.flags = d->flags; p.kn = (float*)1;
+    p.Tq = d->Tq; p.Tk = d->Tk; p.dh = d->dh; p.flags = d->flags; p.kn = (float*)1; p.cs_q = d->d_so2 ? (const float*)1 : nullptr;
     const bool two_stage = !(d->flags & (GTA_FLAG_FUSED_KV | GTA_FLAG_FP32_PRODUCTS | GTA_FLAG_PRETRANSFORMED));
-    const int rows = !two_stage ? 128 : gta_fwd2_rows_per_item(p, padded_dh(d->dh));
+    const int rows = !two_stage ? 128 : gta_fwd2_rows_per_item(p, padded_dh(d->dh), d->dtype == GTA_DTYPE_BF16 ? 2 : 4);
     if (n_items) *n_items = d->B * d->H * ((d->Tq + rows - 1) / rows);
     if (rows_per_item) *rows_per_item = rows;
     return !two_stage ? "gta_fwd_kernel" : rows == 256 ? "gta_attn64_kernel" : "gta_fwd2_kernel";

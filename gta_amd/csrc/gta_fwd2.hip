@@ -36,9 +36,9 @@
 #include "gta_flash_common.h"
 
 int gta_prep_dispatch(const GtaFwdParams& p, int dhp, int esz, hipStream_t stream);                  // gta_prep.hip
-bool gta_attn64_takes(const GtaFwdParams& p, int dhp, int layout);                                  // gta_fwd64.hip
+bool gta_attn64_takes(const GtaFwdParams& p, int dhp, int layout, int esz);                                  // gta_fwd64.hip
 int gta_qtiles_dispatch(const GtaFwdParams& p, hipStream_t stream);
-int gta_attn64_dispatch(const GtaFwdParams& p, int esz, hipStream_t stream);
+int gta_attn64_dispatch(const GtaFwdParams& p, int esz, int layout, hipStream_t stream);
 
 // profiling hook (not part of the product ABI, see gta_hip.h): events for the NEXT attention-kernel launch of this thread
 thread_local void* gta_dbg_fwd_ev_start = nullptr;      // (also read by gta_fwd64.hip)
@@ -787,12 +787,12 @@ static int layout_of(const GtaFwdParams& p, int dhp) {
     return GTA_LAYOUT_GENERIC;
 }
 
-int gta_fwd2_rows_per_item(const GtaFwdParams& p, int dhp) { return gta_attn64_takes(p, dhp, layout_of(p, dhp)) ? 256 : 128; }
+int gta_fwd2_rows_per_item(const GtaFwdParams& p, int dhp, int esz) { return gta_attn64_takes(p, dhp, layout_of(p, dhp), esz) ? 256 : 128; }
 
 // Compile-time layouts exist for the shipped configs; others read the chunk table.
 template <int DHP, int ESZ>
 static int launch_flash(const GtaFwdParams& p, hipStream_t stream) {
-    if (gta_attn64_takes(p, DHP, layout_of(p, DHP))) return gta_attn64_dispatch(p, ESZ, stream);   // 64 rows per wave (gta_fwd64.hip)
+    if (gta_attn64_takes(p, DHP, layout_of(p, DHP), ESZ)) return gta_attn64_dispatch(p, ESZ, layout_of(p, DHP), stream);   // 64 rows per wave (gta_fwd64.hip)
     switch (layout_of(p, DHP)) {
         case GTA_LAYOUT_MS:  if (DHP == 96) return launch_fwd2<DHP, ESZ, (DHP == 96 ? GTA_LAYOUT_MS : GTA_LAYOUT_GENERIC)>(p, stream); break;
         case GTA_LAYOUT_CL:  if (DHP == 64) return launch_fwd2<DHP, ESZ, (DHP == 64 ? GTA_LAYOUT_CL : GTA_LAYOUT_GENERIC)>(p, stream); break;
@@ -809,7 +809,7 @@ int gta_fwd2_dispatch(GtaFwdParams& p, int dhp, int esz, bool run_prep, bool run
     p.nrec = 128 / p.Pq + 2 < p.Nq ? 128 / p.Pq + 2 : p.Nq;
     int rc = GTA_OK;
     // the q-side rep tiles (rho_q / rho_q^-1 on the matrix cores) only where the 64-rows-per-wave kernel will use them
-    if (!(p.qtiles && esz == 2 && run_flash && gta_attn64_takes(p, dhp, layout_of(p, dhp)))) p.qtiles = nullptr;
+    if (!(p.qtiles && esz == 2 && run_flash && gta_attn64_takes(p, dhp, layout_of(p, dhp), esz))) p.qtiles = nullptr;
     if (run_prep) rc = gta_prep_dispatch(p, dhp, esz, stream);
     else if (p.qtiles) rc = gta_qtiles_dispatch(p, stream);
     if (rc != GTA_OK || !run_flash) return rc;

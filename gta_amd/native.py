@@ -114,6 +114,14 @@ def lib():
     return _lib
 
 
+def attention_kernel(desc):
+    """(kernel name, work items, query rows per item) of the attention kernel gta_attn_fwd launches for desc when it is given a
+    workspace (include/gta_hip.h: gta_debug_attention_kernel)"""
+    n, rows = c_int32(0), c_int32(0)
+    name = lib().gta_debug_attention_kernel(ctypes.byref(desc), ctypes.byref(n), ctypes.byref(rows)) or b""
+    return name.decode(), n.value, rows.value
+
+
 def check(rc: int, what: str):
     if rc != 0:
         raise GtaError(f"{what} failed ({rc}): {lib().gta_strerror(rc).decode()}")

@@ -219,13 +219,11 @@ def test_attn64_loop_generator_checks_and_is_current():
     g = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(g)
     progs = {}
-    for name, kw in g.production_variants():
-        gen = g.Gen(**kw)
-        prog = gen.program()
-        g.check_all(gen, prog)
+    for name, dh, kw in g.production_variants():
+        gen, prog = g.build_program(dh, kw)               # (simulated inside)
         progs[name] = prog
         n_mfma = sum(1 for x in prog if x.kind == "mfma")
-        assert n_mfma > 48 * 4
+        assert n_mfma > (dh // 2) * 4
     import tempfile
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "loop.inc")
@@ -233,8 +231,7 @@ def test_attn64_loop_generator_checks_and_is_current():
         assert open(out).read() == open(os.path.join(root, "gta_amd", "csrc", "gta_attn64_loop.inc")).read(), \
             "gta_attn64_loop.inc is stale: python3 gta_amd/csrc/gen_attn64.py --out gta_amd/csrc/gta_attn64_loop.inc"
     # the simulation does catch what it is there for: a P.V MFMA moved in front of its fragment's wait, a dropped exp
-    gen = g.Gen(**dict(g.production_variants()[0][1]))
-    prog = gen.program()
+    gen, prog = g.build_program(96, dict(g.production_variants()[0][2]))
     i = next(i for i, x in enumerate(prog) if x.kind == "wait" and x.sem[0] == "lgkm" and prog[i + 1].kind == "mfma")
     bad = prog[:i] + [prog[i + 1], prog[i]] + prog[i + 2:]
     with pytest.raises(g.CheckError):

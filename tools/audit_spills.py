@@ -106,8 +106,8 @@ def audit_attn64():
     access behind the kernel's set-up (a reload sits behind a vmcnt(0))."""
     text = _asm("gta_fwd64.hip", ("-fno-slp-vectorize",))
     report, problems = [], []
-    for m in re.finditer(r"^(_ZN\w*gta_attn64_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)E\w+):", text, re.M):
-        name, key = m.group(1), (int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5)))
+    for m in re.finditer(r"^(_ZN\w*gta_attn64_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)E\w+):", text, re.M):
+        name, key = m.group(1), tuple(int(m.group(i)) for i in range(2, 7))       # (dh, element size, layout, variant, coalesced I/O)
         body = text[m.start():text.index(".Lfunc_end", m.start())]
         meta = text[text.index(".amdhsa_kernel " + name):][:4000]
         vgpr = int(re.search(r"\.amdhsa_next_free_vgpr\s+(\d+)", meta).group(1))

@@ -17,8 +17,8 @@ MS = {"triv": 0, "se3": 48, "so3": 24, "so2": 24}
 ROWS32 = 1 << 11
 
 
-def build(B, H, Nq, Pq, Nk, Pk, dtype, seed=2, qmul=None):
-    q, k, v, ex, ak, cross = C.synth_inputs(B, H, Nq, Pq, Nk, Pk, MS, 6, 2, dtype, seed=seed)
+def build(B, H, Nq, Pq, Nk, Pk, dtype, seed=2, qmul=None, layout=(MS, 6, 2)):
+    q, k, v, ex, ak, cross = C.synth_inputs(B, H, Nq, Pq, Nk, Pk, layout[0], layout[1], layout[2], dtype, seed=seed)
     if qmul is not None:
         q = q.clone()
         q[B - 1] *= qmul              # hot logits in the last scene: the lazy softmax must rebase
@@ -27,19 +27,19 @@ def build(B, H, Nq, Pq, Nk, Pk, dtype, seed=2, qmul=None):
     gta_amd.pre_compute_reps_encoder(ak, exd)
     if cross:
         gta_amd.pre_compute_reps_decoder(ak, exd)
-    packed = gta_amd.pack_reps(exd, MS)
+    packed = gta_amd.pack_reps(exd, layout[0])
     lay = lambda t: t.to(dtype).cuda().permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
-    return (q, k, v, ex, ak, cross), (lay(q), lay(k), lay(v), packed, exd.get("gta_so3_degree", 0))
+    return (q, k, v, ex, ak, cross), (lay(q), lay(k), lay(v), packed, exd.get("gta_so3_degree", 0), layout[0])
 
 
 def run(dev, flags, ws=None, want_lse=False):
-    q, k, v, packed, L = dev
+    q, k, v, packed, L, f_dims = dev
     B, H, Tq, dh = q.shape
     out = torch.zeros(B, Tq, H, dh, device=q.device, dtype=q.dtype).permute(0, 2, 1, 3)
     lse = torch.zeros(B, H, Tq, device=q.device, dtype=torch.float32)
-    Nq, Nk = packed["vrep_q"].shape[1], packed["vrep_k"].shape[1]
-    desc = native.make_desc(q, k, v, out, MS, L, Nq, Nk, dh ** -0.5, native.FLAG_V_TRANSFORM | flags)
-    tc = torch.tensor([0.01], device=q.device)
+    Nq, Nk = (packed["vrep_q"].shape[1], packed["vrep_k"].shape[1]) if "vrep_q" in packed else (1, 1)
+    desc = native.make_desc(q, k, v, out, f_dims, L, Nq, Nk, dh ** -0.5, native.FLAG_V_TRANSFORM | flags)
+    tc = torch.tensor([0.01], device=q.device) if f_dims.get("se3", 0) else None
     if ws is None:
         ws = torch.empty(native.attn_fwd_workspace_bytes(desc), device=q.device, dtype=torch.uint8)
     fn = lambda: native.attn_fwd(desc, q, k, v, packed.get("vrep_q"), packed.get("vrep_k"), packed.get("cs_q"), packed.get("cs_k"), tc,
@@ -255,6 +255,43 @@ def variants(which, B=32):
           f"load {ph[0]:5.0f} rho_q {ph[1]:5.0f} loop {ph[2]:6.0f} epi {ph[3]:5.0f} total {ph[4]:6.0f} | STEP {(ph2[2] - ph[2]) / 20:5.0f} cyc/tile")
 
 
+def phases(workload):
+    """per-item phase cycles of the attention kernel at one of bench.py's workloads, 64-row kernel and 32-row kernel"""
+    import ctypes
+    import bench
+    H, Nq, Pq, Nk, Pk, f_dims, so2, so3, B = bench.WORKLOADS[workload]
+    _, dev = build(B, H, Nq, Pq, Nk, Pk, torch.bfloat16, layout=(f_dims, so2, so3))
+    fn_fill, _, _, ws = run(dev, 0)
+    fn_fill()
+    torch.cuda.synchronize()
+    for label, flags in (("attn64", 0), ("rows32", ROWS32)):
+        fn = run(dev, native.FLAG_KV_READY | flags, ws=ws)[0]
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 100
+        prof = torch.zeros(B * H * ((Nq * Pq + 127) // 128), 8, dtype=torch.int64, device="cuda")
+        native.lib().gta_debug_set_profile_buffer(ctypes.c_void_p(prof.data_ptr()))
+        torch.cuda.synchronize()
+        fn()
+        torch.cuda.synchronize()
+        native.lib().gta_debug_set_profile_buffer(None)
+        P = prof.cpu().double()
+        P = P[P[:, 4] > 0]
+        real = P[:, 6] - P[:, 5]
+        ghz = ((P[:, 4] - P[:, 0]) / real).mean().item() * 0.1
+        span = ((P[:, 6].max() - P[:, 5].min()) / 100.0).item()
+        ph = [(P[:, b_] - P[:, a_]).mean().item() for a_, b_ in ((0, 1), (1, 2), (2, 3), (3, 4), (0, 4))]
+        print(f"{workload} {label}: {us:7.1f} us | {len(P)} items | span {span:6.1f} us x {ghz:.3f} GHz = {span * ghz:6.1f}k cyc | item: load {ph[0]:6.0f} "
+              f"rho_q {ph[1]:6.0f} loop {ph[2]:6.0f} epi {ph[3]:6.0f} total {ph[4]:6.0f}", flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     ok = True
@@ -274,6 +311,9 @@ if __name__ == "__main__":
         time_ab("MS-dec B32", 32, 8, 5, 512, 5, 256)
     if which == "timeline":
         timeline()
+    if which == "phases":
+        for w in (sys.argv[2] if len(sys.argv) > 2 else "dit,ms-dec").split(","):
+            phases(w)
     if which == "variants":
         variants((sys.argv[2] if len(sys.argv) > 2 else "0,2,3,4,5,6,7,8").split(","))
     print("ALL OK" if ok else "FAILURES")
