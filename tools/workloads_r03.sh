@@ -1,0 +1,15 @@
+# One bench.py line per BASELINE workload (SURVEY 8d shapes) -> gpurun_out/prof_r03/workloads.jsonl (copied to profiles/r03 by collect_r03.py)
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/prof_r03
+mkdir -p $OUT
+: > $OUT/workloads.jsonl
+for w in ms-enc ms-dec cl-enc cl-dec dit; do
+  timeout 300 python $R/bench.py --workload $w --block-steps 0 2>/dev/null | tail -1 >> $OUT/workloads.jsonl
+done
+python - <<PY
+import json
+for l in open("$OUT/workloads.jsonl"):
+    d = json.loads(l); r = d["roofline"]
+    print(d["config"]["workload"].split(":")[0], round(d["value"], 1), "Mtok/s", round(d["ms_per_step"] * 1e3, 1), "us/step", r["kernel"], round(r["kernel_ms"] * 1e3, 1), "us frac", round(r["frac"], 3),
+          "step_frac", round(r["step_frac"], 3), "fwd_bwd", round(d["fwd_bwd"]["ms_per_step"], 3), "parity", d["parity"]["parity_max_abs"])
+PY
