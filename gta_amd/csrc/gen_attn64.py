@@ -209,13 +209,14 @@ def branch(text, target, sem):
 
 class Gen:
     def __init__(self, R=4, kread_early=True, sched=True, boundary_in_a=False, ablate=(), carry=False, dma_spread=False, fast_ends=False, pk_sum=False,
-                 dot_sum=False):
+                 dot_sum=False, first_fast=False):
         assert R in (2, 4)
         self.R, self.early, self.sched, self.bina = R, kread_early and R == 4, sched, boundary_in_a
         self.ablate = set(ablate)          # timing-only builds (wrong results): novalu, nods, nodma, nobar
         self.carry = carry                 # K' reads stay in flight across the step labels
         self.dma_spread = dma_spread       # boundary in phase A: one LDS-DMA piece per gap instead of three back to back
         self.pk_sum = pk_sum               # row sums as v_pk_add_f32 on (even, odd) value pairs
+        self.first_fast = first_fast       # tile 0 without the rebase when its scores cannot leave the lazy softmax's window around m = 0
         self.dot_sum = dot_sum             # row sums from the PACKED words: one v_dot2c_f32_bf16 (x 1.0, 1.0) per pair of scores
         self.fast_ends = fast_ends         # O zeroed inside the head's MFMA gaps; the last step's softmax inside its P V MFMAs
         self.KRING, self.VRING = 0, R * IMG            # LDS byte offsets of the two rings
@@ -614,8 +615,28 @@ class Gen:
             zero = [Ins(f"v_accvgpr_write_b32 {O(rb, d, i)}, 0", "valu", [], [O(rb, d, i)]) for rb in range(RB) for d in range(DB) for i in range(16)]
             for i, z in enumerate(zero):
                 gaps[i // 4].append(z)
+        if self.first_fast:
+            # The first tile's scores are taken relative to m = 0 -- no row max, no rebase -- when |q'| max|k'(0)| stays inside the
+            # window the lazy softmax allows around its reference anyway (the same test as every later tile's, against m = 0): the
+            # -m splats and the row sums are zeroed in the head's gaps, the rebase is jumped over.
+            dec0 = [Ins(f"v_readlane_b32 {S_KN}, %[kn], 0", "valu", [], [S_KN], ("readkn",)),
+                    Ins(f"v_mul_f32 {T[0]}, %[qn0], {S_KN}", "valu", [S_KN], [T[0]]),
+                    Ins(f"v_mul_f32 {T[1]}, %[qn1], {S_KN}", "valu", [S_KN], [T[1]]),
+                    Ins(f"v_max_f32 {T[0]}, {T[0]}, {T[1]}", "valu", [T[0], T[1]], [T[0]]),
+                    Ins(f"v_cmp_lt_f32 vcc, 0x{THR_BITS:08x}, {T[0]}", "valu", [T[0]], ["vcc"])]
+            for i, x in enumerate(dec0):
+                gaps[i].append(x)
+            z = [Ins(f"v_mov_b32 {MS(rb, i)}, 0", "valu", [], [MS(rb, i)]) for rb in range(RB) for i in range(16)]
+            z += [Ins(f"v_mov_b32 {a}, 0", "valu", [], [a]) for rb in range(RB) for a in LA[rb] + LB[rb]]
+            for i, x in enumerate(z):
+                gaps[i * len(mf) // len(z)].append(x)
         out += self.weave([], mf, gaps) + k1
+        if self.first_fast:
+            out.append(branch("s_cbranch_vccz", L("first_fast"), ("br_first",)))
         out += self.rebase(0, True, 0, zero_o=not self.fast_ends)
+        if self.first_fast:
+            out.append(label(L("first_fast")))
+            out.append(nop(16))               # (the jump's way here: the head's last XDL writes of S' retire before the first exp)
         out += self.exph0_plain(0, 0)
         # ---- the unrolled steps ----
         for c in range(R):
@@ -745,8 +766,9 @@ class CheckError(Exception):
 
 
 class Sim:
-    def __init__(self, gen, prog, n_tiles, rebase_at=(), has_tail=False, items=2):
+    def __init__(self, gen, prog, n_tiles, rebase_at=(), has_tail=False, items=2, first_rebase=True):
         self.g, self.prog, self.n, self.rebase_at, self.has_tail, self.items = gen, prog, n_tiles, set(rebase_at), has_tail, items
+        self.first_rebase = first_rebase or not gen.first_fast      # does tile 0 take the rebase (its bound leaves the window)?
         self.labels = {ins.label: i for i, ins in enumerate(prog) if ins.kind == "label"}
         self.count = 0
 
@@ -1042,10 +1064,12 @@ class Sim:
                     for hh in range(2):
                         for r in Sregs(p, rb, hh):
                             regs[r][0] = regs[r][0][:6] + (msver[rb],)
-            elif op in ("br_need", "br_tail", "br_nomask", "br_tailstep", "br_always"):
+            elif op in ("br_need", "br_tail", "br_nomask", "br_tailstep", "br_always", "br_first"):
                 taken = False
                 if op == "br_always":
                     taken = True
+                elif op == "br_first":
+                    taken = not self.first_rebase
                 elif op == "br_need":
                     taken = (sc["j"] + 1) in self.rebase_at
                 elif op == "br_tail":
@@ -1075,7 +1099,7 @@ class Sim:
             self.fail("LDS reads outstanding at the end of the item")
         if not ksel_done or not vsel_done:
             self.fail("the DMA streams did not pass to the next item")
-        want = {0} | {t for t in self.rebase_at if 0 < t < n} | ({n - 1} if self.has_tail else set())
+        want = ({0} if self.first_rebase else set()) | {t for t in self.rebase_at if 0 < t < n} | ({n - 1} if self.has_tail else set())
         if rebased_tiles != want:
             self.fail(f"rebased tiles {sorted(rebased_tiles)} != {sorted(want)}")
         return sc["kptr"], sc["vptr"]
@@ -1162,9 +1186,10 @@ def check_all(gen, prog, verbose=False):
     cases = [(R, (), False), (2 * R, (), False), (5 * R, (), False), (2 * R, (1,), False), (3 * R, (2, 5, 2 * R + 1), True),
              (2 * R, (R - 1, R, 2 * R - 1), False), (R, (), True), (3 * R, tuple(range(1, 3 * R)), True)]
     for n, reb, tail in cases:
-        st = Sim(gen, prog, n, reb, tail).run()
-        if verbose:
-            print(f"  ok: n_tiles {n:2d} rebase at {reb} tail {tail}: {st['instr']} instructions, {st['mfma']} MFMAs (two items)")
+        for first in ((True, False) if gen.first_fast else (True,)):
+            st = Sim(gen, prog, n, reb, tail, first_rebase=first).run()
+            if verbose:
+                print(f"  ok: n_tiles {n:2d} rebase at {reb} tail {tail} first-tile rebase {first}: {st['instr']} instructions, {st['mfma']} MFMAs (two items)")
 
 
 BEST = dict(boundary_in_a=True, carry=True, fast_ends=True, dma_spread=True)      # measured r03: profiles/r03/attn64_dev_log.md
@@ -1201,7 +1226,7 @@ if __name__ == "__main__":
     variants = production_variants() if not a.plain else [(n, dh, dict(sched=False)) for n, dh, _ in production_variants()]
     if a.dev:     # development variants (gta_fwd64.hip -DGTA_ATTN64_DEV, GTA_ATTN64_VARIANT=n): schedules and timing-only ablations
         for dh, pre in ((96, "GTA_ATTN64_LOOP"), (64, "GTA_ATTN64_LOOP64")):
-            variants += [(f"{pre}_V2", dh, dict(best, dot_sum=True)),
+            variants += [(f"{pre}_V2", dh, dict(best, first_fast=True)),
                          (f"{pre}_V3", dh, dict(best, ablate=("novalu",))),
                          (f"{pre}_V4", dh, dict(best, ablate=("nods",))),
                          (f"{pre}_V5", dh, dict(best, ablate=("nodma", "nobar"))),

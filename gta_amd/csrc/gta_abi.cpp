@@ -217,7 +217,7 @@ extern "C" int gta_attn_fwd(const GtaAttnDesc* d, const void* q, const void* k, 
 // backward
 // ---------------------------------------------------------------------------------------------
 namespace {
-struct BwdLayout { int64_t off_qimg, off_stats, off_dc, off_dt, off_kv, total; int n_prep, n_dq, n_dkv; };
+struct BwdLayout { int64_t off_qimg, off_stats, off_dc, off_dt, off_kv, off_ds, total; int n_prep, n_dq, n_dkv; };
 BwdLayout bwd_layout(const GtaAttnDesc* d) {
     BwdLayout L;
     const int dhp = padded_dh(d->dh);
@@ -232,7 +232,10 @@ BwdLayout bwd_layout(const GtaAttnDesc* d) {
     L.off_dc = al(L.off_stats + (int64_t)d->B * d->H * n_qt * 128 * 4);
     L.off_dt = al(L.off_dc + (int64_t)(L.n_prep + L.n_dq + L.n_dkv) * 4);
     L.off_kv = al(L.off_dt + (int64_t)L.n_dq * 4);
-    L.total = al(L.off_kv + (int64_t)d->B * d->H * n_kt * stage);
+    L.off_ds = al(L.off_kv + (int64_t)d->B * d->H * n_kt * stage);
+    // dS-tile plan (GTA_FLAG_BWD_DS_TILES): one 8-KiB bf16 tile per (key tile, query tile) + one tile of slack (gta_bwd_dq2_kernel reads tile pairs)
+    const int64_t ds_bytes = (d->flags & GTA_FLAG_BWD_DS_TILES) ? ((int64_t)d->B * d->H * n_kt * n_qt + 1) * (64 * 64 * 2) : 0;
+    L.total = al(L.off_ds + ds_bytes);
     return L;
 }
 }  // namespace
@@ -287,6 +290,7 @@ extern "C" int gta_attn_bwd(const GtaAttnDesc* d, const void* q, const void* k, 
     p.cs_q = need_cs ? cs_q : nullptr; p.cs_k = need_cs ? cs_k : nullptr;
     p.trans_coeff = trans_coeff; p.tau = tau;
     p.kvimg = kv_images; p.qimg = ws + L.off_qimg; p.stats = (float*)(ws + L.off_stats);
+    p.dsimg = (d->flags & GTA_FLAG_BWD_DS_TILES) ? ws + L.off_ds : nullptr;
     p.dc_partial = (float*)(ws + L.off_dc); p.dtrans_coeff = (d->d_se3 > 0) ? dtrans_coeff : nullptr;
     p.dt_partial = (tau && dtau) ? (float*)(ws + L.off_dt) : nullptr; p.dtau = (tau && dtau) ? dtau : nullptr;
     p.q_sb = d->q_stride[0]; p.q_sh = d->q_stride[1]; p.q_st = d->q_stride[2];

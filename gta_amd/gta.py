@@ -16,6 +16,8 @@ from typing import Dict, Optional, Tuple
 import numpy as np
 import weakref
 
+import os
+
 import torch
 
 from . import native
@@ -416,6 +418,11 @@ def _generic_forward(q, k, v, f_dims, packed, so3_degree, trans_coeff, tau, scal
 PRECISE_FP32 = False
 
 
+# Backward plan (include/gta_hip.h): True = GTA_FLAG_BWD_DS_TILES, the dK/dV kernel writes its bf16 dS^T tiles and the dQ kernel streams them
+# (10 GEMM-units instead of 14, workspace + 2 B per (query, key) pair and head); same speed as the default at the MSN shapes.
+BWD_DS_TILES = bool(int(os.environ.get("GTA_BWD_DS_TILES", "0")))
+
+
 def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: int = 0,
                   trans_coeff=None, tau=None, scale: Optional[float] = None, v_transform: bool = True,
                   euclid: bool = False, pretransformed: bool = False, use_dma: bool = True,
@@ -452,6 +459,8 @@ def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: 
         kv_mode = "prepass"
     if kv_mode not in ("auto", "prepass", "fused"):
         raise ValueError(f"kv_mode {kv_mode!r}")
+    if BWD_DS_TILES:
+        flags |= native.FLAG_BWD_DS_TILES
     if precise is None:
         precise = PRECISE_FP32 and q.dtype == torch.float32
     if precise:

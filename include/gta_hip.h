@@ -45,6 +45,8 @@ extern "C" {
                                          /* results for the reference's mixed_prec: False configs, single-kernel plan, 3x the MFMAs */
 #define GTA_FLAG_ROWS32        (1u << 11) /* tuning: keep the 32-rows-per-wave attention kernel (gta_fwd2.hip) where the     */
                                           /* 64-rows-per-wave one (gta_fwd64.hip: dh = 96, whole ring turns of key tiles) would run */
+#define GTA_FLAG_BWD_DS_TILES  (1u << 12) /* backward: the dK/dV kernel writes its bf16 dS^T tiles and the dQ kernel streams them (10 GEMM-units */
+                                          /* instead of 14, + 2 B per (query, key) pair and head of workspace); default: the dQ kernel recomputes S, dP */
 #define GTA_FLAG_NO_DMA        (1u << 8) /* debug: stage K/V tiles through VGPRs, not LDS-DMA  */
 
 /* error codes */
@@ -144,6 +146,11 @@ int64_t gta_attn_fwd_workspace_bytes(const GtaAttnDesc* desc);
  *   inputs : q, k, v (as given to the forward; strides from desc), out and lse from the forward,
  *            dout [B,H,Tq,dh] with element strides dout_stride[3] (b,h,t), reps as in the forward.
  *   kv_images: the forward's workspace (K'/V' tile images) or NULL -> recomputed here.
+ *   plan     : Q''/dO~ pre-pass -> dQ kernel -> dK/dV kernel, each recomputing S and dP from the images (14 GEMM-units).
+ *              GTA_FLAG_BWD_DS_TILES: the dK/dV kernel runs first and writes every bf16 dS^T = P (dP - D) tile it forms, the dQ
+ *              kernel streams those tiles (dQ' = dS K' only: 10 units; workspace larger by B H ceil(Tq/64) ceil(Tk/64) 8 KiB).  On
+ *              MI355X the two plans take the same time at the MSN shapes (the tile stream is bound by the LDS-DMA path, DESIGN.md
+ *              4.3).  The flag must be the same in the workspace query and in the call.  Deterministic either way (no atomics).
  *   outputs: dq, dk, dv with element strides dqkv_stride[9] = dq(b,h,t), dk(b,h,t), dv(b,h,t);
  *            dtrans_coeff [1] fp32 (d loss / d trans_coeff, layers.py:191) or NULL;
  *            dtau [1] fp32 (d loss / d tau of TemperatureAdjsutableSoftmax, layers.py:135-143,195-200) or
