@@ -161,20 +161,20 @@ __device__ __forceinline__ void view_reps_body(int block, const float* __restric
 
 // theta_{t,c=2f+d} = (float)(max_freq_d * 2 pi) * (coord_d * freq_f), freq_f = 2^(f+1-F) or 1
 // (gta.py:57-63: the double scalar is rounded to fp32 when it meets the fp32 tensor).
+// One thread = one (token, frequency): both axes' (cos, sin) pairs, c = 2 f and 2 f + 1, in one 16-B store (two threads' worth of
+// the former one-pair-per-thread grid: the launch is latency-sized, half the workgroups end it sooner).
 __device__ __forceinline__ void so2_table_body(int block, const float* __restrict__ coord, int n_tokens, int F,
                                                float k_h, float k_w, int shared, float* __restrict__ cs) {
     const int i = block * 256 + threadIdx.x;
-    const int nblk = 2 * F;
-    if (i >= n_tokens * nblk) return;
-    const int t = i / nblk, c = i - t * nblk;
-    const int f = c >> 1, d = c & 1;
+    if (i >= n_tokens * F) return;
+    const int t = i / F, f = i - t * F;
     const float freq = shared ? 1.f : exp2f((float)(f + 1 - F));
-    const float prod = coord[2 * t + d] * freq;
-    const float th = (d == 0 ? k_h : k_w) * prod;
-    float s, co;
-    sincosf(th, &s, &co);
-    cs[2 * i] = co;
-    cs[2 * i + 1] = s;
+    const float2 xy = *reinterpret_cast<const float2*>(coord + 2 * t);
+    const float th0 = k_h * (xy.x * freq), th1 = k_w * (xy.y * freq);
+    float s0, c0, s1, c1;
+    sincosf(th0, &s0, &c0);
+    sincosf(th1, &s1, &c1);
+    *reinterpret_cast<float4*>(cs + 4 * (long)i) = float4{c0, s0, c1, s1};      // blocks 2 f (row coordinate), 2 f + 1 (column coordinate)
 }
 
 __global__ __launch_bounds__(256) void build_view_reps_kernel(const float* __restrict__ E, int n_views, int L,
@@ -213,7 +213,7 @@ extern "C" int gta_build_so2_table(const float* coord, int32_t n_tokens, int32_t
     const double two_pi = 6.283185307179586;
     const float k_h = (float)((double)max_freq_h * two_pi);
     const float k_w = (float)((double)max_freq_w * two_pi);
-    const long total = (long)n_tokens * 2 * nfreqs;
+    const long total = (long)n_tokens * nfreqs;         // one thread per (token, frequency)
     const int th = 256;                  // (so2_table_body assumes 256-thread blocks)
     hipLaunchKernelGGL(build_so2_table_kernel, dim3((unsigned)((total + th - 1) / th)), dim3(th), 0,
                        (hipStream_t)stream, coord, n_tokens, nfreqs, k_h, k_w, shared_freqs, cs);
@@ -229,7 +229,7 @@ extern "C" int gta_build_reps(const float* extrinsics, int32_t n_views, int32_t 
     const float k_h = (float)((double)max_freq_h * two_pi);
     const float k_w = (float)((double)max_freq_w * two_pi);
     const int n_vb = (n_views + 3) / 4;
-    const long total = (long)n_tokens * 2 * nfreqs;
+    const long total = (long)n_tokens * nfreqs;         // one thread per (token, frequency)
     const long n_tb = (total + 255) / 256;
     hipLaunchKernelGGL(build_reps_kernel, dim3((unsigned)(n_vb + n_tb)), dim3(256), 0, (hipStream_t)stream, extrinsics,
                        n_views, so3_degree, vrep, n_vb, coord, n_tokens, nfreqs, k_h, k_w, shared_freqs, cs);
