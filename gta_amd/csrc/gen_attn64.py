@@ -134,6 +134,27 @@ def Vregs(sl, d, half=None):
     return [f"a{b + i}" for i in range(4)] if half is None else [f"a{b + 2 * half}", f"a{b + 2 * half + 1}"]
 
 
+def _lb():
+    return _vb() + 4 * NVS * DB          # msum: the row sums as two 32x32 accumulators behind the V'^T fragments, then the all-ones A fragment
+
+
+def Lacc(rb, i=None):
+    b = _lb() + 16 * rb
+    return f"a[{b}:{b + 15}]" if i is None else f"a{b + i}"
+
+
+def Lregs(rb):
+    return [f"a{_lb() + 16 * rb + i}" for i in range(16)]
+
+
+ONES = None                              # set by configure(): "a[x:x+3]"
+
+
+def ONESregs():
+    b = _lb() + 16 * RB
+    return [f"a{b + i}" for i in range(4)]
+
+
 # low literal VGPRs
 KOFF = [f"v{32 + i}" for i in range(KS)]             # K' fragment byte offsets (ring base 0)
 VOFF = [[f"v{38 + 2 * d + h}" for h in range(2)] for d in range(DB)]   # V' transpose-read offsets (V ring base folded in)
@@ -151,6 +172,9 @@ def configure(dh):
     KOFF = [f"v{32 + i}" for i in range(KS)]
     VOFF = [[f"v{38 + 2 * d + h}" for h in range(2)] for d in range(DB)]
     assert _vb() + 4 * NVS * DB <= 256
+    global ONES
+    b = _lb() + 16 * RB
+    ONES = f"a[{b}:{b + 3}]"
 LA = [[f"v{44 + 2 * rb + e}" for e in range(2)] for rb in range(RB)]   # row sums of the hh = 1 halves (phase A), even / odd
 LB = [[f"v{48 + 2 * rb + e}" for e in range(2)] for rb in range(RB)]   # row sums of the hh = 0 halves (phase B)
 MRUN = [f"v{52 + rb}" for rb in range(RB)]
@@ -209,13 +233,15 @@ def branch(text, target, sem):
 
 class Gen:
     def __init__(self, R=4, kread_early=True, sched=True, boundary_in_a=False, ablate=(), carry=False, dma_spread=False, fast_ends=False, pk_sum=False,
-                 dot_sum=False, first_fast=False):
+                 dot_sum=False, first_fast=False, msum=False):
         assert R in (2, 4)
         self.R, self.early, self.sched, self.bina = R, kread_early and R == 4, sched, boundary_in_a
         self.ablate = set(ablate)          # timing-only builds (wrong results): novalu, nods, nodma, nobar
         self.carry = carry                 # K' reads stay in flight across the step labels
         self.dma_spread = dma_spread       # boundary in phase A: one LDS-DMA piece per gap instead of three back to back
         self.pk_sum = pk_sum               # row sums as v_pk_add_f32 on (even, odd) value pairs
+        self.msum = msum                   # row sums on the matrix pipe: l^T += 1 P per key slab (dh = 64: the pipe has the slack, the VALU does not)
+        assert not msum or _lb() + 16 * RB + 4 <= 256, "msum needs 36 free accumulator registers (dh = 64)"
         self.first_fast = first_fast       # tile 0 without the rebase when its scores cannot leave the lazy softmax's window around m = 0
         self.dot_sum = dot_sum             # row sums from the PACKED words: one v_dot2c_f32_bf16 (x 1.0, 1.0) per pair of scores
         self.fast_ends = fast_ends         # O zeroed inside the head's MFMA gaps; the last step's softmax inside its P V MFMAs
@@ -242,6 +268,25 @@ class Gen:
         hh, t = sl >> 1, sl & 1
         return Ins(f"v_mfma_f32_32x32x16_bf16 {O(rb, d)}, {V(sl, d)}, {P(p, rb, hh, t)}, {O(rb, d)}", "mfma",
                    Vregs(sl, d) + Pregs(p, rb, hh, t) + Oregs(rb, d), Oregs(rb, d), ("pv", p, sl, d, rb))
+
+    def pl(self, p, sl, rb):
+        """l^T[rb] += 1 (32 x 16) P (16 keys of slab sl x 32 rows): every output row is the rows' sum over the slab's keys"""
+        hh, t = sl >> 1, sl & 1
+        return Ins(f"v_mfma_f32_32x32x16_bf16 {Lacc(rb)}, {ONES}, {P(p, rb, hh, t)}, {Lacc(rb)}", "mfma",
+                   ONESregs() + Pregs(p, rb, hh, t) + Lregs(rb), Lregs(rb), ("pl", p, sl, rb))
+
+    def pv_list(self, c):
+        """the P V MFMAs of a step in issue order: per slab (d, rb) pairs, then (msum) the slab's two row-sum MFMAs"""
+        out = []
+        for sl in range(4):
+            out += [self.pv(c & 1, sl, g >> 1, g & 1) for g in range(2 * DB)]
+            if self.msum:
+                out += [self.pl(c & 1, sl, rb) for rb in range(RB)]
+        return out
+
+    @property
+    def SLN(self):
+        return 2 * DB + (RB if self.msum else 0)          # MFMAs per key slab in phase B
 
     def exp(self, p, rb, hh, r, tile_rel):
         x = S(p, rb, hh, r)
@@ -301,7 +346,7 @@ class Gen:
         return Ins(f"v_dot2c_f32_bf16 {a}, 0x3f803f80, {w}", "valu", [a, w], [a], ("dotsum", p, rb, hh, r >> 3, (r & 7) >> 1))
 
     def sums(self, p, rb, hh, e2, acc):
-        if self.dot_sum:
+        if self.dot_sum or self.msum:
             return []
         if self.pk_sum:
             return [self.add2(p, rb, hh, e2, acc)]
@@ -411,14 +456,14 @@ class Gen:
     # ---- phase B of step copy c: O += V'(j) P(j)   ||  softmax of the hh = 0 half of tile j + 1 -------------------
     def phase_b(self, c, plain=False, last=False):
         R, pn = self.R, (c + 1) & 1
-        mf = [self.pv(c & 1, g // (2 * DB), (g % (2 * DB)) >> 1, g & 1) for g in range(4 * 2 * DB)]   # g -> (slab, d, rb)
+        mf = self.pv_list(c)                                  # g -> (slab, d, rb) (+ the slab's row-sum MFMAs)
         vreads = [self.ds_v(c, sl, d, h) for sl in (2, 3) for d in range(DB) for h in range(2)]
         kreads = [self.ds_k((c + 2) % R, ks, hh, 2) for ks in range(KS) for hh in range(2)] if (self.early and not last) else []
         valu = [] if plain else self.softmax_items(pn, 0, 1, "B")
         pre, gaps = [], [[] for _ in mf]
         if not self.sched or plain:
             pre = vreads[:2 * DB] + kreads + [x for x in valu if x.sem[0] != "pack"]
-            gaps[2 * DB - 1] += vreads[2 * DB:]           # slab 3 takes slab 0's registers: behind slab 0's MFMAs
+            gaps[self.SLN - 1] += vreads[2 * DB:]         # slab 3 takes slab 0's registers: behind slab 0's MFMAs
             packs = [x for x in valu if x.sem[0] == "pack"]
             return self.weave(pre, mf, gaps) + packs
         # V' reads of slabs 2 (needed by MFMA 12) and 3 (MFMA 18): one per gap from gap 0
@@ -431,7 +476,7 @@ class Gen:
         self.deal(valu, gaps, range(2, len(mf)))
         pre.append(ready([r for d in range(DB) for r in Vregs(0, d)]))
         for sl in (1, 2, 3):
-            gaps[2 * DB * sl - 1].append(ready([r for d in range(DB) for r in Vregs(sl, d)]))
+            gaps[self.SLN * sl - 1].append(ready([r for d in range(DB) for r in Vregs(sl, d)]))
         return self.weave(pre, mf, gaps)
 
     def deal(self, valu, gaps, grange):
@@ -480,15 +525,15 @@ class Gen:
             out += self.phase_b(c, plain=True, last=True)
             return out
         # the softmax of the last tile's hh = 1 half inside the gaps of the P V MFMAs of its hh = 0 half (slabs 0, 1)
-        mf = [self.pv(c & 1, g // (2 * DB), (g % (2 * DB)) >> 1, g & 1) for g in range(4 * 2 * DB)]
+        mf = self.pv_list(c)
         gaps = [[] for _ in mf]
         v23 = [self.ds_v(c, sl, d, h) for sl in (2, 3) for d in range(DB) for h in range(2)]
         for i, vr in enumerate(v23):
             gaps[i].append(vr)
-        self.deal(self.softmax_items(p, 1, 0, "A"), gaps, range(0, 2 * 2 * DB - 1))
+        self.deal(self.softmax_items(p, 1, 0, "A"), gaps, range(0, 2 * self.SLN - 1))
         pre = vreads + [ready([r for d in range(DB) for r in Vregs(0, d)])]
         for sl in (1, 2, 3):
-            gaps[2 * DB * sl - 1].append(ready([r for d in range(DB) for r in Vregs(sl, d)]))
+            gaps[self.SLN * sl - 1].append(ready([r for d in range(DB) for r in Vregs(sl, d)]))
         return out + self.weave(pre, mf, gaps)
 
     # ---- rebase (the lazy softmax's full path) on the S' buffer of parity p ----------------------------------------
@@ -550,6 +595,9 @@ class Gen:
                 for d in range(DB if zero_o else 0):
                     for i in range(16):
                         out.append(Ins(f"v_accvgpr_write_b32 {O(rb, d, i)}, 0", "valu", [], [O(rb, d, i)]))
+                if self.msum and zero_o:
+                    for i in range(16):
+                        out.append(Ins(f"v_accvgpr_write_b32 {Lacc(rb, i)}, 0", "valu", [], [Lacc(rb, i)]))
             else:
                 out.append(Ins(f"v_sub_f32 {al}, 0, {dl}", "valu", [dl], [al]))
                 out.append(Ins(f"v_exp_f32 {al}, {al}", "trans", [al], [al]))
@@ -560,6 +608,15 @@ class Gen:
                 for d in range(DB):
                     for i in range(0, 16, 2):
                         a0, a1 = O(rb, d, i), O(rb, d, i + 1)
+                        out.append(Ins(f"v_accvgpr_read_b32 {T[8]}, {a0}", "valu", [a0], [T[8]]))
+                        out.append(Ins(f"v_accvgpr_read_b32 {T[9]}, {a1}", "valu", [a1], [T[9]]))
+                        out.append(Ins(f"v_mul_f32 {T[8]}, {T[8]}, {al}", "valu", [T[8], al], [T[8]]))
+                        out.append(Ins(f"v_mul_f32 {T[9]}, {T[9]}, {al}", "valu", [T[9], al], [T[9]]))
+                        out.append(Ins(f"v_accvgpr_write_b32 {a0}, {T[8]}", "valu", [T[8]], [a0]))
+                        out.append(Ins(f"v_accvgpr_write_b32 {a1}, {T[9]}", "valu", [T[9]], [a1]))
+                if self.msum:
+                    for i in range(0, 16, 2):
+                        a0, a1 = Lacc(rb, i), Lacc(rb, i + 1)
                         out.append(Ins(f"v_accvgpr_read_b32 {T[8]}, {a0}", "valu", [a0], [T[8]]))
                         out.append(Ins(f"v_accvgpr_read_b32 {T[9]}, {a1}", "valu", [a1], [T[9]]))
                         out.append(Ins(f"v_mul_f32 {T[8]}, {T[8]}, {al}", "valu", [T[8], al], [T[8]]))
@@ -594,6 +651,10 @@ class Gen:
         out.append(salu(f"s_sub_u32 {S_NMR1}, %[n], {R - 1}", [], [S_NMR1, "scc"], ("nmr1",)))
         for rb in range(RB):
             out.append(Ins(f"v_mov_b32 {MRUN[rb]}, 0", "valu", [], [MRUN[rb]]))
+        if self.msum:                         # the all-ones A fragment (bf16 1.0 pairs)
+            out.append(Ins(f"v_mov_b32 {T[0]}, 0x3f803f80", "valu", [], [T[0]]))
+            for r in ONESregs():
+                out.append(Ins(f"v_accvgpr_write_b32 {r}, {T[0]}", "valu", [T[0]], [r]))
         out.append(lgkm(0))
         # tile 0 (and whatever else of this item's first tiles was requested by the previous item / the kernel prologue)
         out.append(vmw(0))
@@ -613,8 +674,10 @@ class Gen:
                     (gaps[tgt] if g_free + 1 <= len(mf) - 1 else k1).append(self.ds_k(1 % R, ks, hh, 1))
         if self.fast_ends:                   # O = 0 inside the gaps of the first tile's QK^T (nothing else to do there)
             zero = [Ins(f"v_accvgpr_write_b32 {O(rb, d, i)}, 0", "valu", [], [O(rb, d, i)]) for rb in range(RB) for d in range(DB) for i in range(16)]
+            if self.msum:
+                zero += [Ins(f"v_accvgpr_write_b32 {Lacc(rb, i)}, 0", "valu", [], [Lacc(rb, i)]) for rb in range(RB) for i in range(16)]
             for i, z in enumerate(zero):
-                gaps[i // 4].append(z)
+                gaps[i * len(mf) // len(zero)].append(z)
         if self.first_fast:
             # The first tile's scores are taken relative to m = 0 -- no row max, no rebase -- when |q'| max|k'(0)| stays inside the
             # window the lazy softmax allows around its reference anyway (the same test as every later tile's, against m = 0): the
@@ -668,6 +731,12 @@ class Gen:
         out += self.tail_step()
         out.append(nop(16))                   # the last XDL writes of O retire before the epilogue's v_accvgpr_read
         for rb in range(RB):
+            if self.msum:
+                # every lane of a row's pair holds the row's whole sum (both key halves went through the matrix instruction): half of
+                # it, so that the kernel's l(lane) + l(lane ^ 32) stays what it is for the VALU sums
+                out.append(Ins(f"v_accvgpr_read_b32 {T[0]}, {Lacc(rb, 0)}", "valu", [Lacc(rb, 0)], [T[0]]))
+                out.append(Ins(f"v_mul_f32 %[lr{rb}], 0.5, {T[0]}", "valu", [T[0]], []))
+                continue
             out.append(Ins(f"v_add_f32 {LA[rb][0]}, {LA[rb][0]}, {LA[rb][1]}", "valu", [LA[rb][0], LA[rb][1]], [LA[rb][0]]))
             out.append(Ins(f"v_add_f32 {LB[rb][0]}, {LB[rb][0]}, {LB[rb][1]}", "valu", [LB[rb][0], LB[rb][1]], [LB[rb][0]]))
             out.append(Ins(f"v_add_f32 %[lr{rb}], {LA[rb][0]}, {LB[rb][0]}", "valu", [LA[rb][0], LB[rb][0]], []))
@@ -814,6 +883,7 @@ class Sim:
         self.pending_tile = getattr(self, "pending_tile", {})
         msver = [0, 0]
         o_done = {(rb, d): set() for rb in range(RB) for d in range(DB)}
+        l_done = {rb: set() for rb in range(RB)}
         sums = {}
         packed_from = {}
         exps = {}
@@ -981,7 +1051,7 @@ class Sim:
                 v = usereg(x, ("S", t, rb, hh, r_, "raw"), cur)
                 if v[6] != msver[rb]:
                     self.fail(f"{x}: score relative to an old running max (version {v[6]} vs {msver[rb]})", cur)
-                regs[x] = [("S", t, rb, hh, r_, "exp"), 1 if g.dot_sum else 2]         # one add (or none: summed as a packed word), one pack
+                regs[x] = [("S", t, rb, hh, r_, "exp"), 1 if (g.dot_sum or g.msum) else 2]         # one add (or none: summed as a packed word), one pack
                 exps[(t, rb)] = exps.get((t, rb), 0) + 1
             elif op == "add":
                 p, rb, hh, r_ = sem[1:]
@@ -1018,7 +1088,7 @@ class Sim:
                     self.fail(f"pack of {a}, {b} before both exps", cur)
                 ta[1] -= 1
                 tb[1] -= 1
-                setreg(P(p, rb, hh, tt, w), ("P", ta[0][1], rb, hh, tt, w), DB + (1 if g.dot_sum else 0))
+                setreg(P(p, rb, hh, tt, w), ("P", ta[0][1], rb, hh, tt, w), DB + (1 if (g.dot_sum or g.msum) else 0))
                 if g.dot_sum:
                     packed_from[P(p, rb, hh, tt, w)] = (a, b, ta[0][1])
             elif op == "dotsum":
@@ -1043,6 +1113,14 @@ class Sim:
                 if o_done[(rb, d)] and max(o_done[(rb, d)]) > (t, sl):
                     self.fail(f"O[{rb}][{d}] accumulates out of order", cur)
                 o_done[(rb, d)].add((t, sl))
+            elif op == "pl":
+                p, sl, rb = sem[1:]
+                t = sc["j"]
+                for w, r in enumerate(Pregs(p, rb, sl >> 1, sl & 1)):
+                    usereg(r, ("P", t, rb, sl >> 1, sl & 1, w), cur)
+                if (t, sl) in l_done[rb] or (l_done[rb] and max(l_done[rb]) > (t, sl)):
+                    self.fail(f"l[{rb}] accumulates tile {t} slab {sl} twice or out of order", cur)
+                l_done[rb].add((t, sl))
             elif op == "rebase_begin":
                 p, first, rel = sem[1:]
                 t = sc.get("j", 0) + rel
@@ -1056,6 +1134,10 @@ class Sim:
                 for (rb, d), done in o_done.items():
                     if len(done) != 4 * t:
                         self.fail(f"rebase for tile {t} with O[{rb}][{d}] at {len(done)} slabs", cur)
+                if g.msum:
+                    for rb, done in l_done.items():
+                        if len(done) != 4 * t:
+                            self.fail(f"rebase for tile {t} with l[{rb}] at {len(done)} slabs", cur)
                 rebased_tiles.add(t)
             elif op == "rebase_end":
                 p, first, rel = sem[1:]
@@ -1090,7 +1172,10 @@ class Sim:
         # ---- end-of-item checks ----
         for rb in range(RB):
             for t in range(n):
-                if exps.get((t, rb), 0) != 32 or sums.get((t, rb), 0) != 32:
+                if g.msum:
+                    if exps.get((t, rb), 0) != 32 or sum(1 for x in l_done[rb] if x[0] == t) != 4:
+                        self.fail(f"item {item}: tile {t} row block {rb}: {exps.get((t, rb), 0)} exps, row-sum slabs {sorted(x for x in l_done[rb] if x[0] == t)}")
+                elif exps.get((t, rb), 0) != 32 or sums.get((t, rb), 0) != 32:
                     self.fail(f"item {item}: tile {t} row block {rb}: {exps.get((t, rb), 0)} exps, {sums.get((t, rb), 0)} sums (32 each expected)")
             for d in range(DB):
                 if len(o_done[(rb, d)]) != 4 * n:
@@ -1197,9 +1282,9 @@ BEST = dict(boundary_in_a=True, carry=True, fast_ends=True, dma_spread=True)    
 
 def production_variants():
     """what gta_attn64_loop.inc holds, as (macro, dh, options): V0 = the shipped schedule, V1 = the same instructions un-interleaved
-    (GTA_ATTN64_VARIANT=1), for dh = 96 and for dh = 64"""
+    (GTA_ATTN64_VARIANT=1), for dh = 96 and for dh = 64 (there with the row sums on the matrix pipe: msum)"""
     return [("GTA_ATTN64_LOOP_V0", 96, dict(BEST)), ("GTA_ATTN64_LOOP_V1", 96, dict(sched=False)),
-            ("GTA_ATTN64_LOOP64_V0", 64, dict(BEST)), ("GTA_ATTN64_LOOP64_V1", 64, dict(sched=False))]
+            ("GTA_ATTN64_LOOP64_V0", 64, dict(BEST, msum=True)), ("GTA_ATTN64_LOOP64_V1", 64, dict(sched=False, msum=True))]
 
 
 def build_program(dh, kw, R=4, kread_early=True, check=True, verbose=False):
@@ -1226,7 +1311,7 @@ if __name__ == "__main__":
     variants = production_variants() if not a.plain else [(n, dh, dict(sched=False)) for n, dh, _ in production_variants()]
     if a.dev:     # development variants (gta_fwd64.hip -DGTA_ATTN64_DEV, GTA_ATTN64_VARIANT=n): schedules and timing-only ablations
         for dh, pre in ((96, "GTA_ATTN64_LOOP"), (64, "GTA_ATTN64_LOOP64")):
-            variants += [(f"{pre}_V2", dh, dict(best, first_fast=True)),
+            variants += [(f"{pre}_V2", dh, dict(best) if dh == 64 else dict(best, first_fast=True)),      # (dh = 64: V2 = the VALU row sums)
                          (f"{pre}_V3", dh, dict(best, ablate=("novalu",))),
                          (f"{pre}_V4", dh, dict(best, ablate=("nods",))),
                          (f"{pre}_V5", dh, dict(best, ablate=("nodma", "nobar"))),

@@ -91,7 +91,8 @@ if __name__ == "__main__":
     if which == "ab":
         # fair A/B of two flag sets of the attention kernel alone: alternate them, report the median of 7 rounds each
         shapes = {"MS-enc": (8, 5, 256, 5, 256, MS, 6, 2), "MS-dec": (8, 5, 512, 5, 256, MS, 6, 2), "CL-enc": (6, 2, 300, 2, 300, CL, 8, 0),
-                  "CL-dec": (6, 3, 853, 2, 300, CL, 8, 0), "DT": (16, 1, 1024, 1, 1024, {"so2": 64}, 16, 0)}
+                  "CL-dec": (6, 3, 853, 2, 300, CL, 8, 0), "DT": (16, 1, 1024, 1, 1024, {"so2": 64}, 16, 0),
+                  "MS-so2": (8, 5, 256, 5, 256, {"triv": 72, "so2": 24}, 6, 0)}      # (no per-view arithmetic: what the se3 / so3 matvecs cost)
         VT = native.FLAG_V_TRANSFORM
         for name, (H_, Nq_, Pq_, Nk_, Pk_, FD, so2_, so3_) in shapes.items():
             q, k, v, packed, L = setup(B, H_, Nq_, Pq_, Nk_, Pk_, FD, so2_, so3_, torch.bfloat16)
@@ -127,7 +128,8 @@ if __name__ == "__main__":
             print(f"{name:10s} Tq={Nq_*Pq_:5d} Tk={Nk_*Pk_:5d} " + "  ".join(f"{n}: {sorted(r)[2]*1e3:7.1f} us" for n, r in res.items()), flush=True)
     if which == "prep":
         # the K/V pre-pass alone (FLAG_PREP_ONLY) at the BASELINE shapes: time and effective bandwidth on algorithmic bytes
-        shapes = {"MS-enc": (8, 5, 256, 5, 256, MS, 6, 2), "CL-enc": (6, 2, 300, 2, 300, CL, 8, 0), "DT": (16, 1, 1024, 1, 1024, {"so2": 64}, 16, 0)}
+        shapes = {"MS-enc": (8, 5, 256, 5, 256, MS, 6, 2), "CL-enc": (6, 2, 300, 2, 300, CL, 8, 0), "DT": (16, 1, 1024, 1, 1024, {"so2": 64}, 16, 0),
+                  "MS-so2": (8, 5, 256, 5, 256, {"triv": 72, "so2": 24}, 6, 0)}      # (no per-view arithmetic: what the se3 / so3 matvecs cost)
         VT = native.FLAG_V_TRANSFORM
         for name, (H_, Nq_, Pq_, Nk_, Pk_, FD, so2_, so3_) in shapes.items():
             q, k, v, packed, L = setup(B, H_, Nq_, Pq_, Nk_, Pk_, FD, so2_, so3_, torch.bfloat16)
