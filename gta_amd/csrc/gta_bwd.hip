@@ -961,8 +961,9 @@ __global__ __launch_bounds__(256, (DHP > 96 ? 1 : 2)) void gta_bwd_dkv_kernel(co
                     w1 = u32x4_t{0u, 0u, 0u, 0u};
                 }
                 char* tile = (char*)p.dsimg + ((ktile0 + my_kt) * n_qt + j) * (long)GTA_DS_TILE + (((wave & 1) * 2 + qb) * 2) * 1024;   // (wave-uniform)
-                *reinterpret_cast<u32x4_t*>(tile + (unsigned)ln * 16u) = w0;
-                *reinterpret_cast<u32x4_t*>(tile + 1024 + (unsigned)ln * 16u) = w1;
+                // (non-temporal: 839 MB of tiles at the MSN shape must not push the Q''/dO~ images, which the workgroups of a (b,h) share, out of L2)
+                __builtin_nontemporal_store(w0, reinterpret_cast<u32x4_t*>(tile + (unsigned)ln * 16u));
+                __builtin_nontemporal_store(w1, reinterpret_cast<u32x4_t*>(tile + 1024 + (unsigned)ln * 16u));
             }
             // dV'^T += dO~^T P ; dK'^T += Q''^T dS   (A operands by transpose-read of the row-major images)
             const uint32_t qb_l = lds_addr(qi) + qb * 32 * CHP * 16, db_l = lds_addr(di) + qb * 32 * CHP * 16;
