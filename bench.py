@@ -249,6 +249,9 @@ def main():
     ap.add_argument("--kv-mode", dest="kv_mode", default="prepass", choices=["prepass", "fused", "prepass_rows32"],
                     help="execution plan of gta_attn_fwd (see include/gta_hip.h); prepass_rows32 = GTA_FLAG_ROWS32: the 32-rows-per-wave "
                          "attention kernel where the 64-rows one would run (A/B)")
+    ap.add_argument("--precise", action="store_true",
+                    help="fp32-faithful forward for fp32 inputs (GTA_FLAG_FP32_PRODUCTS: split-bf16 operands, three MFMAs per product, "
+                         "single-kernel plan; the reference's mixed_prec: False configs); needs --dtype f32; no backward leg")
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing check without a GPU: same launch contract, rendezvous (gloo), barriers, MAX-over-ranks and "
                          "JSON line, the step itself replaced by a host no-op (tests/test_ddp_gloo.py runs this at world size 2)")
@@ -285,13 +288,18 @@ def main():
     Tq, Tk, dh = Nq * Pq, Nk * Pk, sum(f_dims.values())
     need_view = f_dims.get("se3", 0) > 0 or f_dims.get("so3", 0) > 0
     so3_deg = so3 if f_dims.get("so3", 0) > 0 else 0
+    if args.precise:
+        if args.dtype != "f32":
+            raise SystemExit("--precise is the fp32-faithful mode: use --dtype f32")
+        args.kv_mode, args.train_steps = "fused", 0        # (the mode exists in the single-kernel plan's forward only)
     fused = args.kv_mode == "fused"
 
     # ---- the planned step: rep build(s) + one gta_attn_fwd ----
     reps_k = plan.RepPlan(B, Nk, Pk, so3_deg, so2, device=device) if (need_view and f_dims.get("so2", 0) > 0) else None
     reps_q = plan.RepPlan(B, Nq, Pq, so3_deg, so2, device=device) if (reps_k is not None and cross) else None
     fwd = plan.ForwardPlan(q, k, v, f_dims, so3_degree=so3_deg, Nq=Nq if need_view else 1, Nk=Nk if need_view else 1,
-                           flags=native.FLAG_FUSED_KV if fused else native.FLAG_ROWS32 if args.kv_mode == "prepass_rows32" else 0)
+                           flags=(native.FLAG_FUSED_KV | (native.FLAG_FP32_PRODUCTS if args.precise else 0)) if fused
+                           else native.FLAG_ROWS32 if args.kv_mode == "prepass_rows32" else 0)
     n_it, rows_it = ctypes.c_int32(0), ctypes.c_int32(0)
     kname = (L.gta_debug_attention_kernel(ctypes.byref(fwd.desc), ctypes.byref(n_it), ctypes.byref(rows_it)) or b"").decode()
     n_samp = args.steps if args.kernel_samples <= 0 else min(args.kernel_samples, args.steps)
@@ -473,7 +481,8 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}: GTA attention forward (rep build + K/V rep pre-pass + attention kernel), "
                                    f"B={B}/GPU, H={H}, Tq={Tq}, Tk={Tk}, dh={dh}, f_dims={f_dims}, "
-                                   f"views q/k={Nq}/{Nk}", "global_batch": n * B, "parallelism": f"dp{n}"},
+                                   f"views q/k={Nq}/{Nk}" + (", fp32-faithful products (GTA_FLAG_FP32_PRODUCTS)" if args.precise else ""),
+                       "global_batch": n * B, "parallelism": f"dp{n}"},
             "host_ms_per_step": t_host / args.steps * 1e3, "per_rank_ms_per_step": per_rank,
             "dist": __import__("gta_amd.ddp", fromlist=["backend_info"]).backend_info(),
         }

@@ -11,7 +11,7 @@ SRC = os.path.join(ROOT, "gpurun_out", "prof_r03")
 DST = os.path.join(ROOT, "profiles", "r03")
 os.makedirs(DST, exist_ok=True)
 for a, b in (("summary_kernel_stats.csv", "kernel_stats.csv"), ("summary_kernels.json", "kernels.json"), ("step_gaps.txt", "step_gaps.txt"),
-             ("bench_line.json", "bench_line.json"), ("workloads.jsonl", "workloads.jsonl")):
+             ("bench_line.json", "bench_line.json")):      # (workloads.jsonl is copied by hand: its lines may come from different calls)
     if os.path.exists(os.path.join(SRC, a)):
         shutil.copy(os.path.join(SRC, a), os.path.join(DST, b))
 k = json.load(open(os.path.join(SRC, "summary_kernels.json")))
