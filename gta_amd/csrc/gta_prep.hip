@@ -163,8 +163,11 @@ __global__ __launch_bounds__(256) void gta_kv_prep_kernel(const GtaFwdParams p) 
     // kind is wave-uniform; every kind runs its own load -> rho -> pack -> store body, so no register arrays are merged
     // behind the branches (the phi copies of a shared body were a third of this kernel's VALU instructions, and its
     // compute phase is VALU-issue bound: profiles/r02/README.md).
-    auto pass = [&](auto ISK, auto XF) {
-        constexpr bool is_k = decltype(ISK)::value, xf = decltype(XF)::value;
+    // (JOINTC: K and V chunk of the row side by side in one pass -- one load of the view matrices / (cos, sin) pairs for both, one
+    //  barrier less.  Faster where a tile is small (dh <= 64: 13.9 against 15.2 us at CLEVR-TR's encoder shape, r02); at dh = 96 the
+    //  two-pass form wins because K' goes out while V is transformed.)
+    auto pass = [&](auto ISK, auto XF, auto JOINTC) {
+        constexpr bool is_k = decltype(ISK)::value, xf = decltype(XF)::value, joint = decltype(JOINTC)::value;
         const char* raw = smem + (is_k ? S::OFF_RAWK : S::OFF_RAWV);
         char* img = smem + (is_k ? S::OFF_IMGK : S::OFF_IMGV);
 #pragma unroll
@@ -182,6 +185,20 @@ __global__ __launch_bounds__(256) void gta_kv_prep_kernel(const GtaFwdParams p) 
                     x[0][4] = bb.x; x[0][5] = bb.y; x[0][6] = bb.z; x[0][7] = bb.w;
                 }
                 apply(x);
+                if constexpr (joint) {                     // the V chunk of the same row and position, the same matrices
+                    float y[1][8];
+                    const char* rawv = smem + S::OFF_RAWV;
+                    if (ESZ == 2) {
+                        unpack8(*reinterpret_cast<const u32x4_t*>(rawv + (r * U + swz<U>(r, c)) * 16), y[0]);
+                    } else {
+                        const f32x4_t a = *reinterpret_cast<const f32x4_t*>(rawv + (r * U + swz<U>(r, 2 * c)) * 16);
+                        const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(rawv + (r * U + swz<U>(r, 2 * c + 1)) * 16);
+                        y[0][0] = a.x; y[0][1] = a.y; y[0][2] = a.z; y[0][3] = a.w;
+                        y[0][4] = bb.x; y[0][5] = bb.y; y[0][6] = bb.z; y[0][7] = bb.w;
+                    }
+                    if (xv) apply(y);
+                    *reinterpret_cast<u32x4_t*>(smem + S::OFF_IMGV + off) = pack8(y[0]);
+                }
                 const u32x4_t w = pack8(x[0]);
                 *reinterpret_cast<u32x4_t*>(img + off) = w;
                 if (is_k) {
@@ -224,6 +241,7 @@ __global__ __launch_bounds__(256) void gta_kv_prep_kernel(const GtaFwdParams p) 
                 }
             } else {
                 *reinterpret_cast<u32x4_t*>(img + off) = u32x4_t{0u, 0u, 0u, 0u};
+                if constexpr (joint) *reinterpret_cast<u32x4_t*>(smem + S::OFF_IMGV + off) = u32x4_t{0u, 0u, 0u, 0u};
             }
         }
     };
@@ -239,7 +257,9 @@ __global__ __launch_bounds__(256) void gta_kv_prep_kernel(const GtaFwdParams p) 
         }
     };
 
-    pass(std::true_type{}, std::true_type{});                     // K rows -> K' image (in place for bf16 input)
+    constexpr bool JOINT = DHP <= 64 && ESZ == 2;                  // (fp32 inputs: the V image is not in place, keep the two passes)
+    if constexpr (JOINT) pass(std::true_type{}, std::true_type{}, std::true_type{});
+    else pass(std::true_type{}, std::true_type{}, std::false_type{});      // K rows -> K' image (in place for bf16 input)
     float* rowsq = reinterpret_cast<float*>(smem + S::OFF_ROWSQ);
     if (p.kn) rowsq[wave * 64 + lane] = ksq;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // this wave's K' units and partials are written
@@ -253,10 +273,12 @@ __global__ __launch_bounds__(256) void gta_kv_prep_kernel(const GtaFwdParams p) 
         for (int o = 32; o > 0; o >>= 1) tot = fmaxf(tot, __shfl_xor(tot, o));
         if (lane == 0) p.kn[((long)b * p.H + h) * n_tiles + j] = sqrtf(tot) * 1.0001f;
     }
-    if (xv) pass(std::false_type{}, std::true_type{}); else pass(std::false_type{}, std::false_type{});
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // (the K' stores may still be in flight)
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+    if constexpr (!JOINT) {
+        if (xv) pass(std::false_type{}, std::true_type{}, std::false_type{}); else pass(std::false_type{}, std::false_type{}, std::false_type{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // (the K' stores may still be in flight)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
     store_image(smem + S::OFF_IMGV, gimg + IMG);
 }
 
