@@ -335,3 +335,31 @@ def test_j_convention_check(tmp_path):
         checkpoint.check_j_convention([blob[0], torch.eye(3, dtype=torch.float64), blob[2]])
     with pytest.raises(ValueError):
         checkpoint.check_j_convention([blob[0], blob[1], blob[2].roll(1, 0)])
+
+
+def test_attention_kernel_selection_and_backward_workspace_without_gpu():
+    """Host logic of the C ABI that needs no device: which attention kernel a descriptor gets (gta_debug_attention_kernel: the 64-rows-per-wave
+    kernel for dh = 96 in the MSN layout and dh = 64 bf16 in the CLEVR-TR / pure-so2 layouts when the key side is whole ring turns of 64-key
+    tiles and there are more than 128 query rows), and what GTA_FLAG_BWD_DS_TILES adds to the backward's workspace."""
+    MS, CL, DIT = {"se3": 48, "so3": 24, "so2": 24}, {"se3": 32, "so2": 32}, {"so2": 64}
+
+    def kern(dh, f, L, Tq, Tk, dtype, N=1, flags=0):
+        q = torch.empty(2, 4, Tq, dh, dtype=dtype)
+        k = torch.empty(2, 4, Tk, dh, dtype=dtype)
+        d = native.make_desc(q, k, k, q, f, L, N, N, dh ** -0.5, native.FLAG_V_TRANSFORM | flags)
+        return native.attention_kernel(d)[0::2]
+    bf, f32 = torch.bfloat16, torch.float32
+    assert kern(96, MS, 2, 1280, 1280, bf, 5) == ("gta_attn64_kernel", 256)
+    assert kern(96, MS, 2, 1280, 1280, f32, 5) == ("gta_attn64_kernel", 256)
+    assert kern(96, MS, 2, 1280, 1280, bf, 5, native.FLAG_ROWS32) == ("gta_fwd2_kernel", 128)
+    assert kern(96, MS, 2, 1280, 640, bf, 5) == ("gta_fwd2_kernel", 128)            # 10 key tiles: not whole ring turns
+    assert kern(96, MS, 2, 125, 1280, bf, 5) == ("gta_fwd2_kernel", 128)            # no more than 128 query rows: the 32-row kernel
+    assert kern(64, CL, 0, 512, 512, bf, 2) == ("gta_attn64_kernel", 256)
+    assert kern(64, CL, 0, 512, 512, f32, 2) == ("gta_fwd2_kernel", 128)            # the dh = 64 instances are bf16
+    assert kern(64, CL, 0, 600, 600, bf, 2) == ("gta_fwd2_kernel", 128)             # CLEVR-TR's own Tk = 600: 9.4 key tiles
+    assert kern(64, DIT, 0, 1024, 1024, bf) == ("gta_attn64_kernel", 256)
+    q = torch.empty(2, 8, 1280, 96, dtype=bf)
+    d0 = native.make_desc(q, q, q, q, MS, 2, 5, 5, 96 ** -0.5, native.FLAG_V_TRANSFORM)
+    d1 = native.make_desc(q, q, q, q, MS, 2, 5, 5, 96 ** -0.5, native.FLAG_V_TRANSFORM | native.FLAG_BWD_DS_TILES)
+    w0, w1 = native.lib().gta_attn_bwd_workspace_bytes(ctypes.byref(d0)), native.lib().gta_attn_bwd_workspace_bytes(ctypes.byref(d1))
+    assert 0 < w0 < w1 and 0 <= (w1 - w0) - (2 * 8 * 20 * 20 + 1) * 8192 < 512           # one 8-KiB tile per (key tile, query tile) + one of slack
