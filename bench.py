@@ -114,7 +114,7 @@ def latest_traffic(workload, B, dtype, kernel):
 
 
 def kernel_clock(prof):
-    """[n_items, 8] stamps of one launch (include/gta_hip.h: gta_debug_set_profile_buffer) -> (shader cycles of the launch, granted
+    """[n_items, 8] stamps of one launch (include/gta_hip.h: gta_debug_profile_next_attention_kernel) -> (shader cycles of the launch, granted
     shader clock in MHz): span of the 100-MHz stamps x the clock the items' own cycle counts give."""
     P = prof.cpu().double()
     real = P[:, 6] - P[:, 5]
@@ -124,6 +124,61 @@ def kernel_clock(prof):
     mhz = float(((P[:, 4] - P[:, 0])[ok] / real[ok]).mean()) * 100.0
     span_us = float(P[ok][:, 6].max() - P[ok][:, 5].min()) / 100.0
     return span_us * mhz, mhz
+
+
+def model_train_leg(args, dist, world, rank, local_rank, device, model, loss_of):
+    """K optimizer steps of ``model`` (sub-modules ``encoder`` / ``decoder``) under the reference's data-parallel structure
+    (train.py:182-188: each in its OWN DistributedDataParallel -> two bucketed gradient all-reduce streams per step, RCCL over xGMI on
+    the GPUs, gloo in --dry-run), timed between barriers with the MAX over ranks; then the bucket timeline on two EXTRA steps (the
+    Python hook replaces DDP's C++ all-reduce, so it stays out of the timed steps).  -> the `srt_train` object of the JSON line."""
+    from gta_amd import ddp
+    cuda = device.type == "cuda"
+    if dist is not None:
+        model, _ = ddp.wrap_srt_ddp(model, local_rank, logged=False)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+
+    def sync():
+        if cuda:
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def model_step():
+        opt.zero_grad(set_to_none=True)
+        loss = loss_of(model)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(2):
+        model_step()
+    sync()
+    tm0 = time.perf_counter()
+    for _ in range(args.model_train_steps):
+        last = model_step()
+    sync()
+    dtm = time.perf_counter() - tm0
+    if dist is not None:
+        tt = torch.tensor([dtm], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dtm = float(tt.item())
+    n_ = max(world, 1)
+    ms = dtm / args.model_train_steps * 1e3
+    out = {"ms_per_step": ms, "steps": args.model_train_steps, "scenes_per_s": n_ * args.model_batch / (ms * 1e-3),
+           "loss": float(last.item()), "grad_allreduce": None,
+           "ddp": "two DistributedDataParallel instances (encoder, decoder) as train.py:182-188" if dist is not None else None,
+           "note": "whole-model optimizer step on synthetic batches (SURVEY 8 f2); not part of `value`"}
+    if dist is not None:
+        logs = []
+        for sub in (model.encoder, model.decoder):
+            lg = ddp.BucketLog()
+            sub.register_comm_hook(None, lg.hook)
+            logs.append(lg)
+        for _ in range(2):
+            model_step()
+        sync()
+        out["grad_allreduce"] = {nm: lg.summary(2) for nm, lg in zip(("encoder", "decoder"), logs)}
+    return out
 
 
 def dry_run(args):
@@ -159,9 +214,23 @@ def dry_run(args):
         g = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
         dist.all_gather(g, torch.tensor([mine / args.steps * 1e3], dtype=torch.float64))
         per_rank = [float(u.item()) for u in g]
+    # the whole-model leg's control flow (two DDP instances, timed optimizer steps between barriers, MAX over ranks, bucket timeline)
+    # on a stand-in model with the same encoder / decoder structure: the same function the GPU run calls
+    srt_train = None
+    if args.model_train_steps < 0:
+        args.model_train_steps = 5 if world > 1 else 0
+    if args.model_train_steps > 0:
+        torch.manual_seed(7)
+        model = torch.nn.Module()
+        model.encoder = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.GELU(), torch.nn.Linear(32, 16))
+        model.decoder = torch.nn.Sequential(torch.nn.Linear(16, 8))
+        xb = torch.randn(args.model_batch, 16, generator=torch.Generator().manual_seed(99 + rank))
+        srt_train = model_train_leg(args, dist, world, rank, 0, torch.device("cpu"), model,
+                                    lambda m: m.decoder(m.encoder(xb)).square().mean())
     if rank == 0:
         n = max(world, 1)
         print(json.dumps({"metric": "GTA-attn Mtokens/s (V=5,H=W=128,d=768)", "value": n * B * Nq * Pq * args.steps / elapsed / 1e6,
+                          "srt_train": srt_train,
                           "unit": "Mtokens/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": elapsed / args.steps * 1e3, "per_rank_ms_per_step": per_rank,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
@@ -212,10 +281,10 @@ def block_layer_leg(B, steps, device):
     res = {}
     try:
         for label, on in (("modules", False), ("fused", True)):
-            layers.FUSED_BLOCKS = on
+            tr.fused_blocks = on
             res[label] = {"forward_us": timeit(fwd), "forward_backward_us": timeit(fwd_bwd)}
     finally:
-        layers.FUSED_BLOCKS = True
+        tr.fused_blocks = True
     res["config"] = f"one pre-LN layer of the MSN gta_so3 encoder: d=768 (8 x 96), mlp 1536, B={B}, 1280 tokens, bf16 autocast"
     res["note"] = "fused = libgta_block.so (DESIGN.md section 8); modules = nn.LayerNorm / nn.Linear / nn.GELU + autograd; not part of `value`"
     return res
@@ -231,9 +300,11 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the full-batch output")
-    ap.add_argument("--model-train-steps", type=int, default=0,
+    ap.add_argument("--model-train-steps", type=int, default=-1,
                     help="also time K optimizer steps of the whole MSN gta_so3 TransformingSRT (gta_amd.srt) on synthetic "
-                         "multi-view batches, DDP over the ranks; reported as `srt_train`, not part of `value`")
+                         "multi-view batches, DDP over the ranks (RCCL's bucketed gradient all-reduce: the one collective of the "
+                         "north star); reported as `srt_train`, not part of `value`.  Default: 5 when launched on more than one "
+                         "GPU (so the driver's `--gpus N --steps K --warmup W` line carries the collective), 0 on one GPU")
     ap.add_argument("--model-batch", type=int, default=8, help="per-GPU scenes for --model-train-steps")
     ap.add_argument("--train-steps", type=int, default=10,
                     help="extra (untimed-for-`value`) forward+backward steps reported as fwd_bwd_* fields; 0 = skip")
@@ -276,6 +347,8 @@ def main():
         torch.cuda.set_device(0)
     device = torch.device("cuda", local_rank if world > 1 else 0)
     L = native.lib()   # fail loudly if the HIP library is missing
+    if args.model_train_steps < 0:
+        args.model_train_steps = 5 if world > 1 else 0
 
     H, Nq, Pq, Nk, Pk, f_dims, so2, so3, Bdef = WORKLOADS[args.workload]
     B = args.batch or Bdef
@@ -327,11 +400,9 @@ def main():
         if i in sampled and not fused:
             e = ev[sampled[i]]
             L.gta_debug_time_next_attention_kernel(ctypes.c_void_p(e[0]), ctypes.c_void_p(e[1]))
-            L.gta_debug_set_profile_buffer(ctypes.c_void_p(profs[sampled[i]].data_ptr()))
-            try:
-                return fwd(q, k, v, vq, vk, cq, ck, tc)
-            finally:
-                L.gta_debug_set_profile_buffer(None)
+            pb = profs[sampled[i]]
+            L.gta_debug_profile_next_attention_kernel(ctypes.c_void_p(pb.data_ptr()), pb.shape[0])      # (one-shot: this launch only)
+            return fwd(q, k, v, vq, vk, cq, ck, tc)
         return fwd(q, k, v, vq, vk, cq, ck, tc)
 
     for _ in range(args.warmup):
@@ -371,6 +442,13 @@ def main():
         sclk_mhz = sum(c[1] for c in cyc) / len(cyc) if cyc else None
     for a, b in ev:
         L.gta_debug_event_destroy(ctypes.c_void_p(a)); L.gta_debug_event_destroy(ctypes.c_void_p(b))
+    # every rank's granted shader clock and attention-kernel time (eight GPUs under load are not granted one clock)
+    per_rank_sclk, per_rank_kern = [sclk_mhz], [kern_ms]
+    if dist is not None:
+        g = [torch.zeros(2, device=device, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(g, torch.tensor([sclk_mhz or 0.0, kern_ms or 0.0], device=device, dtype=torch.float64))
+        per_rank_sclk = [float(u[0].item()) or None for u in g]
+        per_rank_kern = [float(u[1].item()) or None for u in g]
 
     parity = None
     if rank == 0 and not args.no_parity:
@@ -410,60 +488,17 @@ def main():
     if args.model_train_steps > 0:
         # whole-model optimizer step (conv stem, 5 + 2 Transformer blocks on the HIP attention path,
         # render MLP, MSE loss, AdamW; bf16 autocast; DDP's bucketed gradient all-reduce over RCCL when world > 1)
-        from gta_amd import srt, ddp
+        from gta_amd import srt
         torch.manual_seed(1234 + rank)
         model = srt.TransformingSRT(srt.msn_gta_so3_cfg()).to(device)
-        if dist is not None:
-            # the reference's structure (train.py:182-188): encoder and decoder in their own DistributedDataParallel
-            model, _ = ddp.wrap_srt_ddp(model, local_rank, logged=False)
-        opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
         batch = srt.synthetic_batch(args.model_batch, device=device, seed=99 + rank)
-
-        def model_step():
-            opt.zero_grad(set_to_none=True)
-            loss, _ = srt.compute_loss(model, batch, mixed_prec=(args.dtype == "bf16"))
-            loss.mean().backward()
-            opt.step()
-            return loss
-
-        for _ in range(2):
-            model_step()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        tm0 = time.perf_counter()
-        for _ in range(args.model_train_steps):
-            last = model_step()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        dtm = time.perf_counter() - tm0
-        if dist is not None:
-            tt = torch.tensor([dtm], device=device, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dtm = float(tt.item())
-        n_ = max(world, 1)
-        ms = dtm / args.model_train_steps * 1e3
-        srt_train = {"ms_per_step": ms, "scenes_per_s": n_ * args.model_batch / (ms * 1e-3),
-                     "enc_mtokens_s": n_ * args.model_batch * 1280 / (ms * 1e-3) / 1e6,
-                     "loss": float(last.mean().item()),
-                     "config": f"MSN gta_so3 TransformingSRT (encoder 5 blocks d=768, decoder 2 blocks, 5 input + 5 target "
-                               f"views, 1280 scene tokens, 2560 query rays), {args.model_batch} scenes/GPU, "
-                               f"AdamW, {args.dtype} autocast, dp{n_}",
-                     "note": "whole-model optimizer step on synthetic batches (SURVEY 8 f2); not part of `value`"}
-        if dist is not None:
-            # the bucket timeline on two EXTRA steps (the Python hook replaces DDP's C++ all-reduce: not inside the timed steps)
-            logs = []
-            for sub in (model.encoder, model.decoder):
-                lg = ddp.BucketLog()
-                sub.register_comm_hook(None, lg.hook)
-                logs.append(lg)
-            for _ in range(2):
-                model_step()
-            torch.cuda.synchronize()
-            srt_train["grad_allreduce"] = {nm: lg.summary(2) for nm, lg in zip(("encoder", "decoder"), logs)}
-        srt_train["ddp"] = "two DistributedDataParallel instances (encoder, decoder) as train.py:182-188" if dist is not None else None
-        del model, opt, batch
+        srt_train = model_train_leg(args, dist, world, rank, local_rank, device, model,
+                                    lambda m: srt.compute_loss(m, batch, mixed_prec=(args.dtype == "bf16"))[0].mean())
+        srt_train.update({"enc_mtokens_s": srt_train["scenes_per_s"] * 1280 / 1e6,
+                          "config": f"MSN gta_so3 TransformingSRT (encoder 5 blocks d=768, decoder 2 blocks, 5 input + 5 target "
+                                    f"views, 1280 scene tokens, 2560 query rays), {args.model_batch} scenes/GPU, "
+                                    f"AdamW, {args.dtype} autocast, dp{max(world, 1)}"})
+        del model, batch
     flops = 4.0 * B * H * Tq * Tk * dh                               # QK^T + PV, 2 flop/MAC
     alg_bytes = (2 * Tq + 2 * Tk) * H * dh * q.element_size() * B    # read Q,K,V once, write O once
     achieved = flops / (kern_ms * 1e-3) / 1e12 if kern_ms else None
@@ -484,6 +519,7 @@ def main():
                                    f"views q/k={Nq}/{Nk}" + (", fp32-faithful products (GTA_FLAG_FP32_PRODUCTS)" if args.precise else ""),
                        "global_batch": n * B, "parallelism": f"dp{n}"},
             "host_ms_per_step": t_host / args.steps * 1e3, "per_rank_ms_per_step": per_rank,
+            "per_rank_sclk_mhz": per_rank_sclk, "per_rank_kernel_ms": per_rank_kern,
             "dist": __import__("gta_amd.ddp", fromlist=["backend_info"]).backend_info(),
         }
         if achieved is not None:

@@ -16,7 +16,7 @@
 
 int gta_fwd_lds_bytes(int dhp, int esz);
 int gta_fwd_dispatch(const GtaFwdParams& p, int dhp, int esz, bool dma, int n_wg, hipStream_t stream);
-long gta_fwd2_workspace_bytes(int B, int H, int Tk, int dhp, int Nq);
+long gta_fwd2_workspace_bytes(int B, int H, int Tk, int dhp, int Nq, int esz);
 long gta_fwd2_qtiles_offset(int B, int H, int Tk, int dhp);
 int gta_fwd2_rows_per_item(const GtaFwdParams& p, int dhp, int esz);                   // 256: gta_attn64_kernel, 128: gta_fwd2_kernel
 long gta_fwd2_image_bytes(int B, int H, int Tk, int dhp);
@@ -96,9 +96,15 @@ int check_common(const GtaAttnDesc* d) {
 
 }  // namespace
 
-static unsigned long long* g_prof = nullptr;
-// debug hook (not part of the product ABI): device buffer [n_workgroups][8] for s_memtime stamps
-extern "C" void gta_debug_set_profile_buffer(void* p) { g_prof = (unsigned long long*)p; }
+// debug hook (not part of the product ABI): device buffer [capacity_items][8] for the per-item s_memtime stamps of the NEXT attention
+// launch this thread makes through gta_attn_fwd -- thread-local and one-shot, like gta_debug_time_next_attention_kernel, and dropped
+// (no stamps) when the launch has more work items than the buffer holds
+static thread_local unsigned long long* t_prof = nullptr;
+static thread_local int64_t t_prof_items = 0;
+extern "C" void gta_debug_profile_next_attention_kernel(void* p, int64_t capacity_items) {
+    t_prof = (unsigned long long*)p;
+    t_prof_items = p ? capacity_items : 0;
+}
 extern "C" int gta_abi_version(void) { return GTA_ABI_VERSION; }
 extern "C" int gta_sizeof_attn_desc(void) { return (int)sizeof(GtaAttnDesc); }
 
@@ -128,7 +134,7 @@ extern "C" int gta_attn_fwd_supported(const GtaAttnDesc* desc) {
 
 extern "C" int64_t gta_attn_fwd_workspace_bytes(const GtaAttnDesc* desc) {
     if (gta_attn_fwd_supported(desc)) return 0;
-    return gta_fwd2_workspace_bytes(desc->B, desc->H, desc->Tk, padded_dh(desc->dh), desc->Nq);
+    return gta_fwd2_workspace_bytes(desc->B, desc->H, desc->Tk, padded_dh(desc->dh), desc->Nq, desc->dtype == GTA_DTYPE_BF16 ? 2 : 4);
 }
 
 extern "C" int gta_attn_fwd_launch_info(const GtaAttnDesc* desc, int32_t* lds_bytes, int32_t* n_workgroups,
@@ -148,7 +154,7 @@ extern "C" const char* gta_debug_attention_kernel(const GtaAttnDesc* d, int32_t*
     GtaFwdParams p;
     memset(&p, 0, sizeof p);
     if (build_ctab(d, p.ctab)) return "";
-    p.Tq = d->Tq; p.Tk = d->Tk; p.dh = d->dh; p.flags = d->flags; p.kn = (float*)1; p.cs_q = d->d_so2 ? (const float*)1 : nullptr;
+    p.B = d->B; p.H = d->H; p.Tq = d->Tq; p.Tk = d->Tk; p.dh = d->dh; p.flags = d->flags; p.kn = (float*)1; p.cs_q = d->d_so2 ? (const float*)1 : nullptr;
     const bool two_stage = !(d->flags & (GTA_FLAG_FUSED_KV | GTA_FLAG_FP32_PRODUCTS | GTA_FLAG_PRETRANSFORMED));
     const int rows = !two_stage ? 128 : gta_fwd2_rows_per_item(p, padded_dh(d->dh), d->dtype == GTA_DTYPE_BF16 ? 2 : 4);
     if (n_items) *n_items = d->B * d->H * ((d->Tq + rows - 1) / rows);
@@ -190,18 +196,26 @@ extern "C" int gta_attn_fwd(const GtaAttnDesc* d, const void* q, const void* k, 
 #ifdef GTA_ABLATE
     { const char* e = getenv("GTA_DBG"); p.dbg = e ? (uint32_t)atoi(e) : 0u; }
 #endif
-    p.prof = g_prof;        // (start / end stamps of every work item when a buffer is set: gta_debug_set_profile_buffer)
     const long n_wg = (long)d->B * d->H * p.n_qtiles;
+    if (t_prof && !(d->flags & GTA_FLAG_PREP_ONLY)) {      // (start / end stamps of every work item: gta_debug_profile_next_attention_kernel)
+        GtaFwdParams pk = p;
+        pk.kn = (float*)1;
+        const bool two_stage = workspace && !(d->flags & (GTA_FLAG_FUSED_KV | GTA_FLAG_FP32_PRODUCTS)) && !pre;
+        const int rows = two_stage ? gta_fwd2_rows_per_item(pk, padded_dh(d->dh), esz) : 128;
+        if ((int64_t)d->B * d->H * ((d->Tq + rows - 1) / rows) <= t_prof_items) p.prof = t_prof;
+        t_prof = nullptr;
+        t_prof_items = 0;
+    }
     if (n_wg > 0x7fffffffL) return fail(GTA_E_UNSUPPORTED, "grid too large");
     if ((d->flags & GTA_FLAG_FP32_PRODUCTS) && d->dtype != GTA_DTYPE_F32)
         return fail(GTA_E_BADARG, "GTA_FLAG_FP32_PRODUCTS is for fp32 inputs (bf16 inputs ask for bf16 arithmetic)");
     if (workspace && !(d->flags & (GTA_FLAG_FUSED_KV | GTA_FLAG_FP32_PRODUCTS)) && !pre) {
-        if (workspace_bytes < gta_fwd2_workspace_bytes(d->B, d->H, d->Tk, padded_dh(d->dh), d->Nq))
+        if (workspace_bytes < gta_fwd2_workspace_bytes(d->B, d->H, d->Tk, padded_dh(d->dh), d->Nq, esz))
             return fail(GTA_E_BADARG, "workspace smaller than gta_attn_fwd_workspace_bytes()");
         if (d->H > 65535 || d->B > 65535) return fail(GTA_E_UNSUPPORTED, "B or H above 65535");
         p.kp = workspace;
         p.kn = (float*)((char*)workspace + ((gta_fwd2_image_bytes(d->B, d->H, d->Tk, padded_dh(d->dh)) + 255) & ~255L));
-        if (padded_dh(d->dh) == 96 && need_view) p.qtiles = (char*)workspace + gta_fwd2_qtiles_offset(d->B, d->H, d->Tk, 96);
+        if (padded_dh(d->dh) == 96 && esz == 2 && need_view) p.qtiles = (char*)workspace + gta_fwd2_qtiles_offset(d->B, d->H, d->Tk, 96);
         rc = gta_fwd2_dispatch(p, padded_dh(d->dh), esz, !(d->flags & GTA_FLAG_KV_READY), !(d->flags & GTA_FLAG_PREP_ONLY),
                                (hipStream_t)stream);
         if (rc) return fail(rc, rc == GTA_E_LAUNCH ? hipGetErrorString(hipGetLastError()) : "no kernel instance");
@@ -217,7 +231,7 @@ extern "C" int gta_attn_fwd(const GtaAttnDesc* d, const void* q, const void* k, 
 // backward
 // ---------------------------------------------------------------------------------------------
 namespace {
-struct BwdLayout { int64_t off_qimg, off_stats, off_dc, off_dt, off_kv, off_ds, total; int n_prep, n_dq, n_dkv; };
+struct BwdLayout { int64_t off_qimg, off_stats, off_dc, off_dt, off_kv, total; int n_prep, n_dq, n_dkv; };
 BwdLayout bwd_layout(const GtaAttnDesc* d) {
     BwdLayout L;
     const int dhp = padded_dh(d->dh);
@@ -232,10 +246,7 @@ BwdLayout bwd_layout(const GtaAttnDesc* d) {
     L.off_dc = al(L.off_stats + (int64_t)d->B * d->H * n_qt * 128 * 4);
     L.off_dt = al(L.off_dc + (int64_t)(L.n_prep + L.n_dq + L.n_dkv) * 4);
     L.off_kv = al(L.off_dt + (int64_t)L.n_dq * 4);
-    L.off_ds = al(L.off_kv + (int64_t)d->B * d->H * n_kt * stage);
-    // dS-tile plan (GTA_FLAG_BWD_DS_TILES): one 8-KiB bf16 tile per (key tile, query tile) + one tile of slack (gta_bwd_dq2_kernel reads tile pairs)
-    const int64_t ds_bytes = (d->flags & GTA_FLAG_BWD_DS_TILES) ? ((int64_t)d->B * d->H * n_kt * n_qt + 1) * (64 * 64 * 2) : 0;
-    L.total = al(L.off_ds + ds_bytes);
+    L.total = al(L.off_kv + (int64_t)d->B * d->H * n_kt * stage);
     return L;
 }
 }  // namespace
@@ -290,7 +301,6 @@ extern "C" int gta_attn_bwd(const GtaAttnDesc* d, const void* q, const void* k, 
     p.cs_q = need_cs ? cs_q : nullptr; p.cs_k = need_cs ? cs_k : nullptr;
     p.trans_coeff = trans_coeff; p.tau = tau;
     p.kvimg = kv_images; p.qimg = ws + L.off_qimg; p.stats = (float*)(ws + L.off_stats);
-    p.dsimg = (d->flags & GTA_FLAG_BWD_DS_TILES) ? ws + L.off_ds : nullptr;
     p.dc_partial = (float*)(ws + L.off_dc); p.dtrans_coeff = (d->d_se3 > 0) ? dtrans_coeff : nullptr;
     p.dt_partial = (tau && dtau) ? (float*)(ws + L.off_dt) : nullptr; p.dtau = (tau && dtau) ? dtau : nullptr;
     p.q_sb = d->q_stride[0]; p.q_sh = d->q_stride[1]; p.q_st = d->q_stride[2];

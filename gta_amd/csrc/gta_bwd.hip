@@ -581,210 +581,6 @@ __global__ __launch_bounds__(256, 2) void gta_bwd_dq_kernel(const GtaBwdParams p
 }
 
 // ================================================================================================
-// 2b. dQ from the dS^T tiles of the dK/dV kernel (the dS-tile plan: GTA_FLAG_BWD_DS_TILES)
-// ================================================================================================
-// gta_bwd_dkv_kernel forms every dS^T = P (dP - D) tile anyway (bf16, for dK'^T += Q''^T dS) and writes it out as a tile image;
-// this kernel then only runs dQ'^T += K'^T dS^T: 2 of the 6 GEMM-units gta_bwd_dq_kernel spends (it recomputes S and dP), no exp,
-// no statistics, no Q''/dO~ images.  It is a stream: per 64-key step a workgroup (128 query rows) takes the K' image (IMG bytes)
-// and its two dS^T tiles (16 KiB) through a ring of LDS-DMA stages and issues 4 DB MFMAs per wave -- HBM-bound (B H Tq Tk 2 bytes
-// of dS^T in all): two workgroups per CU, each one stage ahead, hide the fetch latency and each other's prologue / epilogue.
-constexpr int GTA_DS_TILE = BN * BN * 2;                   // one [64 keys x 64 queries] bf16 dS^T tile image (gta_bwd_dkv_kernel)
-template <int DHP>
-struct Dq2Smem {
-    static constexpr int CHP = DHP / 8;
-    static constexpr int IMG = BN * DHP * 2;
-    static constexpr int STAGE = IMG + 2 * GTA_DS_TILE;    // K' image | dS^T tiles of the workgroup's two 64-row query tiles
-    static constexpr int NST = 2;                          // two workgroups per CU: the other one's stage is in flight while this one waits
-    static constexpr int OROW = DHP + 4;
-    static constexpr int OST = 128 * OROW * 4;             // the epilogue's dQ' staging re-uses the ring
-    static constexpr int RING = NST * STAGE > OST ? NST * STAGE : OST;
-    static constexpr int OFF_RING = 0;
-    static constexpr int OFF_SCR = RING;
-    static constexpr int OFF_REC = RING + 32;
-    static int total(int nviews) { return OFF_REC + nviews * BREC * 4; }
-};
-
-template <int DHP, int ESZ>
-__global__ __launch_bounds__(256, 2) void gta_bwd_dq2_kernel(const GtaBwdParams p) {
-    using S = Dq2Smem<DHP>;
-    constexpr int CHP = S::CHP, DB = DHP / 32, BM = 128, NST = S::NST;
-    constexpr int PW = S::STAGE / 4096;                    // 1-KiB DMA pieces per wave and stage
-    constexpr int ITEMS = 2 * CHP / 4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, lh = lane >> 5;
-
-    int w;
-    {
-        const int nwg = gridDim.x, L = blockIdx.x;
-        const int xcd = L & 7, idx = L >> 3, q8 = nwg >> 3, r8 = nwg & 7;
-        w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-    }
-    const int n_q128 = (p.Tq + BM - 1) / BM;
-    const int bh = w / n_q128, qt = w - bh * n_q128;
-    const int b = bh / p.H, h = bh - b * p.H;
-    const int q0 = qt * BM;
-    const int n_tiles = (p.Tk + BN - 1) / BN;
-    const int n_qt64 = (p.Tq + BN - 1) / BN;
-    const int ch_real = p.dh >> 3;
-    char* ring = smem + S::OFF_RING;
-    float* rec = reinterpret_cast<float*>(smem + S::OFF_REC);
-    const char* kimg = (const char*)p.kvimg + ((long)b * p.H + h) * n_tiles * (2L * S::IMG);       // [K' | V'] pairs: K' of tile j at 2 j IMG
-    // the dS^T tiles (j, 2 qt) and (j, 2 qt + 1) are neighbours in memory (an odd last tile reads one tile past its row: the
-    // workspace has the slack, the garbage only reaches query rows past Tq, which are never stored)
-    const char* dsimg = (const char*)p.dsimg + (((long)b * p.H + h) * n_tiles * n_qt64 + 2 * qt) * (long)GTA_DS_TILE;
-    auto request = [&](int j) {
-        char* st = ring + (j % NST) * S::STAGE;
-        dma_linear4<S::IMG>(st, kimg + (long)j * (2L * S::IMG), wave, lane);
-        dma_linear4<2 * GTA_DS_TILE>(st + S::IMG, dsimg + (long)j * n_qt64 * GTA_DS_TILE, wave, lane);
-    };
-#pragma unroll
-    for (int j = 0; j < NST - 1; ++j)
-        if (j < n_tiles) request(j);
-
-    const int t_last = (q0 + BM - 1 < p.Tq ? q0 + BM - 1 : p.Tq - 1);
-    const int n_first = q0 / p.Pq;
-    const int n_cnt = t_last / p.Pq - n_first + 1;
-    const float tc = p.trans_coeff ? *p.trans_coeff : 1.0f;
-    if (p.vrep_q) stage_brec(rec, p.vrep_q, (long)b * p.Nq + n_first, n_cnt, 0, tc, tid, 256);
-    const int my_row = wave * 32 + l31;                 // this lane's query row in the workgroup: column of dQ'^T and of dS^T
-    const int my_tile = my_row >> 6, qb = (my_row >> 5) & 1;
-
-    f32x16_t dq[DB];
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) dq[d][i] = 0.f;
-
-    // transpose-read addresses: A = K'^T (channel block d x 16-key slab) of the K' image as in gta_bwd_dq_kernel; B = dS^T (16-key
-    // slab x this wave's 32 queries) of the dS^T tile image -- the same 4 rows x 4 pieces per 16 lanes, located in the image's
-    // [32-key block][32-query block][register half][lane (key, query half)][two groups of 4 queries] order (gta_bwd_dkv_kernel)
-    const int g16 = lane >> 4, p16 = lane & 15;
-    int voff[DB][2], xoff[2];
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-        const int r = 4 * lh + (p16 >> 2) + 8 * hf;
-#pragma unroll
-        for (int d = 0; d < DB; ++d) {
-            const int u = 4 * d + 2 * (g16 & 1) + ((p16 & 3) >> 1);
-            voff[d][hf] = (r * CHP + swz<CHP>(r, u)) * 16 + (p16 & 1) * 8;
-        }
-        // piece = queries 16 (g16 & 1) + 4 (p16 & 3) + 0..3 of the block: register half g16 & 1, group (p16 & 3) >> 1, lane half p16 & 1
-        xoff[hf] = ((qb * 2 + (g16 & 1)) * 64 + (p16 & 1) * 32 + r) * 16 + ((p16 & 3) >> 1) * 8 + S::IMG + my_tile * GTA_DS_TILE;
-    }
-
-    for (int j = 0; j < n_tiles; ++j) {
-        // stage j has landed when at most the stages requested after it are in flight (wave-uniform counts)
-        const int newer = n_tiles - 1 - j < NST - 2 ? n_tiles - 1 - j : NST - 2;
-        if (newer >= 3)      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PW) : "memory");
-        else if (newer == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
-        else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
-        else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (j + NST - 1 < n_tiles) request(j + NST - 1);         // into the stage every wave left in step j - 1
-        const uint32_t kbase_l = lds_addr(ring + (j % NST) * S::STAGE);
-        constexpr int SL = 16 * CHP * 16;
-        constexpr int X1 = 16 * 16, X2 = 4096;            // slab 1: keys 16..31 of the block (lanes 16..31); slabs 2, 3: the next 32-key block
-        u32x2_t xlo[4], xhi[4];
-        xlo[0] = lds_tr16_b64<0>(kbase_l + xoff[0]);       xhi[0] = lds_tr16_b64<0>(kbase_l + xoff[1]);
-        xlo[1] = lds_tr16_b64<X1>(kbase_l + xoff[0]);      xhi[1] = lds_tr16_b64<X1>(kbase_l + xoff[1]);
-        xlo[2] = lds_tr16_b64<X2>(kbase_l + xoff[0]);      xhi[2] = lds_tr16_b64<X2>(kbase_l + xoff[1]);
-        xlo[3] = lds_tr16_b64<X2 + X1>(kbase_l + xoff[0]); xhi[3] = lds_tr16_b64<X2 + X1>(kbase_l + xoff[1]);
-        u32x2_t klo[2][4], khi[2][4];
-        auto tr_reads = [&](int d, int set) {
-            const uint32_t a0 = kbase_l + voff[d][0], a1 = kbase_l + voff[d][1];
-            klo[set][0] = lds_tr16_b64<0>(a0);      khi[set][0] = lds_tr16_b64<0>(a1);
-            klo[set][1] = lds_tr16_b64<SL>(a0);     khi[set][1] = lds_tr16_b64<SL>(a1);
-            klo[set][2] = lds_tr16_b64<2 * SL>(a0); khi[set][2] = lds_tr16_b64<2 * SL>(a1);
-            klo[set][3] = lds_tr16_b64<3 * SL>(a0); khi[set][3] = lds_tr16_b64<3 * SL>(a1);
-        };
-        tr_reads(0, 0);
-        static_for_bwd<DB>([&](auto DC) {
-            constexpr int d = decltype(DC)::value, set = d & 1;
-            if constexpr (d + 1 < DB) {
-                tr_reads(d + 1, set ^ 1);
-                asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int sl = 0; sl < 4; ++sl) {
-                const u32x4_t av = {klo[set][sl].x, klo[set][sl].y, khi[set][sl].x, khi[set][sl].y};
-                const u32x4_t bv = {xlo[sl].x, xlo[sl].y, xhi[sl].x, xhi[sl].y};
-                dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av), __builtin_bit_cast(bf16x8_t, bv), dq[d], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    }
-
-    // ---- epilogue: dq = A_q^T (c1 dQ') ; d trans_coeff through A_q ----
-    const float c1 = p.scale / (p.tau ? *p.tau : 1.0f);
-    __syncthreads();
-    float* ost = reinterpret_cast<float*>(smem + S::OFF_RING);
-    {
-        const int r = wave * 32 + l31;
-#pragma unroll
-        for (int d = 0; d < DB; ++d)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4_t v = {dq[d][4 * g] * c1, dq[d][4 * g + 1] * c1, dq[d][4 * g + 2] * c1, dq[d][4 * g + 3] * c1};
-                *reinterpret_cast<f32x4_t*>(ost + r * S::OROW + 32 * d + 8 * g + 4 * lh) = v;
-            }
-    }
-    __syncthreads();
-    const char* qg = (const char*)p.q + ((long)b * p.q_sb + (long)h * p.q_sh) * ESZ;
-    char* dqg = (char*)p.dq + ((long)b * p.dq_sb + (long)h * p.dq_sh) * ESZ;
-    float dcpart = 0.f, dtpart = 0.f;
-    const bool want_dtau = p.dt_partial != nullptr;
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-        const int item = wave + 4 * it;
-        const int c = item >> 1;
-        const int r = lane + 64 * (item & 1);
-        const int t = q0 + r;
-        if (c < ch_real && t < p.Tq) {
-            const uint32_t desc = p.ctab[c];
-            float x[1][8];
-            const f32x4_t a = *reinterpret_cast<const f32x4_t*>(ost + r * S::OROW + 8 * c);
-            const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(ost + r * S::OROW + 8 * c + 4);
-            x[0][0] = a.x; x[0][1] = a.y; x[0][2] = a.z; x[0][3] = a.w;
-            x[0][4] = bb.x; x[0][5] = bb.y; x[0][6] = bb.z; x[0][7] = bb.w;
-            if (desc) {
-                const int n = view_of(t, p.Pq, p.invPq) - n_first;
-                const float* rc = rec + n * BREC;
-                if (!(desc & GTA_CHUNK_SO3) && (cd_lo(desc) == GTA_HALF_SE3 || cd_hi(desc) == GTA_HALF_SE3)) {
-                    float q8[8];
-                    g_load_chunk<ESZ>(qg + (long)t * p.q_st * ESZ, c, q8);
-                    const float t0 = rc[BREC_T], t1 = rc[BREC_T + 1], t2 = rc[BREC_T + 2];
-                    if (cd_lo(desc) == GTA_HALF_SE3) dcpart += x[0][3] * (t0 * q8[0] + t1 * q8[1] + t2 * q8[2]);
-                    if (cd_hi(desc) == GTA_HALF_SE3) dcpart += x[0][7] * (t0 * q8[4] + t1 * q8[5] + t2 * q8[6]);
-                }
-                f32x2_t cs[4];
-                if (p.cs_q) load_cs(desc, p.cs_q + ((long)b * p.Tq + t) * 2 * p.nso2, cs);
-                // A_q^T = E.m (record slot MT), D^T, R^T
-                chunk_apply<true, 1>(desc, rc + BREC_MT, rc + BREC_D1T, rc + BREC_D2T, cs, x);
-            }
-            g_store_chunk<ESZ>(dqg + (long)t * p.dq_st * ESZ, c, x[0]);
-            if (want_dtau) {                  // d tau = -(1/tau) sum <q, dq>  (gta_hip.h)
-                float q8[8];
-                g_load_chunk<ESZ>(qg + (long)t * p.q_st * ESZ, c, q8);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) dtpart += x[0][i] * q8[i];
-            }
-        }
-    }
-    const float dc_wg = wg_sum256(dcpart, reinterpret_cast<float*>(smem + S::OFF_SCR), tid);
-    if (tid == 0) p.dc_partial[p.dc_off_dq + w] = dc_wg;
-    if (want_dtau) {
-        __syncthreads();
-        const float dt_wg = wg_sum256(dtpart, reinterpret_cast<float*>(smem + S::OFF_SCR), tid);
-        if (tid == 0) p.dt_partial[w] = dt_wg;
-    }
-}
-
-// ================================================================================================
 // 3. dK, dV
 // ================================================================================================
 template <int DHP>
@@ -904,11 +700,8 @@ __global__ __launch_bounds__(256, (DHP > 96 ? 1 : 2)) void gta_bwd_dkv_kernel(co
         // (every thread issues exactly one load so the counted vmcnt below is wave-uniform)
         float st_next = 0.f;
         if (j + 1 < n_qt) st_next = gstats[(long)(j + 1) * 128 + (tid & 127)];
-        // (with the dS-tile plan the previous step's four tile stores sit between this step's DMA pieces and the next step's in
-        //  the counter: the same count + 4 still leaves exactly the newer stage in flight)
         if (j + 1 < n_qt) {
-            if (p.dsimg && my_kt < n_my_kt && j > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE + 1 + 4) : "memory");
-            else                                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE + 1) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE + 1) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -948,23 +741,6 @@ __global__ __launch_bounds__(256, (DHP > 96 ? 1 : 2)) void gta_bwd_dkv_kernel(co
             bf16x8_t pf[2], dsf[2];
             pf[0] = __builtin_bit_cast(bf16x8_t, pack_acc8(s, 0));   pf[1] = __builtin_bit_cast(bf16x8_t, pack_acc8(s, 1));
             dsf[0] = __builtin_bit_cast(bf16x8_t, pack_acc8(ds, 0)); dsf[1] = __builtin_bit_cast(bf16x8_t, pack_acc8(ds, 1));
-            // dS-tile plan (gta_bwd_dq2_kernel): the bf16 dS^T words just formed go out as the image of the (key tile, query tile)
-            // pair, so that the dQ kernel runs dQ'^T += K'^T dS^T alone (keys past Tk: zeros)
-            if (p.dsimg && my_kt < n_my_kt) {
-                // tile image [32-key block][32-query block][register half][lane][16 B]: the lane's packed words as they are, 1 KiB per
-                // wave-instruction (row-major tiles meant 64 separate 8-B writes per instruction: +120 us on this kernel)
-                int ln = lane;
-                asm volatile("" : "+v"(ln));       // (addresses from the lane id at the point of use: nothing new stays live across the loop)
-                u32x4_t w0 = __builtin_bit_cast(u32x4_t, dsf[0]), w1 = __builtin_bit_cast(u32x4_t, dsf[1]);
-                if (k0 + BK > p.Tk && !(k0 + wave * 32 + (ln & 31) < p.Tk)) {      // (only the workgroup with the ragged key tile pays for the select)
-                    w0 = u32x4_t{0u, 0u, 0u, 0u};
-                    w1 = u32x4_t{0u, 0u, 0u, 0u};
-                }
-                char* tile = (char*)p.dsimg + ((ktile0 + my_kt) * n_qt + j) * (long)GTA_DS_TILE + (((wave & 1) * 2 + qb) * 2) * 1024;   // (wave-uniform)
-                // (non-temporal: 839 MB of tiles at the MSN shape must not push the Q''/dO~ images, which the workgroups of a (b,h) share, out of L2)
-                __builtin_nontemporal_store(w0, reinterpret_cast<u32x4_t*>(tile + (unsigned)ln * 16u));
-                __builtin_nontemporal_store(w1, reinterpret_cast<u32x4_t*>(tile + 1024 + (unsigned)ln * 16u));
-            }
             // dV'^T += dO~^T P ; dK'^T += Q''^T dS   (A operands by transpose-read of the row-major images)
             const uint32_t qb_l = lds_addr(qi) + qb * 32 * CHP * 16, db_l = lds_addr(di) + qb * 32 * CHP * 16;
             // the transpose-reads of channel block d + 1 are requested before the MFMAs of block d (two register sets)
@@ -1091,14 +867,8 @@ int run_bwd(const GtaBwdParams& p, hipStream_t stream) {
     hipLaunchKernelGGL((gta_bwd_prep_kernel<DHP, ESZ>), dim3((unsigned)prep_grid), dim3(256), lds_prep, stream, p);
     const int n_dq = p.B * p.H * ((p.Tq + 127) / 128);
     const int n_dkv = p.B * p.H * ((p.Tk + 127) / 128);
-    if (p.dsimg) {       // dS-tile plan: dK/dV first (it writes the dS^T tiles), then the dQ stream over them
-        if (int rc = gta_lds_optin<&gta_bwd_dq2_kernel<DHP, ESZ>>(Dq2Smem<DHP>::total(GTA_MAX_VIEWS))) return rc;
-        hipLaunchKernelGGL((gta_bwd_dkv_kernel<DHP, ESZ>), dim3(n_dkv), dim3(256), DkvSmem<DHP>::total(p.vrep_k ? p.Nk : 0), stream, p);
-        hipLaunchKernelGGL((gta_bwd_dq2_kernel<DHP, ESZ>), dim3(n_dq), dim3(256), Dq2Smem<DHP>::total(p.vrep_q ? p.Nq : 0), stream, p);
-    } else {
-        hipLaunchKernelGGL((gta_bwd_dq_kernel<DHP, ESZ>), dim3(n_dq), dim3(256), DqSmem<DHP>::total(p.vrep_q ? p.Nq : 0), stream, p);
-        hipLaunchKernelGGL((gta_bwd_dkv_kernel<DHP, ESZ>), dim3(n_dkv), dim3(256), DkvSmem<DHP>::total(p.vrep_k ? p.Nk : 0), stream, p);
-    }
+    hipLaunchKernelGGL((gta_bwd_dq_kernel<DHP, ESZ>), dim3(n_dq), dim3(256), DqSmem<DHP>::total(p.vrep_q ? p.Nq : 0), stream, p);
+    hipLaunchKernelGGL((gta_bwd_dkv_kernel<DHP, ESZ>), dim3(n_dkv), dim3(256), DkvSmem<DHP>::total(p.vrep_k ? p.Nk : 0), stream, p);
     if (p.dtrans_coeff)
         hipLaunchKernelGGL(gta_reduce_kernel, dim3(1), dim3(1024), 0, stream, p.dc_partial, p.dc_total, p.dtrans_coeff,
                            (const float*)nullptr);

@@ -10,7 +10,6 @@ struct GtaBwdParams {
     const void* kvimg;        // K'/V' tile images (forward workspace layout)
     void* qimg;               // Q''/dO~ tile images   [B,H,n_qt64][2 images]
     float* stats;             // [B,H,n_qt64][128] = lse*log2e | D
-    void* dsimg;              // dS-tile plan: bf16 dS^T tile images [B,H,n_kt64,n_qt64][64 keys x 64 queries] (or null: recompute plan)
     float* dc_partial;        // per-workgroup d trans_coeff partial sums
     float* dtrans_coeff;      // [1] or null
     float* dt_partial;        // per-dQ-workgroup sum of <q, dq> (d tau), or null

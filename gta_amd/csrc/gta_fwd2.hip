@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256, (DHP <= 64 ? 3 : 2)) void gta_fwd2_kernel(cons
     const int ch_real = pp->dh >> 3;
     char* ring = smem + S::OFF_RING;
 
-    // per work item, when a profile buffer is set (gta_debug_set_profile_buffer): [0] start, [4] end (s_memtime: shader cycles),
+    // per work item, when a profile buffer is set (gta_debug_profile_next_attention_kernel): [0] start, [4] end (s_memtime: shader cycles),
     // [5] / [6] start / end by s_memrealtime (100 MHz) -- what bench.py turns into kernel cycles and the granted clock.
     // Instrumented builds add [1] Q loads + records landed, [2] rho_q done, [3] tile loop done, [7] next item's loads issued.
 #define GTA_STAMP_ON(V_, k) do { if (pp->prof && tid == 0) pp->prof[(long)(V_) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -761,8 +761,10 @@ long gta_fwd2_qtiles_offset(int B, int H, int Tk, int dhp) {
     const long img = (gta_fwd2_image_bytes(B, H, Tk, dhp) + 255) & ~255L;
     return img + (((long)B * H * n_tiles * 4 + 255) & ~255L);
 }
-long gta_fwd2_workspace_bytes(int B, int H, int Tk, int dhp, int Nq) {
-    return gta_fwd2_qtiles_offset(B, H, Tk, dhp) + (dhp == 96 ? (long)B * Nq * GTA_QT_TILES * GTA_QT_BYTES : 0L);
+// (the q-side tiles exist for the one instance that uses them: bf16 inputs at dh = 96 -- the only part of the workspace whose size
+//  depends on the QUERY side, through Nq)
+long gta_fwd2_workspace_bytes(int B, int H, int Tk, int dhp, int Nq, int esz) {
+    return gta_fwd2_qtiles_offset(B, H, Tk, dhp) + (dhp == 96 && esz == 2 ? (long)B * Nq * GTA_QT_TILES * GTA_QT_BYTES : 0L);
 }
 int gta_fwd2_lds_bytes(int dhp, int nrec) {
     switch (dhp) {

@@ -210,6 +210,7 @@ extern "C" int gta_build_so2_table(const float* coord, int32_t n_tokens, int32_t
                                    float max_freq_h, float max_freq_w, int32_t shared_freqs,
                                    float* cs, void* stream) {
     if (!coord || !cs || n_tokens <= 0 || nfreqs <= 0) return GTA_E_BADARG;
+    if (((uintptr_t)coord & 7) || ((uintptr_t)cs & 15)) return GTA_E_BADARG;      // float2 loads of coord, float4 stores of cs (gta_hip.h)
     const double two_pi = 6.283185307179586;
     const float k_h = (float)((double)max_freq_h * two_pi);
     const float k_w = (float)((double)max_freq_w * two_pi);
@@ -224,6 +225,7 @@ extern "C" int gta_build_reps(const float* extrinsics, int32_t n_views, int32_t 
                               const float* coord, int32_t n_tokens, int32_t nfreqs, float max_freq_h,
                               float max_freq_w, int32_t shared_freqs, float* cs, void* stream) {
     if (!extrinsics || !vrep || n_views <= 0 || !coord || !cs || n_tokens <= 0 || nfreqs <= 0) return GTA_E_BADARG;
+    if (((uintptr_t)coord & 7) || ((uintptr_t)cs & 15)) return GTA_E_BADARG;      // float2 loads of coord, float4 stores of cs (gta_hip.h)
     if (so3_degree < 0 || so3_degree > 2) return GTA_E_UNSUPPORTED;
     const double two_pi = 6.283185307179586;
     const float k_h = (float)((double)max_freq_h * two_pi);

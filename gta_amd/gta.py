@@ -244,7 +244,12 @@ class _GtaAttn(torch.autograd.Function):
                     raise native.GtaError("kv_cache holds images of a different key set")
                 desc.flags = flags | native.FLAG_KV_READY
             else:
-                ws = torch.empty(native.attn_fwd_workspace_bytes(desc), device=q.device, dtype=torch.uint8)
+                need = native.attn_fwd_workspace_bytes(desc)
+                if kv_cache is not None:
+                    # the workspace's tail (query-side operand tiles, bf16 at dh = 96) grows with the number of QUERY views: a cache
+                    # serves later query sets against the same keys, so it is sized for the most views a call can have
+                    need += max(0, native.MAX_VIEWS - Nq) * B * 24 * 1024
+                ws = torch.empty(need, device=q.device, dtype=torch.uint8)
                 if kv_cache is not None:
                     kv_cache["images"] = ws
         if ws is not None and _GtaAttn.flash_events is not None and not (desc.flags & native.FLAG_KV_READY):
@@ -413,16 +418,6 @@ def _generic_forward(q, k, v, f_dims, packed, so3_degree, trans_coeff, tau, scal
     return _GenericAttn.apply(q, k, v, tc, ta, (f_dims, so3_degree, scale, v_transform, euclid, precise), packed)
 
 
-# Module-level default of ``gta_attention(precise=None)``: True makes every float32 call use the split-bf16 products
-# (GTA_FLAG_FP32_PRODUCTS) -- the setting for the reference's ``mixed_prec: False`` configs (runs/clevrtr/GTA/gta).
-PRECISE_FP32 = False
-
-
-# Backward plan (include/gta_hip.h): True = GTA_FLAG_BWD_DS_TILES, the dK/dV kernel writes its bf16 dS^T tiles and the dQ kernel streams them
-# (10 GEMM-units instead of 14, workspace + 2 B per (query, key) pair and head); same speed as the default at the MSN shapes.
-BWD_DS_TILES = bool(int(os.environ.get("GTA_BWD_DS_TILES", "0")))
-
-
 def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: int = 0,
                   trans_coeff=None, tau=None, scale: Optional[float] = None, v_transform: bool = True,
                   euclid: bool = False, pretransformed: bool = False, use_dma: bool = True,
@@ -433,7 +428,7 @@ def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: 
                          the 64-rows-per-wave one of gta_fwd64.hip, 'prepass_rows32' keeps gta_fwd2.hip's);
              'fused'   = one kernel, rho_k applied inside the attention loop;
              'auto'    = 'prepass' when several query tiles share each key tile, else 'fused'.
-    precise: float32 inputs only.  False (default unless ``gta.PRECISE_FP32``): operands are rounded to bf16 once, after
+    precise: float32 inputs only.  False / None (default): operands are rounded to bf16 once, after
              rho, and the two contractions run on the bf16 MFMA (fp32 accumulation) -- the reference's bf16-autocast
              accuracy.  True: operands are kept as bf16 hi+lo pairs and every product is three MFMAs -- fp32-class results
              (max |error| ~1e-5 of max |out|) at 3x the matrix work, single-kernel plan; the backward stays bf16-product.
@@ -459,10 +454,7 @@ def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: 
         kv_mode = "prepass"
     if kv_mode not in ("auto", "prepass", "fused"):
         raise ValueError(f"kv_mode {kv_mode!r}")
-    if BWD_DS_TILES:
-        flags |= native.FLAG_BWD_DS_TILES
-    if precise is None:
-        precise = PRECISE_FP32 and q.dtype == torch.float32
+    precise = bool(precise)
     if precise:
         if q.dtype != torch.float32:
             raise native.GtaError("precise=True is for float32 inputs (bf16 inputs ask for bf16 arithmetic)")

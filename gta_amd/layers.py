@@ -6,8 +6,8 @@ the reference's ``Attention`` (layers.py:172-444), ``Transformer`` (:447-488), `
 reference checkpoint loads with ``load_state_dict(strict=True)``.  The attention core is the
 fused HIP kernel.  On an MI355X ``Transformer`` runs each layer as the fused block of ``gta_amd.fused`` (LayerNorm+cast
 kernel, hipBLASLt GEMMs with bias / skip / GELU epilogues, LayerNorm backward fused with the skip gradient; SURVEY.md
-section 8 row f1); ``FUSED_BLOCKS = False`` (or env ``GTA_FUSED_BLOCKS=0``) keeps the module-by-module path, which is
-also what ``Attention`` / ``PreNorm`` / ``FeedForward`` do when called on their own.
+section 8 row f1); ``Transformer.fused_blocks = False`` on an instance (env ``GTA_FUSED_BLOCKS=0`` sets the default at construction)
+keeps the module-by-module path, which is also what ``Attention`` / ``PreNorm`` / ``FeedForward`` do when called on their own.
 Only ``method: gta`` is built -- the other positional-encoding baselines of the reference
 (repast/ape/mln/gbt/rpe/frustum) are out of scope.
 """
@@ -24,8 +24,9 @@ from . import fused as _fused
 from . import gta as _gta
 from . import native
 
-# run Transformer layers as fused blocks (gta_amd.fused) where they qualify
-FUSED_BLOCKS = os.environ.get("GTA_FUSED_BLOCKS", "1") != "0"
+def _fused_blocks_default() -> bool:
+    """construction-time default of ``Transformer.fused_blocks``: run layers as fused blocks (gta_amd.fused) where they qualify"""
+    return os.environ.get("GTA_FUSED_BLOCKS", "1") != "0"
 
 
 class JaxLinear(nn.Linear):
@@ -113,6 +114,10 @@ class Attention(nn.Module):
         else:
             self.attend = None
         self.euclid = self.method_args.get("euclid_sim", False)
+        # fp32-faithful products for float32 inputs (split-bf16 operands): a per-module setting -- the reference's
+        # ``mixed_prec: False`` configs (runs/clevrtr/GTA/gta/config.yaml:55) set it through ``attn_args['method']['args']['precise']``
+        # or on the instance; bf16 / autocast inputs are not affected
+        self.precise = bool(self.method_args.get("precise", False))
         if kv_dim is not None:
             self.to_q = linear_module(dim, inner_dim, bias=use_bias)
             self.to_kv = linear_module(kv_dim, 2 * inner_dim, bias=use_bias)
@@ -168,7 +173,7 @@ class Attention(nn.Module):
             so3_degree=_gta._so3_degree(self.f_dims, packed, extras),
             trans_coeff=self.trans_coeff, tau=tau,
             scale=self.scale, v_transform=self.method_args.get("v_transform", True), euclid=self.euclid,
-            kv_cache=kv_cache)
+            kv_cache=kv_cache, precise=self.precise and q.dtype == torch.float32 and kv_cache is None)
         out = out.permute(0, 2, 1, 3).reshape(B, Tq, H * dh)              # free: out is [B,Tq,H,dh] in memory
         attn = None
         if return_attmap:                                                  # layers.py:441-442
@@ -209,10 +214,11 @@ class Transformer(nn.Module):
             ff = PreNorm(dim, FeedForward(dim, mlp_dim, dropout=dropout, linear_module=ViTLinear))
             self.layers.append(nn.ModuleList([attn, ff]))
         self.return_last_attmap = return_last_attmap
+        self.fused_blocks = _fused_blocks_default()       # per instance: False keeps the module-by-module path
 
     def _fused_dtype(self, x, attn, ff):
         """Compute dtype of the fused block for this layer and input, or None -> module-by-module path."""
-        if not FUSED_BLOCKS or not isinstance(attn.fn, Attention):
+        if not self.fused_blocks or not isinstance(attn.fn, Attention):
             return None
         cdt = _fused.compute_dtype(x)
         if cdt is None or x.dim() != 3:

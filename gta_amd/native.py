@@ -28,7 +28,6 @@ FLAG_NO_DMA = 1 << 8
 FLAG_PERSIST = 1 << 9
 FLAG_FP32_PRODUCTS = 1 << 10
 FLAG_ROWS32 = 1 << 11
-FLAG_BWD_DS_TILES = 1 << 12
 VREP_STRIDE = 72
 VREP_INV, VREP_REP, VREP_D1, VREP_D2 = 0, 16, 32, 41
 MAX_VIEWS = 16
@@ -40,7 +39,7 @@ ABI_SYMBOLS = (
     "gta_rep_apply", "gta_attn_fwd_plain",
     "gta_strerror", "gta_abi_version", "gta_sizeof_attn_desc",
     "gta_debug_time_next_attention_kernel", "gta_debug_event_create", "gta_debug_event_destroy", "gta_debug_event_elapsed_ms",
-    "gta_debug_set_profile_buffer", "gta_debug_attention_kernel",
+    "gta_debug_profile_next_attention_kernel", "gta_debug_attention_kernel",
 )
 
 
@@ -107,8 +106,8 @@ def lib():
         L.gta_debug_event_destroy.restype = None
         L.gta_debug_event_elapsed_ms.argtypes = [c_void_p, c_void_p]
         L.gta_debug_event_elapsed_ms.restype = c_float
-        L.gta_debug_set_profile_buffer.argtypes = [c_void_p]
-        L.gta_debug_set_profile_buffer.restype = None
+        L.gta_debug_profile_next_attention_kernel.argtypes = [c_void_p, c_int64]
+        L.gta_debug_profile_next_attention_kernel.restype = None
         L.gta_debug_attention_kernel.argtypes = [ctypes.POINTER(GtaAttnDesc), ctypes.POINTER(c_int32), ctypes.POINTER(c_int32)]
         L.gta_debug_attention_kernel.restype = ctypes.c_char_p
         _lib = L

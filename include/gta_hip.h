@@ -45,8 +45,6 @@ extern "C" {
                                          /* results for the reference's mixed_prec: False configs, single-kernel plan, 3x the MFMAs */
 #define GTA_FLAG_ROWS32        (1u << 11) /* tuning: keep the 32-rows-per-wave attention kernel (gta_fwd2.hip) where the     */
                                           /* 64-rows-per-wave one (gta_fwd64.hip: dh = 96, whole ring turns of key tiles) would run */
-#define GTA_FLAG_BWD_DS_TILES  (1u << 12) /* backward: the dK/dV kernel writes its bf16 dS^T tiles and the dQ kernel streams them (10 GEMM-units */
-                                          /* instead of 14, + 2 B per (query, key) pair and head of workspace); default: the dQ kernel recomputes S, dP */
 #define GTA_FLAG_NO_DMA        (1u << 8) /* debug: stage K/V tiles through VGPRs, not LDS-DMA  */
 
 /* error codes */
@@ -103,14 +101,16 @@ int gta_build_view_reps(const float* extrinsics, int32_t n_views, int32_t so3_de
 
 /* coord [n_tokens,2] fp32 in [0,1) (extras['input_coord'] / ['target_coord'] flattened) ->
  * cs [n_tokens, 2*nfreqs, 2] = (cos, sin) of theta_{t, c=2f+d} = max_freq_d * 2pi * coord_d *
- * 2^(f+1-F)  (make_SO2mats, gta.py:47-69; block order c = 2f+d from gta.py:68 + encoder.py:195). */
+ * 2^(f+1-F)  (make_SO2mats, gta.py:47-69; block order c = 2f+d from gta.py:68 + encoder.py:195).
+ * Alignment: coord 8 bytes, cs 16 bytes (the kernel moves a token's coordinate pair and a frequency's two (cos, sin) pairs in one
+ * access each); anything else returns GTA_E_BADARG. */
 int gta_build_so2_table(const float* coord, int32_t n_tokens, int32_t nfreqs,
                         float max_freq_h, float max_freq_w, int32_t shared_freqs,
                         float* cs, void* stream);
 
 /* Both of the above in ONE launch (they are independent and launch-latency sized): what
  * pre_compute_reps (source/encoder.py:183-265) does for a gta_so3-style config in one call.
- * Arguments as for gta_build_view_reps followed by those of gta_build_so2_table. */
+ * Arguments (and alignment requirements) as for gta_build_view_reps followed by those of gta_build_so2_table. */
 int gta_build_reps(const float* extrinsics, int32_t n_views, int32_t so3_degree, float* vrep,
                    const float* coord, int32_t n_tokens, int32_t nfreqs, float max_freq_h,
                    float max_freq_w, int32_t shared_freqs, float* cs, void* stream);
@@ -138,7 +138,11 @@ int gta_attn_fwd(const GtaAttnDesc* desc,
  *   workspace of >= gta_attn_fwd_workspace_bytes(desc) bytes: a K/V pre-pass writes K' = rho_k K,
  *       V' = rho_k V once as bf16 tile images into the workspace, then a lean attention kernel
  *       streams them.  The workspace content stays valid for other query sets against the same
- *       keys (GTA_FLAG_KV_READY) and is what the backward consumes. */
+ *       keys (GTA_FLAG_KV_READY) and is what the backward consumes.
+ *   Size: [K'/V' images | per-tile key norms] depend on (B, H, Tk, dh) only.  For bf16 inputs at dh in (64, 96] the workspace ends
+ *       with B * Nq * 24 KiB of query-side operand tiles (rewritten by every call), so the size ALSO depends on the query side's
+ *       number of views: a workspace kept for GTA_FLAG_KV_READY calls must be sized for the largest Nq it will see (query the size
+ *       with that Nq; a too-small buffer returns GTA_E_BADARG). */
 int64_t gta_attn_fwd_workspace_bytes(const GtaAttnDesc* desc);
 
 /* -------------------------------------------------------------------------------------------
@@ -147,10 +151,7 @@ int64_t gta_attn_fwd_workspace_bytes(const GtaAttnDesc* desc);
  *            dout [B,H,Tq,dh] with element strides dout_stride[3] (b,h,t), reps as in the forward.
  *   kv_images: the forward's workspace (K'/V' tile images) or NULL -> recomputed here.
  *   plan     : Q''/dO~ pre-pass -> dQ kernel -> dK/dV kernel, each recomputing S and dP from the images (14 GEMM-units).
- *              GTA_FLAG_BWD_DS_TILES: the dK/dV kernel runs first and writes every bf16 dS^T = P (dP - D) tile it forms, the dQ
- *              kernel streams those tiles (dQ' = dS K' only: 10 units; workspace larger by B H ceil(Tq/64) ceil(Tk/64) 8 KiB).  On
- *              MI355X the two plans take the same time at the MSN shapes (the tile stream is bound by the LDS-DMA path, DESIGN.md
- *              4.3).  The flag must be the same in the workspace query and in the call.  Deterministic either way (no atomics).
+ *              Deterministic (no atomics: fixed-order reductions).
  *   outputs: dq, dk, dv with element strides dqkv_stride[9] = dq(b,h,t), dk(b,h,t), dv(b,h,t);
  *            dtrans_coeff [1] fp32 (d loss / d trans_coeff, layers.py:191) or NULL;
  *            dtau [1] fp32 (d loss / d tau of TemperatureAdjsutableSoftmax, layers.py:135-143,195-200) or
@@ -214,16 +215,17 @@ int gta_attn_fwd_launch_info(const GtaAttnDesc* desc, int32_t* lds_bytes, int32_
  *     bracketed by the two events through the dispatch packet itself (hipExtLaunchKernelGGL), i.e. without the marker
  *     packets of hipEventRecord that push neighbouring kernels apart.  One-shot.
  *   gta_debug_event_*: thin wrappers so a ctypes caller needs no second HIP binding.
- *   gta_debug_set_profile_buffer: device buffer [n_items][8] of uint64 (or NULL): the two-stage plan's attention kernel writes, per
- *       work item, [0] / [4] = s_memtime at its start / end (shader cycles) and [5] / [6] = s_memrealtime (100 MHz) -- kernel cycles
- *       and the granted shader clock of a launch follow from them; -DGTA_ABLATE builds add per-phase stamps.
+ *   gta_debug_profile_next_attention_kernel: device buffer [capacity_items][8] of uint64 (or NULL): the NEXT attention kernel launched
+ *       by THIS thread through gta_attn_fwd writes, per work item, [0] / [4] = s_memtime at its start / end (shader cycles) and
+ *       [5] / [6] = s_memrealtime (100 MHz) -- kernel cycles and the granted shader clock of a launch follow from them; -DGTA_ABLATE
+ *       builds add per-phase stamps.  One-shot and thread-local; a launch with more work items than capacity_items writes nothing.
  *   gta_debug_attention_kernel: name of the attention kernel a workspace call of gta_attn_fwd launches for desc, its number of
  *       work items and query rows per item ("" if desc is not supported). */
 void gta_debug_time_next_attention_kernel(void* start_event, void* stop_event);
 void* gta_debug_event_create(void);
 void gta_debug_event_destroy(void* event);
 float gta_debug_event_elapsed_ms(void* start_event, void* stop_event);
-void gta_debug_set_profile_buffer(void* device_buffer);
+void gta_debug_profile_next_attention_kernel(void* device_buffer, int64_t capacity_items);
 const char* gta_debug_attention_kernel(const GtaAttnDesc* desc, int32_t* n_items, int32_t* rows_per_item);
 
 const char* gta_strerror(int code);

@@ -112,3 +112,10 @@ def test_bench_launch_contract_dry_run_world2():
     assert rec["ms_per_step"] >= max(rec["per_rank_ms_per_step"]) * 0.95
     assert rec["per_rank_ms_per_step"][1] > rec["per_rank_ms_per_step"][0]
     assert rec["config"]["global_batch"] == 64 and rec["config"]["parallelism"] == "dp2"
+    # launched on more than one rank without --model-train-steps, the line carries the whole-model leg: optimizer steps under the two
+    # DDP instances of train.py:182-188 and the gradient all-reduce's bucket timeline (the north star's one collective)
+    st = rec["srt_train"]
+    assert st["steps"] == 5 and st["ms_per_step"] > 0 and st["scenes_per_s"] > 0 and st["ddp"].startswith("two DistributedDataParallel")
+    assert set(st["grad_allreduce"]) == {"encoder", "decoder"}
+    enc = st["grad_allreduce"]["encoder"]
+    assert enc["buckets_per_step"] >= 1 and enc["bytes_per_step"] == (16 * 32 + 32 + 32 * 16 + 16) * 4

@@ -137,12 +137,9 @@ def test_tau_gradient_vs_oracle_autograd(shape, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", ["MS-enc", "MS-dec", "CL-dec", "ragged", "many-views", "wide-ragged"])
-def test_backward_plans_agree(shape, dtype):
-    """The dS-tile plan (GTA_FLAG_BWD_DS_TILES: the dK/dV kernel writes its bf16 dS^T tiles, the dQ kernel streams them) against the
-    default plan in which the dQ kernel recomputes S and dP: the same bf16 dS words enter the same dQ' accumulation in
-    the same order, so dq agrees to rounding of the recomputed scores; dk, dv and d trans_coeff come from the same kernel and must
-    be bit-identical -- as must two runs of either plan (no atomics anywhere in the backward)."""
-    from gta_amd import gta as G_
+def test_backward_is_bit_reproducible(shape, dtype):
+    """Two runs of the backward on the same inputs agree bit for bit: no atomics anywhere (the per-row D, d trans_coeff and d tau are
+    fixed-order sums)."""
     B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3 = SHAPES[shape]
     q, k, v, ex, ak, cross = C.synth_inputs(B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, dtype, seed=23)
     w = torch.randn(q.shape, generator=torch.Generator().manual_seed(29)).cuda()
@@ -152,19 +149,12 @@ def test_backward_plans_agree(shape, dtype):
         gta_amd.pre_compute_reps_decoder(ak, exd)
     packed = gta_amd.pack_reps(exd, f_dims)
     res = {}
-    for run, tiles in enumerate((True, False, True)):
-        G_.BWD_DS_TILES = tiles
-        try:
-            qd, kd, vd = (t.to(dtype).cuda().requires_grad_() for t in (q, k, v))
-            tcd = torch.tensor([0.37], device="cuda", requires_grad=True)
-            out = gta_amd.gta_attention(qd, kd, vd, f_dims, packed, so3_degree=exd.get("gta_so3_degree", 0),
-                                        trans_coeff=tcd if f_dims.get("se3", 0) > 0 else None, kv_mode="prepass")
-            (out.float() * w).sum().backward()
-            torch.cuda.synchronize()
-        finally:
-            G_.BWD_DS_TILES = False
+    for run in range(2):
+        qd, kd, vd = (t.to(dtype).cuda().requires_grad_() for t in (q, k, v))
+        tcd = torch.tensor([0.37], device="cuda", requires_grad=True)
+        out = gta_amd.gta_attention(qd, kd, vd, f_dims, packed, so3_degree=exd.get("gta_so3_degree", 0),
+                                    trans_coeff=tcd if f_dims.get("se3", 0) > 0 else None, kv_mode="prepass")
+        (out.float() * w).sum().backward()
+        torch.cuda.synchronize()
         res[run] = (qd.grad.float().cpu(), kd.grad.float().cpu(), vd.grad.float().cpu(), float(tcd.grad.item()) if tcd.grad is not None else 0.0)
-    _check(res[0][0], res[1][0], "dq", 2e-3, 5e-4)
-    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
-    assert abs(res[0][3] - res[1][3]) <= 1e-3 * max(1.0, abs(res[1][3]))
-    assert all(torch.equal(res[0][i], res[2][i]) for i in range(3)) and res[0][3] == res[2][3]      # run-to-run
+    assert all(torch.equal(res[0][i], res[1][i]) for i in range(3)) and res[0][3] == res[1][3]

@@ -168,7 +168,7 @@ def _transformer(cross, seed=0, dim=128):
 
 
 def _run(tr, ex, x, z, fused_on, autocast):
-    layers.FUSED_BLOCKS = fused_on
+    tr.fused_blocks = fused_on
     try:
         for p in tr.parameters():
             p.grad = None
@@ -180,7 +180,7 @@ def _run(tr, ex, x, z, fused_on, autocast):
         torch.cuda.synchronize()
         return y.detach().float(), x.grad.clone(), {n: p.grad.clone() for n, p in tr.named_parameters()}
     finally:
-        layers.FUSED_BLOCKS = True
+        tr.fused_blocks = True
 
 
 @pytest.mark.parametrize("cross,dim", [(False, 128), (True, 128), (True, 180), (False, 180)])

@@ -168,7 +168,7 @@ def test_srt_encoder_blocks_bf16_stream():
     res = {}
     try:
         for name, fused_on, ac in (("ref", False, False), ("fused", True, True)):
-            layers.FUSED_BLOCKS = fused_on
+            tr.fused_blocks = fused_on
             for p in tr.parameters():
                 p.grad = None
             xi = (cap["x"].float() if not ac else cap["x"]).clone().requires_grad_(True)
@@ -178,7 +178,7 @@ def test_srt_encoder_blocks_bf16_stream():
             (y.float() * w).sum().backward()
             res[name] = (y.detach().float().cpu(), xi.grad.float().cpu(), {n: p.grad.float().cpu() for n, p in tr.named_parameters()})
     finally:
-        layers.FUSED_BLOCKS = True
+        tr.fused_blocks = True
     assert res["fused"][0].dtype == torch.float32
     assert C.err_stats(res["fused"][0], res["ref"][0])["rel_rms"] < 2e-2
     assert C.err_stats(res["fused"][1], res["ref"][1])["rel_rms"] < 4e-2

@@ -67,7 +67,7 @@ def test_baseline_shapes_fp32_faithful(shape):
 
 
 def test_precise_mode_contract():
-    """bf16 inputs are refused (they ask for bf16 arithmetic); the module-level default switches float32 calls; gradients
+    """bf16 inputs are refused (they ask for bf16 arithmetic); the mode is a per-call argument (per-module: Attention.precise); gradients
     flow (the backward stays on bf16 products)."""
     f_dims = {"se3": 32, "so2": 32}
     q, k, v, ex, ak, _ = C.synth_inputs(1, 2, 2, 40, 2, 40, f_dims, 8, 0, torch.float32, seed=2)
@@ -78,11 +78,7 @@ def test_precise_mode_contract():
     with pytest.raises(native.GtaError):
         gta_amd.gta_attention(q.cuda().bfloat16(), k.cuda().bfloat16(), v.cuda().bfloat16(), f_dims, packed, trans_coeff=tc, precise=True)
     a = gta_amd.gta_attention(q.cuda(), k.cuda(), v.cuda(), f_dims, packed, trans_coeff=tc, precise=True)
-    gta_amd.gta.PRECISE_FP32 = True
-    try:
-        b = gta_amd.gta_attention(q.cuda(), k.cuda(), v.cuda(), f_dims, packed, trans_coeff=tc)
-    finally:
-        gta_amd.gta.PRECISE_FP32 = False
+    b = gta_amd.gta_attention(q.cuda(), k.cuda(), v.cuda(), f_dims, packed, trans_coeff=tc, precise=True)
     assert torch.equal(a, b)
     qg = q.cuda().requires_grad_()
     out = gta_amd.gta_attention(qg, k.cuda(), v.cuda(), f_dims, packed, trans_coeff=tc, precise=True)

@@ -73,7 +73,7 @@ def audit_others():
         if int(dhp) <= 96 and int(esz) == 2 and vgpr > 96:
             problems.append(f"{row['kernel']}: {vgpr} VGPRs (five 4-wave workgroups per CU need <= 96; six would need <= 80)")
     text = _asm("gta_bwd.hip", ("-fno-slp-vectorize",))
-    for kern in ("gta_bwd_prep_kernel", "gta_bwd_dq_kernel", "gta_bwd_dq2_kernel", "gta_bwd_dkv_kernel"):
+    for kern in ("gta_bwd_prep_kernel", "gta_bwd_dq_kernel", "gta_bwd_dkv_kernel"):
         for name, (dhp, esz), body, vgpr in _kernels(text, kern + r"ILi(\d+)ELi(\d+)E"):
             row = {"kernel": f"{kern}<{dhp},{esz}>", "vgpr": vgpr, "scratch": body.count("scratch_")}
             report.append(row)

@@ -79,10 +79,10 @@ def main():
 
     modes = [m for m in (("modules", False), ("fused", True)) if args.mode in ("both", m[0])]
     for label, on in modes * 2:
-        layers.FUSED_BLOCKS = on
+        tr.fused_blocks = on
         print(f"{label:8s} B={B} mlp={args.mlp}: forward {timeit(fwd):8.1f} us/layer   forward+backward {timeit(fwd_bwd):8.1f} us/layer")
     for label, on in ([] if args.no_launch_count else modes):
-        layers.FUSED_BLOCKS = on
+        tr.fused_blocks = on
         for what, fn in (("forward", fwd), ("forward+backward", fwd_bwd)):
             try:
                 n, names = launches(fn)
@@ -92,7 +92,7 @@ def main():
                     print(f"      {v:3d} x {k[:110]}")
             except Exception as e:  # noqa: BLE001
                 print(f"{label} {what}: profiler unavailable ({type(e).__name__}: {str(e)[:100]})")
-    layers.FUSED_BLOCKS = True
+    tr.fused_blocks = True
 
 
 if __name__ == "__main__":

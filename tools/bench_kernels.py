@@ -194,10 +194,10 @@ if __name__ == "__main__":
             prof = torch.zeros(nwg * 3, 8, dtype=torch.int64, device="cuda")
             torch.cuda.synchronize()
             pre()
-            native.lib().gta_debug_set_profile_buffer(ctypes.c_void_p(prof.data_ptr()))
+            native.lib().gta_debug_profile_next_attention_kernel(ctypes.c_void_p(prof.data_ptr()), prof.shape[0])
             fn_flash()
             torch.cuda.synchronize()
-            native.lib().gta_debug_set_profile_buffer(None)
+            native.lib().gta_debug_profile_next_attention_kernel(None, 0)
             P = prof.cpu().double()[:nwg]
             real = P[:, 6] - P[:, 5]
             ok = real > 0
@@ -234,11 +234,11 @@ if __name__ == "__main__":
                 fn()
             t_us = time_call(fn) * 1e3
             prof = torch.zeros(nwg, 8, dtype=torch.int64, device="cuda")
-            native.lib().gta_debug_set_profile_buffer(ctypes.c_void_p(prof.data_ptr()))
+            native.lib().gta_debug_profile_next_attention_kernel(ctypes.c_void_p(prof.data_ptr()), prof.shape[0])
             torch.cuda.synchronize()
             fn()
             torch.cuda.synchronize()
-            native.lib().gta_debug_set_profile_buffer(None)
+            native.lib().gta_debug_profile_next_attention_kernel(None, 0)
             P = prof.cpu().double()
             if P.abs().sum() == 0:
                 print(f"== {label}: {t_us:.1f} us (no stamps: not an instrumented build)")

@@ -158,11 +158,11 @@ def timeline(B=32):
         torch.cuda.synchronize()
         nwg = B * 8 * (1280 // rows)
         prof = torch.zeros(nwg, 8, dtype=torch.int64, device="cuda")
-        native.lib().gta_debug_set_profile_buffer(ctypes.c_void_p(prof.data_ptr()))
+        native.lib().gta_debug_profile_next_attention_kernel(ctypes.c_void_p(prof.data_ptr()), prof.shape[0])
         torch.cuda.synchronize()
         fn()
         torch.cuda.synchronize()
-        native.lib().gta_debug_set_profile_buffer(None)
+        native.lib().gta_debug_profile_next_attention_kernel(None, 0)
         P = prof.cpu().double()
         if P.abs().sum() == 0:
             print(f"== {label}: no stamps (not an instrumented build)")
@@ -212,11 +212,11 @@ def variants(which, B=32):
     def stamps(f, rows):
         n = B * 8 * (1280 // rows)
         prof = torch.zeros(n, 8, dtype=torch.int64, device="cuda")
-        native.lib().gta_debug_set_profile_buffer(ctypes.c_void_p(prof.data_ptr()))
+        native.lib().gta_debug_profile_next_attention_kernel(ctypes.c_void_p(prof.data_ptr()), prof.shape[0])
         torch.cuda.synchronize()
         f()
         torch.cuda.synchronize()
-        native.lib().gta_debug_set_profile_buffer(None)
+        native.lib().gta_debug_profile_next_attention_kernel(None, 0)
         P = prof.cpu().double()
         real = P[:, 6] - P[:, 5]
         ok = real > 0
@@ -277,11 +277,11 @@ def phases(workload):
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 100
         prof = torch.zeros(B * H * ((Nq * Pq + 127) // 128), 8, dtype=torch.int64, device="cuda")
-        native.lib().gta_debug_set_profile_buffer(ctypes.c_void_p(prof.data_ptr()))
+        native.lib().gta_debug_profile_next_attention_kernel(ctypes.c_void_p(prof.data_ptr()), prof.shape[0])
         torch.cuda.synchronize()
         fn()
         torch.cuda.synchronize()
-        native.lib().gta_debug_set_profile_buffer(None)
+        native.lib().gta_debug_profile_next_attention_kernel(None, 0)
         P = prof.cpu().double()
         P = P[P[:, 4] > 0]
         real = P[:, 6] - P[:, 5]

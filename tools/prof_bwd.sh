@@ -1,9 +1,6 @@
-# kernel times of the operator's forward + backward under rocprofv3 (both backward plans)
+# kernel times of the operator's forward + backward under rocprofv3
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_bwd; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for plan in ds recompute; do
-  [ $plan = ds ] && export GTA_BWD_DS_TILES=1 || unset GTA_BWD_DS_TILES
-  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$plan -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity --block-steps 0 --train-steps 10 > $OUT/$plan.log 2>&1
-  f=$(ls $OUT/$plan/*/*kernel_stats.csv | head -1)
-  echo "== $plan"; head -8 $f | cut -d, -f1-5 | cut -c1-150
-done
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bwd -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity --block-steps 0 --train-steps 10 > $OUT/bwd.log 2>&1
+f=$(ls $OUT/bwd/*/*kernel_stats.csv | head -1)
+head -8 $f | cut -d, -f1-5 | cut -c1-150
