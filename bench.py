@@ -317,9 +317,10 @@ def main():
                     help="also time one whole pre-LN layer around the operator (SURVEY 8 f1: the fused block of libgta_block.so "
                          "against the module-by-module path), forward and forward+backward; reported as `block_layer`, not "
                          "part of `value`; 0 = skip")
-    ap.add_argument("--kv-mode", dest="kv_mode", default="prepass", choices=["prepass", "fused", "prepass_rows32"],
+    ap.add_argument("--kv-mode", dest="kv_mode", default="prepass", choices=["prepass", "fused", "prepass_rows32", "prepass_item_cxx"],
                     help="execution plan of gta_attn_fwd (see include/gta_hip.h); prepass_rows32 = GTA_FLAG_ROWS32: the 32-rows-per-wave "
-                         "attention kernel where the 64-rows one would run (A/B)")
+                         "attention kernel where the 64-rows one would run; prepass_item_cxx = GTA_FLAG_ITEM_CXX: the 64-rows kernel with its "
+                         "compiler-scheduled item prologue / epilogue where the generated item stream would run (A/B)")
     ap.add_argument("--precise", action="store_true",
                     help="fp32-faithful forward for fp32 inputs (GTA_FLAG_FP32_PRODUCTS: split-bf16 operands, three MFMAs per product, "
                          "single-kernel plan; the reference's mixed_prec: False configs); needs --dtype f32; no backward leg")
@@ -372,7 +373,8 @@ def main():
     reps_q = plan.RepPlan(B, Nq, Pq, so3_deg, so2, device=device) if (reps_k is not None and cross) else None
     fwd = plan.ForwardPlan(q, k, v, f_dims, so3_degree=so3_deg, Nq=Nq if need_view else 1, Nk=Nk if need_view else 1,
                            flags=(native.FLAG_FUSED_KV | (native.FLAG_FP32_PRODUCTS if args.precise else 0)) if fused
-                           else native.FLAG_ROWS32 if args.kv_mode == "prepass_rows32" else 0)
+                           else native.FLAG_ROWS32 if args.kv_mode == "prepass_rows32"
+                           else native.FLAG_ITEM_CXX if args.kv_mode == "prepass_item_cxx" else 0)
     n_it, rows_it = ctypes.c_int32(0), ctypes.c_int32(0)
     kname = (L.gta_debug_attention_kernel(ctypes.byref(fwd.desc), ctypes.byref(n_it), ctypes.byref(rows_it)) or b"").decode()
     n_samp = args.steps if args.kernel_samples <= 0 else min(args.kernel_samples, args.steps)

@@ -19,6 +19,7 @@ int gta_fwd_dispatch(const GtaFwdParams& p, int dhp, int esz, bool dma, int n_wg
 long gta_fwd2_workspace_bytes(int B, int H, int Tk, int dhp, int Nq, int esz);
 long gta_fwd2_qtiles_offset(int B, int H, int Tk, int dhp);
 int gta_fwd2_rows_per_item(const GtaFwdParams& p, int dhp, int esz);                   // 256: gta_attn64_kernel, 128: gta_fwd2_kernel
+const char* gta_fwd2_attention_kernel_name(const GtaFwdParams& p, int dhp, int esz);
 long gta_fwd2_image_bytes(int B, int H, int Tk, int dhp);
 int gta_fwd2_lds_bytes(int dhp, int nq);
 int gta_fwd2_dispatch(GtaFwdParams& p, int dhp, int esz, bool run_prep, bool run_flash, hipStream_t stream);
@@ -154,12 +155,18 @@ extern "C" const char* gta_debug_attention_kernel(const GtaAttnDesc* d, int32_t*
     GtaFwdParams p;
     memset(&p, 0, sizeof p);
     if (build_ctab(d, p.ctab)) return "";
+    const int esz = d->dtype == GTA_DTYPE_BF16 ? 2 : 4;
+    const bool need_view = d->d_se3 > 0 || d->d_so3 > 0;
     p.B = d->B; p.H = d->H; p.Tq = d->Tq; p.Tk = d->Tk; p.dh = d->dh; p.flags = d->flags; p.kn = (float*)1; p.cs_q = d->d_so2 ? (const float*)1 : nullptr;
+    // (what gta_attn_fwd would hand the dispatch for a full call with LSE: only null / non-null matters here)
+    p.Nq = d->Nq; p.Nk = d->Nk; p.Pq = d->Tq / d->Nq; p.Pk = d->Tk / d->Nk; p.nso2 = d->d_so2 / 2; p.lse = (float*)1;
+    p.vrep_q = need_view ? (const float*)1 : nullptr; p.q_st = d->q_stride[2]; p.o_st = d->o_stride[2];
+    p.qtiles = (padded_dh(d->dh) == 96 && esz == 2 && need_view) ? (void*)1 : nullptr;
     const bool two_stage = !(d->flags & (GTA_FLAG_FUSED_KV | GTA_FLAG_FP32_PRODUCTS | GTA_FLAG_PRETRANSFORMED));
-    const int rows = !two_stage ? 128 : gta_fwd2_rows_per_item(p, padded_dh(d->dh), d->dtype == GTA_DTYPE_BF16 ? 2 : 4);
+    const int rows = !two_stage ? 128 : gta_fwd2_rows_per_item(p, padded_dh(d->dh), esz);
     if (n_items) *n_items = d->B * d->H * ((d->Tq + rows - 1) / rows);
     if (rows_per_item) *rows_per_item = rows;
-    return !two_stage ? "gta_fwd_kernel" : rows == 256 ? "gta_attn64_kernel" : "gta_fwd2_kernel";
+    return !two_stage ? "gta_fwd_kernel" : gta_fwd2_attention_kernel_name(p, padded_dh(d->dh), esz);
 }
 
 extern "C" int gta_attn_fwd(const GtaAttnDesc* d, const void* q, const void* k, const void* v,

@@ -39,6 +39,7 @@ int gta_prep_dispatch(const GtaFwdParams& p, int dhp, int esz, hipStream_t strea
 bool gta_attn64_takes(const GtaFwdParams& p, int dhp, int layout, int esz);                                  // gta_fwd64.hip
 int gta_qtiles_dispatch(const GtaFwdParams& p, hipStream_t stream);
 int gta_attn64_dispatch(const GtaFwdParams& p, int esz, int layout, hipStream_t stream);
+const char* gta_attn64_kernel_name(const GtaFwdParams& p, int esz, int layout);
 
 // profiling hook (not part of the product ABI, see gta_hip.h): events for the NEXT attention-kernel launch of this thread
 thread_local void* gta_dbg_fwd_ev_start = nullptr;      // (also read by gta_fwd64.hip)
@@ -790,6 +791,9 @@ static int layout_of(const GtaFwdParams& p, int dhp) {
 }
 
 int gta_fwd2_rows_per_item(const GtaFwdParams& p, int dhp, int esz) { return gta_attn64_takes(p, dhp, layout_of(p, dhp), esz) ? 256 : 128; }
+const char* gta_fwd2_attention_kernel_name(const GtaFwdParams& p, int dhp, int esz) {
+    return gta_attn64_takes(p, dhp, layout_of(p, dhp), esz) ? gta_attn64_kernel_name(p, esz, layout_of(p, dhp)) : "gta_fwd2_kernel";
+}
 
 // Compile-time layouts exist for the shipped configs; others read the chunk table.
 template <int DHP, int ESZ>

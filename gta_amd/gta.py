@@ -452,6 +452,9 @@ def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: 
     if kv_mode == "prepass_rows32":    # tuning knob: keep the 32-rows-per-wave attention kernel where the 64-rows one would run
         flags |= native.FLAG_ROWS32
         kv_mode = "prepass"
+    if kv_mode == "prepass_item_cxx":  # tuning knob: the 64-rows kernel with its compiler-scheduled item prologue / epilogue (not the item stream)
+        flags |= native.FLAG_ITEM_CXX
+        kv_mode = "prepass"
     if kv_mode not in ("auto", "prepass", "fused"):
         raise ValueError(f"kv_mode {kv_mode!r}")
     precise = bool(precise)

@@ -45,6 +45,8 @@ extern "C" {
                                          /* results for the reference's mixed_prec: False configs, single-kernel plan, 3x the MFMAs */
 #define GTA_FLAG_ROWS32        (1u << 11) /* tuning: keep the 32-rows-per-wave attention kernel (gta_fwd2.hip) where the     */
                                           /* 64-rows-per-wave one (gta_fwd64.hip: dh = 96, whole ring turns of key tiles) would run */
+#define GTA_FLAG_ITEM_CXX      (1u << 12) /* tuning / diagnostics: keep the 64-rows-per-wave kernel's compiler-scheduled item prologue and epilogue  */
+                                          /* where the generated item stream (gen_item64.py) would run; same results bit for bit               */
 #define GTA_FLAG_NO_DMA        (1u << 8) /* debug: stage K/V tiles through VGPRs, not LDS-DMA  */
 
 /* error codes */

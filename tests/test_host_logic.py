@@ -241,6 +241,72 @@ def test_attn64_loop_generator_checks_and_is_current():
         g.check_all(gen, prog[:j] + prog[j + 1:])
 
 
+def _load_csrc_module(name):
+    import importlib.util
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "gta_amd", "csrc")
+    if d not in sys.path:
+        sys.path.insert(0, d)          # (the generators import each other by plain module name)
+    spec = importlib.util.spec_from_file_location(name, os.path.join(d, name + ".py"))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m, d
+
+
+def test_item_stream_generator_simulates_and_is_current():
+    """gen_item64.py emits the whole work item of gta_attn64_items_kernel (prologue, tile loop, epilogue, request for the next item) as
+    one instruction stream.  Its check() EXECUTES the stream -- the tile loop replaced by a stub that verifies the prologue's results
+    and leaves the loop's -- on the functional wave simulator of isa_model.py (64 lanes, LDS, global memory, in-order memory counters
+    with poisoned load destinations, the ISA's manual wait states) for three launches (exactly representable inputs: results bit for
+    bit; random inputs: within one bf16 step; a single-item launch), all four waves, and compares Q' fragments, |q'| bounds, stream
+    pointers, O rows, LSE and the profile stamps with a numpy model of the C++ prologue / epilogue.  The assembler must accept the
+    text, and the committed gta_attn64_items.inc must be what the generator emits now."""
+    import os
+    import tempfile
+    g, d = _load_csrc_module("gen_item64")
+    st = g.check()
+    assert st["mfma"] == 48 and st["instructions"] < 1400, st          # 2 x 12 MFMAs per item side; ~1 200 instructions incl. the per-launch setup
+    full = g.ItemGen().program()
+    if os.path.exists("/opt/rocm/lib/llvm/bin/clang"):
+        assert g.assemble_check(full)
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "items.inc")
+        g.emit(out, full, g.ItemGen().program(pad4=True))
+        assert open(out).read() == open(os.path.join(d, "gta_attn64_items.inc")).read(), \
+            "gta_attn64_items.inc is stale: make -C gta_amd/csrc regen"
+
+
+@pytest.mark.parametrize("fault", ["fragment_offset", "early_wait", "tile_order", "rotation_sign", "missing_mask", "lse_offset", "missing_pad",
+                                   "store_base"])
+def test_item_stream_simulation_catches_faults(fault):
+    """the simulation objects to what it is there for: a wrong LDS offset, a mis-counted vmcnt at the item's start, swapped operand
+    tiles, a rotation sign, a dropped exec mask, a wrong LSE address, a dropped wait-state pad, a wrong O base"""
+    import os
+    g, d = _load_csrc_module("gen_item64")
+    src = open(os.path.join(d, "gen_item64.py")).read()
+    old, new = {
+        "fragment_offset": ("a.ds_read(128, QR[rb][ks], V_XFR, 32 * ks)", "a.ds_read(128, QR[rb][ks], V_XFR, 16 * ks)"),
+        "early_wait": ("        a.waitcnt(vm=14)\n        # Q rows -> scratch", "        a.waitcnt(vm=20)\n        # Q rows -> scratch"),
+        "tile_order": ("out.append((ACC[rb][d], AT[6 * lo + tl], QR[rb][tl], 0 if i < 3 else ACC[rb][d]))",
+                       "out.append((ACC[rb][d], AT[6 * lo + (tl ^ 1)], QR[rb][tl], 0 if i < 3 else ACC[rb][d]))"),
+        "rotation_sign": ("ops.append(lambda x0=x0, c=c, tt=tt: a.v_fma_f32(x0, x0, c, tt, neg=(False, False, True)))",
+                          "ops.append(lambda x0=x0, c=c, tt=tt: a.v_fma_f32(x0, x0, c, tt))"),
+        "missing_mask": ("                    if ks == 4:\n                        ops.append(lambda: self.hi(a))",
+                         "                    if ks == 44:\n                        ops.append(lambda: self.hi(a))"),
+        "lse_offset": ("a.global_store(1, V_LSE, [t[8 + rb]], cur(D_LSE), 128 * rb)", "a.global_store(1, V_LSE, [t[8 + rb]], cur(D_LSE), 64 * rb)"),
+        "missing_pad": ("            if i == 2:\n                a.nop(7)", "            if i == 2:\n                a.nop(1)"),
+        "store_base": ("S_B[2 * rb + i // 3]", "S_B[rb + i // 3]"),
+    }[fault]
+    assert old in src
+    ns = {"__name__": "gen_item64_fault"}
+    exec(compile(src.replace(old, new, 1), "gen_item64_fault.py", "exec"), ns)
+    with pytest.raises(g.CheckError):
+        ns["check"](waves=(1,))
+
+
 def test_attn64_kernel_leaves_the_accumulator_file_to_the_loop_statement():
     """tools/audit_spills.py audit_attn64: hipcc must not touch accumulator registers in gta_attn64_kernel (the loop statement and
     the fragment writes / O reads around it own them by literal number), one loop statement, 256 + 256 register split."""
@@ -254,7 +320,7 @@ def test_attn64_kernel_leaves_the_accumulator_file_to_the_loop_statement():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     report, problems = mod.audit_attn64()
-    assert len(report) >= 4, report
+    assert len(report) >= 5 and any(r["instance"] == "items" for r in report), report
     assert not problems, problems
 
 
@@ -349,7 +415,9 @@ def test_attention_kernel_selection_and_backward_workspace_without_gpu():
         d = native.make_desc(q, k, k, q, f, L, N, N, dh ** -0.5, native.FLAG_V_TRANSFORM | flags)
         return native.attention_kernel(d)[0::2]
     bf, f32 = torch.bfloat16, torch.float32
-    assert kern(96, MS, 2, 1280, 1280, bf, 5) == ("gta_attn64_kernel", 256)
+    assert kern(96, MS, 2, 1280, 1280, bf, 5) == ("gta_attn64_items_kernel", 256)        # whole one-view items, bf16: the generated item stream
+    assert kern(96, MS, 2, 1280, 1280, bf, 5, native.FLAG_ITEM_CXX) == ("gta_attn64_kernel", 256)
+    assert kern(96, MS, 2, 1536, 1536, bf, 12) == ("gta_attn64_kernel", 256)             # 128-token views: items span views
     assert kern(96, MS, 2, 1280, 1280, f32, 5) == ("gta_attn64_kernel", 256)
     assert kern(96, MS, 2, 1280, 1280, bf, 5, native.FLAG_ROWS32) == ("gta_fwd2_kernel", 128)
     assert kern(96, MS, 2, 1280, 640, bf, 5) == ("gta_fwd2_kernel", 128)            # 10 key tiles: not whole ring turns

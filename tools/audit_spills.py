@@ -139,6 +139,33 @@ def audit_attn64():
             problems.append(f"gta_attn64_kernel<{key}>: register file split {accum} / {vgpr} (expected 256 / 512)")
         if len(scratch_lines) > 12:
             problems.append(f"gta_attn64_kernel<{key}>: {len(scratch_lines)} scratch accesses")
+    # gta_attn64_items_kernel: the whole item loop is ONE statement that names v8..v255, every accumulator register and s20..s99; what
+    # hipcc keeps across it lives in v0..v7 (SGPR spills go to lanes of those) -- no scratch, nothing of hipcc's in the accumulator file
+    for m in re.finditer(r"^(_ZN\w*gta_attn64_items_kernel\w+):", text, re.M):
+        name = m.group(1)
+        body = text[m.start():text.index(".Lfunc_end", m.start())]
+        meta = text[text.index(".amdhsa_kernel " + name):][:4000]
+        vgpr = int(re.search(r"\.amdhsa_next_free_vgpr\s+(\d+)", meta).group(1))
+        accum = int(re.search(r"\.amdhsa_accum_offset\s+(\d+)", meta).group(1))
+        inasm, compiler_acc, long_stmts, cur_len, hi_vgpr = False, 0, 0, 0, 0
+        for line in body.split("\n"):
+            if "#ASMSTART" in line:
+                inasm, cur_len = True, 0
+                continue
+            if "#ASMEND" in line:
+                inasm = False
+                long_stmts += cur_len > 1000
+                continue
+            if inasm:
+                cur_len += 1
+                continue
+            code = line.split(";")[0]
+            compiler_acc += len(re.findall(r"\ba\[?\d+", code))
+        row = {"instance": "items", "vgpr": vgpr, "accum_offset": accum, "compiler_agpr_uses": compiler_acc, "scratch": body.count("scratch_"),
+               "loop_statements": long_stmts}
+        report.append(row)
+        if compiler_acc or row["scratch"] or long_stmts != 1 or vgpr != 512 or accum != 256:
+            problems.append(f"gta_attn64_items_kernel: {row}")
     return report, problems
 
 
