@@ -108,7 +108,8 @@ S_CUR, S_NXT = 40, 56                   # s[40:53] this item's descriptor, s[56:
 S_KPTR, S_VPTR, S_NXK, S_NXV = Sr(72, 2), Sr(74, 2), Sr(76, 2), Sr(78, 2)
 S_WOFF = "s80"
 S_T = Sr(81, 3)                         # s81..s83 temporaries (s84..s96: the tile loop's)
-S_K, S_TAB = "s97", "s98"               # items done, LDS address of the current item's table entry
+S_K, S_TAB = "s97", "s35"               # items done, LDS address of the current item's table entry
+S_PH3 = Sr(98, 2)                       # (diagnostic stream: the epilogue-done stamp, stored with the next boundary's stamps)
 S_HI = Sr(70, 2)                        # exec mask of lanes 32..63
 CLOBBER_S = [i for i in range(20, 100) if i != 32]
 
@@ -181,9 +182,36 @@ def auto_waits(prog):
 
 
 class ItemGen:
-    def __init__(self, loop_kw=None, stamps=True):
+    def __init__(self, loop_kw=None, stamps=True, head_wait=False, phases=False):
         self.loop_kw = dict(G.BEST) if loop_kw is None else loop_kw
         self.stamps = stamps
+        self.head_wait = head_wait     # keep the tile loop's own vmcnt(0) at its head (the item's prologue already waited for the tiles)
+        self.phases = phases           # diagnostic: shader-cycle stamps [1] inputs landed, [2] prologue done, [3] loop done, [7] epilogue done
+
+    def phase(self, a, k):
+        """diagnostic stream only: shader-cycle stamp k -> slot (1, 2, 3, 7)[k] of the item's profile row, stored at once by lane 0 (the
+        extra store of stamp 3 sits behind the request: the item's first wait counts it)"""
+        if not self.phases:
+            return
+        t = TMP
+        lab = f"L_noph{k}_%="
+        a.waitcnt(lgkm=0)
+        a.s_or_b32(S_T[0], "%[prof_lo]", "%[prof_hi]")
+        a.branch("s_cbranch_scc0", lab)
+        if k == 3:                        # (no store here: it would sit behind the request and change what the item's first wait counts)
+            a.s_memtime(S_PH3)
+            a.waitcnt(lgkm=0)
+            a.label(lab)
+            return
+        a.s_memtime(S_T[1:3])
+        a.waitcnt(lgkm=0)
+        a.s_exec_set("lane0")
+        a.v_mov_b32(t[4], 0)
+        a.v_mov_b32(t[6], S_T[1])
+        a.v_mov_b32(t[7], S_T[2])
+        a.global_store(2, t[4], t[6:8], S_ROW, 8 * (1, 2, 3)[k])
+        a.s_exec_set("all")
+        a.label(lab)
 
     def hi(self, a):
         a.s_exec_set("hi", S_HI)
@@ -251,6 +279,8 @@ class ItemGen:
             a.ds_read(32, [r], t[3], 256 * i)
         a.s_mov_b32(S_K, 0)
         a.s_mov_b32(S_TAB, "%[tabl]")
+        if self.phases:
+            a.s_mov_b64(S_PH3, 0)
         a.waitcnt(lgkm=0)
         self.read_desc(a, 0)                                  # item 0's descriptor, as "next" ...
         self.request(a)                                       # ... its inputs requested ...
@@ -340,6 +370,10 @@ class ItemGen:
             a.v_mov_b32(t[i], S_STAMP[i])
         a.global_store(2, t[4], t[0:2], S_PREV, 8 * 4)                # [4] end of the previous item (cycles)
         a.global_store(2, t[4], t[2:4], S_PREV, 8 * 6)                # [6] ... by the 100-MHz clock
+        if self.phases:
+            a.v_mov_b32(t[6], S_PH3[0])
+            a.v_mov_b32(t[7], S_PH3[1])
+            a.global_store(2, t[4], t[6:8], S_PREV, 8 * 7)            # [7] the previous item's epilogue done
         if not last:
             a.global_store(2, t[4], t[0:2], S_ROW, 8 * 0)             # [0] start of this item
             a.global_store(2, t[4], t[2:4], S_ROW, 8 * 5)             # [5]
@@ -358,6 +392,7 @@ class ItemGen:
         # everything requested one item ago has landed -- Q rows, Aq tiles, key norms, (cos, sin) rows (LDS-DMA) -- when only the
         # previous epilogue's twelve O stores and two LSE stores are left in flight
         a.waitcnt(vm=14)
+        self.phase(a, 0)
         # Q rows -> scratch (row-major, 208-byte rows) -> this lane's fragments (row l31, units 2 ks + lh), one row block at a time
         for rb in range(RB):
             for i in range(KS):
@@ -603,8 +638,15 @@ class ItemGen:
         G.configure(96)
         gen = G.Gen(R=R, **self.loop_kw)
         out = []
+        head_vm = not self.head_wait
         for ins in gen.program():
             if ins.sem and ins.sem[0] == "ds_tab":
+                continue
+            if head_vm and ins.kind == "wait" and ins.sem == ("vm", 0):
+                # the loop's own wait for its first tiles: in the item stream the prologue's vmcnt(14) has already seen them land
+                # (they were requested before the item's inputs), and what is still in flight here -- the previous item's O / LSE
+                # stores -- must not hold the loop's first matrix instructions
+                head_vm = False
                 continue
             text = ins.text
             for k, v in LOOP_OPERANDS.items():
@@ -619,13 +661,16 @@ class ItemGen:
         self.stamp(a, "item")
         self.prologue(a)
         a.waitcnt(lgkm=0)
+        self.phase(a, 1)
         if pad4:                           # (diagnostic twin: the tile loop four bytes further on -- MI355X_MICROARCH.md, code placement)
             a.nop(1)
         head = auto_waits(a.out)
         a = Asm()
+        self.phase(a, 2)
         self.epilogue(a)
         # next item: its descriptor becomes the current one, the one after it is read from the table
         a.waitcnt(lgkm=0)
+        self.phase(a, 3)
         self.advance_desc(a)
         a.s_add_u32(S_K, S_K, 1)
         a.s_add_u32(S_TAB, S_TAB, ITEM_BYTES)
@@ -954,8 +999,8 @@ def run_case(prog, case, wave, prof=False):
     return w
 
 
-def check(verbose=False, waves=(0, 1, 2, 3)):
-    gen = ItemGen()
+def check(verbose=False, waves=(0, 1, 2, 3), **kw):
+    gen = ItemGen(**kw)
     prog = gen.program(stub_loop=True)
     stats = {"instructions": sum(1 for x in prog if x.kind not in ("label", "pseudo")), "mfma": sum(1 for x in prog if x.kind == "mfma")}
     # distinct items of one launch write distinct rows: the waves of a case share the O / LSE buffers
@@ -976,7 +1021,7 @@ def clobbers():
     return ", ".join(f'"{r}"' for r in regs_) + ', "vcc", "scc", "memory"'
 
 
-def emit(path, prog, prog_p4=None):
+def emit(path, prog, prog_p4=None, prog_ph=None):
     with open(path, "w") as f:
         f.write("// generated by gen_item64.py (make regen) -- do not edit\n")
         for name, val in (("OFF_CS", OFF_CS), ("OFF_X", OFF_X), ("OFF_ITEMS", OFF_ITEMS), ("ITEM_BYTES", ITEM_BYTES), ("MAX_ITEMS", MAX_ITEMS),
@@ -994,7 +1039,14 @@ def emit(path, prog, prog_p4=None):
             for ins in prog_p4:
                 if ins.kind != "pseudo":
                     f.write(f'    "{ins.text}\\n\\t" \\\n')
-            f.write('    ""\n#endif\n')
+            f.write('    ""\n')
+            if prog_ph is not None:
+                f.write("#define GTA_ATTN64_ITEMS_PH \\\n")
+                for ins in prog_ph:
+                    if ins.kind != "pseudo":
+                        f.write(f'    "{ins.text}\\n\\t" \\\n')
+                f.write('    ""\n')
+            f.write("#endif\n")
         f.write("#define GTA_ATTN64_ITEMS_CLOBBERS \\\n    " + clobbers() + "\n")
 
 
@@ -1035,4 +1087,4 @@ if __name__ == "__main__":
     full = ItemGen().program()
     assemble_check(full)
     if a_.out:
-        emit(a_.out, full, ItemGen().program(pad4=True))
+        emit(a_.out, full, ItemGen().program(pad4=True), ItemGen(phases=True).program())
