@@ -323,7 +323,8 @@ def main():
                          "compiler-scheduled item prologue / epilogue where the generated item stream would run (A/B)")
     ap.add_argument("--precise", action="store_true",
                     help="fp32-faithful forward for fp32 inputs (GTA_FLAG_FP32_PRODUCTS: split-bf16 operands, three MFMAs per product, "
-                         "single-kernel plan; the reference's mixed_prec: False configs); needs --dtype f32; no backward leg")
+                         "single-kernel plan; the reference's mixed_prec: False configs); needs --dtype f32; its fwd_bwd leg: fp32 rho kernels, "
+                         "split-bf16 plain forward, exact-fp32 backward (gta_plain32.hip)")
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing check without a GPU: same launch contract, rendezvous (gloo), barriers, MAX-over-ranks and "
                          "JSON line, the step itself replaced by a host no-op (tests/test_ddp_gloo.py runs this at world size 2)")
@@ -365,7 +366,8 @@ def main():
     if args.precise:
         if args.dtype != "f32":
             raise SystemExit("--precise is the fp32-faithful mode: use --dtype f32")
-        args.kv_mode, args.train_steps = "fused", 0        # (the mode exists in the single-kernel plan's forward only)
+        args.kv_mode = "fused"                             # (the timed forward of the mode is the single-kernel plan; its fwd_bwd leg runs
+                                                           #  rho in fp32 + the exact-fp32 backward of gta_plain32.hip)
     fused = args.kv_mode == "fused"
 
     # ---- the planned step: rep build(s) + one gta_attn_fwd ----
@@ -470,7 +472,8 @@ def main():
         w = torch.randn_like(q)
 
         def train_step():
-            out = gta_amd.gta_attention(qg, kg, vg, f_dims, packed, so3_degree=e2.get("gta_so3_degree", 0), trans_coeff=tcg)
+            out = gta_amd.gta_attention(qg, kg, vg, f_dims, packed, so3_degree=e2.get("gta_so3_degree", 0), trans_coeff=tcg,
+                                        precise=args.precise)
             out.backward(w)
             qg.grad = kg.grad = vg.grad = None
         for _ in range(3):

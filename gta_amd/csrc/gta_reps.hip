@@ -21,49 +21,48 @@ __constant__ float kJ2[25] = {0.f, 0.f, 0.f,  -1.f, 0.f,
 
 // Z(angle) of wigner_d.py:16-25: cos(m a) on the diagonal, sin(m a) on the anti-diagonal, m = l..-l (the
 // diagonal is written last: centre element = cos 0 = 1);  D = Z(g3) J Z(g2) J Z(g1)  (wigner_d.py:28-35).
-// General 4x4 inverse, Gauss-Jordan with partial pivoting in fp64 (the reference calls
-// torch.linalg.inv, encoder.py:219 -- a general inverse, not the rigid closed form).
-__device__ __forceinline__ void inv4(const float* E, float* out) {
-    double a[4][8];
+// General 4x4 inverse: Gauss-Jordan with partial pivoting in fp64 (the reference calls torch.linalg.inv, encoder.py:219 -- a general
+// inverse, not the rigid closed form), see inv4_lanes below.
+// One wave per view.  The work of a view is a chain of dependent scalar steps (a 4x4 fp64 inverse, five atan2f, six sincosf, the
+// Wigner products): run redundantly in every lane it took ~6.5 us of pure latency (r03: the rep build was 8.3 us of a 240-us step).
+// r04: the independent pieces run in DIFFERENT LANES at once -- the eight columns of the augmented matrix [E | I] of the Gauss-Jordan
+// inverse (row operations act column by column; only the pivot column is broadcast per step), the five atan2f (one call, a different
+// argument pair per lane), the six sincosf -- and are handed round by wave shuffles; per element the arithmetic and its order are those
+// of the one-lane form.  Then lanes split the Wigner products by output COLUMN: D[:, j] = Z(g3) J Z(g2) J Z(g1)[:, j] is a chain of
+// matrix-vector products (Z has two non-zeros per row), ~70 FMAs per lane.
+__device__ __forceinline__ void inv4_lanes(const float* E, float* out, int lane) {
+    // lane (j = lane & 7) owns column j of [E | I] (every lane of the wave takes part: the shuffles want all of them)
+    const int j = lane & 7;
+    double col[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { a[i][j] = (double)E[i * 4 + j]; a[i][4 + j] = (i == j) ? 1.0 : 0.0; }
+    for (int i = 0; i < 4; ++i) col[i] = j < 4 ? (double)E[i * 4 + j] : ((i == j - 4) ? 1.0 : 0.0);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        // partial pivoting by compare-and-swap with every lower row (all indices static: registers)
+        double pc[4];                                   // the pivot column as every lane sees it
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pc[r] = __shfl(col[r], c);
+        // partial pivoting by compare-and-swap with every lower row, decided on the broadcast column
 #pragma unroll
         for (int r = c + 1; r < 4; ++r) {
-            const bool sw = fabs(a[r][c]) > fabs(a[c][c]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const double x = a[c][j], y = a[r][j];
-                a[c][j] = sw ? y : x;
-                a[r][j] = sw ? x : y;
-            }
+            const bool sw = fabs(pc[r]) > fabs(pc[c]);
+            const double x = col[c], y = col[r], px = pc[c], py = pc[r];
+            col[c] = sw ? y : x; col[r] = sw ? x : y;
+            pc[c] = sw ? py : px; pc[r] = sw ? px : py;
         }
-        const double inv = 1.0 / a[c][c];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) a[c][j] *= inv;
+        const double inv = 1.0 / pc[c];
+        col[c] *= inv;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (r == c) continue;
-            const double f = a[r][c];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j];
+            col[r] -= pc[r] * col[c];
         }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) out[i * 4 + j] = (float)a[i][4 + j];
+        for (int jj = 0; jj < 4; ++jj) out[i * 4 + jj] = (float)__shfl(col[i], 4 + jj);
 }
 
-// One wave per view.  Every lane runs the (latency-bound, ~300 dependent fp64 ops) inverse and the Euler angles
-// redundantly -- in SIMD that costs what one lane costs -- then lanes split the Wigner products by output
-// COLUMN: D[:, j] = Z(g3) J Z(g2) J Z(g1)[:, j] is a chain of matrix-vector products (Z has two non-zeros per
-// row), ~70 FMAs per lane instead of the 500 of the full 5x5 chain in one thread (the previous 3-threads-per-view
-// kernel took 15 us for 160 views; this one is bounded by the inverse).
 template <int N>
 __device__ __forceinline__ void wigner_column(const float* J, const float (&cs1)[3][2], const float (&cs2)[3][2],
                                               const float (&cs3)[3][2], int j, float* col) {
@@ -111,41 +110,48 @@ __device__ __forceinline__ void view_reps_body(int block, const float* __restric
     if (i >= n_views) return;
     const float* e = E + (size_t)i * 16;
     float* o = vrep + (size_t)i * GTA_VREP_STRIDE;
-    float ev[16], inv[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) ev[j] = e[j];
-    inv4(ev, inv);
+    float inv[16];
+    inv4_lanes(e, inv, lane);
     // records: lanes 0..15 write E and inverse(E); lanes 16.. zero the padding
     if (lane < 16) {
-        float a = 0.f, b2 = 0.f;
+        float b2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { if (j == lane) { a = ev[j]; b2 = inv[j]; } }
-        o[GTA_VREP_INV + lane] = a;
+        for (int j = 0; j < 16; ++j) { if (j == lane) b2 = inv[j]; }
+        o[GTA_VREP_INV + lane] = e[lane];
         o[GTA_VREP_REP + lane] = b2;
     }
     for (int j = GTA_VREP_D2 + 25 + lane; j < GTA_VREP_STRIDE; j += 64) o[j] = 0.f;
     if (L < 1 && lane < 9) o[GTA_VREP_D1 + lane] = 0.f;
     if (L < 2 && lane < 25) o[GTA_VREP_D2 + lane] = 0.f;
     if (L < 1) return;
-    // R = inverse(E)[:3,:3]; ZYZ angles with the reference's gimbal masks (wigner_d.py:39-49)
+    // R = inverse(E)[:3,:3]; ZYZ angles with the reference's gimbal masks (wigner_d.py:39-49): the five atan2f in lanes 0..4
 #define R_(r, c) inv[(r) * 4 + (c)]
     const float EPS = 1e-5f;
-    float g1 = atan2f(R_(2, 1), -R_(2, 0));
-    const float g2 = atan2f(sqrtf(R_(0, 2) * R_(0, 2) + R_(1, 2) * R_(1, 2)), R_(2, 2));
-    float g3 = atan2f(R_(1, 2), R_(0, 2));
+    const float ay = lane == 0 ? R_(2, 1) : lane == 1 ? sqrtf(R_(0, 2) * R_(0, 2) + R_(1, 2) * R_(1, 2)) : lane == 2 ? R_(1, 2) : lane == 3 ? R_(1, 0) : -R_(1, 0);
+    const float ax = lane == 0 ? -R_(2, 0) : lane == 1 ? R_(2, 2) : lane == 2 ? R_(0, 2) : lane == 3 ? R_(0, 0) : -R_(0, 0);
+    const float at = atan2f(ay, ax);
+    float g1 = __shfl(at, 0);
+    const float g2 = __shfl(at, 1);
+    float g3 = __shfl(at, 2);
     const float up = (fabsf(R_(2, 2) - 1.f) < EPS) ? 1.f : 0.f;
     const float dn = (fabsf(R_(2, 2) + 1.f) < EPS) ? 1.f : 0.f;
     const float reg = (1.f - up) * (1.f - dn);
-    g1 = reg * g1 + up * atan2f(R_(1, 0), R_(0, 0)) + dn * atan2f(-R_(1, 0), -R_(0, 0));
+    g1 = reg * g1 + up * __shfl(at, 3) + dn * __shfl(at, 4);
     g3 = reg * g3;
 #undef R_
+    // (cos, sin)(m angle), m = 1, 2, of the three angles: six sincosf in lanes 0..5
     float cs1[3][2], cs2[3][2], cs3[3][2];
-    auto fill = [](float a, float (&cs)[3][2]) {
-        cs[0][0] = 1.f; cs[0][1] = 0.f;
-        sincosf(a, &cs[1][1], &cs[1][0]);
-        sincosf(2.f * a, &cs[2][1], &cs[2][0]);
-    };
-    fill(g1, cs1); fill(g2, cs2); fill(g3, cs3);
+    {
+        const float ga = lane < 2 ? g1 : lane < 4 ? g2 : g3;
+        float sn, cn;
+        sincosf((lane & 1) ? 2.f * ga : ga, &sn, &cn);
+        auto fill = [&](int l0, float (&cs)[3][2]) {
+            cs[0][0] = 1.f; cs[0][1] = 0.f;
+            cs[1][0] = __shfl(cn, l0); cs[1][1] = __shfl(sn, l0);
+            cs[2][0] = __shfl(cn, l0 + 1); cs[2][1] = __shfl(sn, l0 + 1);
+        };
+        fill(0, cs1); fill(2, cs2); fill(4, cs3);
+    }
     if (lane < 3) {                       // D^1 column `lane`
         float col[3];
         wigner_column<3>(kJ1, cs1, cs2, cs3, lane, col);

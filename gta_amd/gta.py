@@ -382,8 +382,16 @@ class _GenericAttn(torch.autograd.Function):
             dhp = dhp2
         pcfg = ({"triv": dhp}, 0, 1, 1, scale, 0)
         # (with the bias in the augmented channels, <q', dq'> also carries the bias part of d tau)
-        dqp, dkp, dvp, _, dta = _bw.attn_bwd(pcfg, qp, kp, vp, op, dop, lse, None, ta, None, None, None, None,
-                                             want_dtau=want_dtau)
+        if _precise and dt == torch.float32:
+            # fp32-faithful mode: exact-fp32 products and sums (gta_plain32.hip) -- the gradients of the reference's fp32 autograd
+            dqp, dkp, dvp = mk(Tq), mk(Tk), mk(Tk)
+            pdesc = native.make_desc(qp, kp, vp, op, {"triv": dhp}, 0, 1, 1, scale, 0)
+            native.attn_bwd_plain_f32(pdesc, qp, kp, vp, op, dop, lse, ta, dqp, dkp, dvp)
+            # dL/dtau = -(1/tau) sum_i <q'_i, dq'_i>  (the kernels of the default mode form it in their epilogue)
+            dta = (-(qp.double() * dqp.double()).sum() / ta.double()).float().reshape(1) if (want_dtau and ta is not None) else None
+        else:
+            dqp, dkp, dvp, _, dta = _bw.attn_bwd(pcfg, qp, kp, vp, op, dop, lse, None, ta, None, None, None, None,
+                                                 want_dtau=want_dtau)
         if dta is not None:
             dta = dta.reshape(ctx.tau_meta[0]).to(ctx.tau_meta[1])
         if euclid:
@@ -431,7 +439,9 @@ def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: 
     precise: float32 inputs only.  False / None (default): operands are rounded to bf16 once, after
              rho, and the two contractions run on the bf16 MFMA (fp32 accumulation) -- the reference's bf16-autocast
              accuracy.  True: operands are kept as bf16 hi+lo pairs and every product is three MFMAs -- fp32-class results
-             (max |error| ~1e-5 of max |out|) at 3x the matrix work, single-kernel plan; the backward stays bf16-product.
+             (max |error| ~1e-5 of max |out|) at 3x the matrix work, single-kernel plan.  When a gradient is wanted the call runs
+             rho in fp32 (gta_rep_apply), the split-bf16 plain forward and an EXACT-fp32 backward (gta_plain32.hip: f32 matrix
+             instructions, 1/16 of the bf16 rate) -- the arithmetic of the reference's ``mixed_prec: False`` training.
     kv_cache: a dict owned by the caller (inference only).  The first call stores the K'/V' tile images of the
              pre-pass in it; later calls with the same keys, reps and trans_coeff (e.g. the next query chunk of a
              full-image decode, trainer.py:137-181) stream them again without re-running the pre-pass."""
@@ -478,6 +488,11 @@ def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: 
         trans_coeff = torch.tensor([float(trans_coeff)], device=q.device, dtype=torch.float32)
     if isinstance(tau, (int, float)):
         tau = None if float(tau) == 1.0 else torch.tensor([float(tau)], device=q.device, dtype=torch.float32)
+    needs_grad = torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in (q, k, v, trans_coeff, tau))
+    if precise and needs_grad and not pretransformed:
+        # fp32-faithful TRAINING: rho in fp32 (gta_rep_apply), split-bf16 forward products, EXACT-fp32 backward (gta_plain32.hip) and the
+        # adjoint rho kernels -- the generic path serves every layout that way; inference keeps the fused single-kernel forward below
+        return _generic_forward(q, k, v, f_dims, packed, so3_degree, trans_coeff, tau, scale, v_transform, euclid, precise=True)
     if q.is_cuda and not pretransformed:
         probe = native.make_desc(q, k, v, q, f_dims, so3_degree, Nq, Nk, scale, flags)
         if native.attn_fwd_supported(probe) == -3:       # GTA_E_UNSUPPORTED: valid request, no fused kernel

@@ -37,7 +37,7 @@ MAX_VIEWS = 16
 ABI_SYMBOLS = (
     "gta_build_view_reps", "gta_build_so2_table", "gta_build_reps", "gta_rep_apply_bwd", "gta_attn_fwd", "gta_attn_fwd_supported",
     "gta_attn_fwd_launch_info", "gta_attn_fwd_workspace_bytes", "gta_attn_bwd", "gta_attn_bwd_workspace_bytes",
-    "gta_rep_apply", "gta_attn_fwd_plain",
+    "gta_rep_apply", "gta_attn_fwd_plain", "gta_attn_bwd_plain_f32", "gta_attn_bwd_plain_f32_workspace_bytes",
     "gta_strerror", "gta_abi_version", "gta_sizeof_attn_desc",
     "gta_debug_time_next_attention_kernel", "gta_debug_event_create", "gta_debug_event_destroy", "gta_debug_event_elapsed_ms",
     "gta_debug_profile_next_attention_kernel", "gta_debug_attention_kernel",
@@ -100,6 +100,10 @@ def lib():
                                     c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int64), c_void_p, c_float, c_int64, c_void_p]
         L.gta_attn_fwd_plain.argtypes = [ctypes.POINTER(GtaAttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                          c_void_p, c_void_p, c_void_p, c_void_p]
+        L.gta_attn_bwd_plain_f32_workspace_bytes.argtypes = [ctypes.POINTER(GtaAttnDesc)]
+        L.gta_attn_bwd_plain_f32_workspace_bytes.restype = c_int64
+        L.gta_attn_bwd_plain_f32.argtypes = ([ctypes.POINTER(GtaAttnDesc)] + [c_void_p] * 5 + [ctypes.POINTER(c_int64), c_void_p, c_void_p,
+                                              c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int64), c_void_p, c_int64, c_void_p])
         L.gta_debug_time_next_attention_kernel.argtypes = [c_void_p, c_void_p]
         L.gta_debug_time_next_attention_kernel.restype = None
         L.gta_debug_event_create.restype = c_void_p
@@ -273,6 +277,16 @@ def attn_bwd(desc: GtaAttnDesc, q, k, v, out, dout, lse, vrep_q, vrep_k, cs_q, c
                              _ptr(vrep_q), _ptr(vrep_k), _ptr(cs_q), _ptr(cs_k), _ptr(trans_coeff), _ptr(tau),
                              _ptr(kv_images), _ptr(dq), _ptr(dk), _ptr(dv), gs, ds, _ptr(dtrans_coeff), _ptr(dtau),
                              _ptr(workspace), workspace.numel(), _stream()), "gta_attn_bwd")
+
+
+def attn_bwd_plain_f32(desc: GtaAttnDesc, q, k, v, out, dout, lse, tau, dq, dk, dv):
+    """exact-fp32 backward of plain attention on pre-transformed float32 tensors (include/gta_hip.h: gta_attn_bwd_plain_f32)"""
+    _require_cuda(q, k, v, out, dout, dq, dk, dv)
+    gs = (c_int64 * 9)(*(list(dq.stride()[:3]) + list(dk.stride()[:3]) + list(dv.stride()[:3])))
+    ds = (c_int64 * 3)(*dout.stride()[:3])
+    ws = torch.empty(int(lib().gta_attn_bwd_plain_f32_workspace_bytes(ctypes.byref(desc))), device=q.device, dtype=torch.uint8)
+    check(lib().gta_attn_bwd_plain_f32(ctypes.byref(desc), _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(dout), ds, _ptr(lse), _ptr(tau),
+                                       _ptr(dq), _ptr(dk), _ptr(dv), gs, _ptr(ws), ws.numel(), _stream()), "gta_attn_bwd_plain_f32")
 
 
 def rep_apply(desc: GtaAttnDesc, mode: int, x, vrep, cs, coord, trans_coeff, y, key_bias=None, bias_scale=0.0):

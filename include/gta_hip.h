@@ -205,6 +205,20 @@ int gta_attn_fwd_plain(const GtaAttnDesc* desc, const void* q, const void* k, co
                        const float* key_bias, int64_t bias_pitch, const float* tau,
                        void* out, float* lse, void* stream);
 
+/* -------------------------------------------------------------------------------------------
+ * fp32-FAITHFUL backward of plain attention (identity layout, fp32 tensors): the gradient leg of the accuracy mode for the
+ * reference's `mixed_prec: False` configs (runs/clevrtr/GTA/gta/config.yaml:55).  q', k', v' (pre-transformed by gta_rep_apply),
+ * o~ and lse from gta_attn_fwd_plain (GTA_FLAG_FP32_PRODUCTS), do~ from gta_rep_apply_bwd(mode 2) -> dq', dk', dv' for
+ * gta_rep_apply_bwd(modes 0 / 1).  Exact fp32 products and accumulation (v_mfma_f32_32x32x2_f32 = an fmaf chain), 1/16 of the bf16
+ * matrix rate: accuracy, not speed.  desc: dtype F32, dh % 8 == 0 (<= 128), strides of q / k / v / out in elements (multiples of
+ * 4); dout_stride[3], dqkv_stride[9] as in gta_attn_bwd; workspace >= gta_attn_bwd_plain_f32_workspace_bytes (B H Tq floats).
+ * ------------------------------------------------------------------------------------------- */
+int64_t gta_attn_bwd_plain_f32_workspace_bytes(const GtaAttnDesc* desc);
+int gta_attn_bwd_plain_f32(const GtaAttnDesc* desc, const void* q, const void* k, const void* v, const void* out,
+                           const void* dout, const int64_t* dout_stride, const float* lse, const float* tau,
+                           void* dq, void* dk, void* dv, const int64_t* dqkv_stride, void* workspace,
+                           int64_t workspace_bytes, void* stream);
+
 /* 0 when gta_attn_fwd has a fused kernel for this desc, else the error it would return. */
 int gta_attn_fwd_supported(const GtaAttnDesc* desc);
 

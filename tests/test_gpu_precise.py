@@ -84,3 +84,88 @@ def test_precise_mode_contract():
     out = gta_amd.gta_attention(qg, k.cuda(), v.cuda(), f_dims, packed, trans_coeff=tc, precise=True)
     out.sum().backward()
     assert torch.isfinite(qg.grad).all() and qg.grad.abs().max() > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# gradients of the fp32-faithful mode: rho in fp32 (gta_rep_apply / its adjoint), split-bf16 forward, EXACT-fp32 backward
+# (gta_plain32.hip: v_mfma_f32_32x32x2_f32).  Same bars as the forward: 1e-4 * max, 3e-5 rel-RMS.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _grad_check(got, ref, name, rel_max=REL_MAX, rel_rms=1e-4):
+    # (the gradient's rel-RMS bar is 1e-4: the forward it differentiates is the split-bf16 one, ~6e-6 off the fp64 value, and the
+    #  softmax Jacobian amplifies that by a few; the default mode's bars are 4e-2 / 2e-2)
+    st = C.err_stats(got, ref)
+    assert st["finite"] and st["max_abs"] <= rel_max * max(st["ref_max"], 1e-30) and st["rel_rms"] <= rel_rms, (name, st)
+
+
+@pytest.mark.parametrize("case", G.list_cases("op_"))
+def test_reference_fixture_gradients_fp32_faithful(case):
+    """dq, dk, dv, d trans_coeff, d tau of the REFERENCE's own autograd (fixtures generated by oracle/make_golden.py from the imported
+    reference, fp64) on every operator case: the CLEVR-TR and MSN layouts, v_transform off, so2-only, t2, euclid, adjustable softmax."""
+    from types import SimpleNamespace
+    d, meta = G.load("op_" + case)
+    ex = G.extras_of(d, torch.float32, "cuda")
+    q, k, v = (torch.from_numpy(d[n]).float().cuda().requires_grad_() for n in "qkv")
+    tc = torch.tensor([float(d["trans_coeff"])], device="cuda", requires_grad=True)
+    tau = G.tau_of(d, torch.float32, "cuda")
+    out, _ = gta_amd.multihead_geometric_transform_attention(
+        q, k, v, attn_fn=SimpleNamespace(scale=float(d["scale"]), tau=tau), f_dims=meta["f_dims"], reps=ex,
+        trans_coeff=tc, v_transform=meta["v_transform"], euclid=meta["euclid"], precise=True)
+    (out.float() * torch.from_numpy(d["w"]).float().cuda()).sum().backward()
+    torch.cuda.synchronize()
+    _grad_check(out.detach().float().cpu(), torch.from_numpy(d["out"]).float(), "out", REL_MAX, REL_RMS)
+    for name, t in (("dq", q), ("dk", k), ("dv", v)):
+        _grad_check(t.grad.float().cpu(), torch.from_numpy(d[name]).float(), name)
+    if meta["f_dims"].get("se3", 0) > 0 and "dtrans_coeff" in d:
+        ref, got = float(d["dtrans_coeff"][0]), float(tc.grad.item())
+        assert abs(got - ref) <= 2e-4 * max(1.0, abs(ref)), (got, ref)
+    if tau is not None:
+        ref, got = float(d["dtau"][0]), float(tau.grad.item())
+        assert abs(got - ref) <= 2e-4 * max(1.0, abs(ref)), (got, ref)
+    # and it IS a different arithmetic from the default backward (bf16 products): that one sits two orders of magnitude away
+    q2, k2, v2 = (torch.from_numpy(d[n]).float().cuda().requires_grad_() for n in "qkv")
+    out2, _ = gta_amd.multihead_geometric_transform_attention(
+        q2, k2, v2, attn_fn=SimpleNamespace(scale=float(d["scale"]), tau=G.tau_of(d, torch.float32, "cuda", grad=False)), f_dims=meta["f_dims"],
+        reps=ex, trans_coeff=float(d["trans_coeff"]), v_transform=meta["v_transform"], euclid=meta["euclid"])
+    (out2.float() * torch.from_numpy(d["w"]).float().cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert C.err_stats(q2.grad.float().cpu(), torch.from_numpy(d["dq"]).float())["rel_rms"] > 10 * C.err_stats(q.grad.float().cpu(), torch.from_numpy(d["dq"]).float())["rel_rms"]
+
+
+@pytest.mark.parametrize("shape", ["C1", "CL-enc", "CL-dec", "MS-enc", "ragged", "wide", "wide-ragged"])
+def test_baseline_shape_gradients_fp32_faithful(shape):
+    """the same against fp64 autograd through the oracle at the BASELINE geometries (CLEVR-TR encoder / decoder: the configs the
+    reference trains in fp32; dh = 96 and the padded dh = 104 -> 128 layouts; ragged tiles)"""
+    from oracle import gta_oracle as O
+    from tests.test_gpu_backward import SHAPES
+    B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3 = SHAPES[shape]
+    q, k, v, ex, ak, cross = C.synth_inputs(B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, torch.float32, seed=7)
+    w = torch.randn(q.shape, generator=torch.Generator().manual_seed(11))
+    qo, ko, vo = (t.double().requires_grad_() for t in (q, k, v))
+    tco = torch.tensor([0.37], dtype=torch.float64, requires_grad=True)
+    taus = torch.tensor([0.8], dtype=torch.float64, requires_grad=True)
+    ex64 = {kk: (vv.double() if vv.is_floating_point() else vv) for kk, vv in ex.items()}
+    reps = O.encoder_reps(ak, ex64)
+    if cross:
+        reps = O.decoder_reps(ak, ex64, reps)
+    out_o, _ = O.gta_attention(qo, ko, vo, f_dims, reps, tco, tau=taus)
+    (out_o * w.double()).sum().backward()
+    exd = {kk: vv.cuda() for kk, vv in ex.items()}
+    gta_amd.pre_compute_reps_encoder(ak, exd)
+    if cross:
+        gta_amd.pre_compute_reps_decoder(ak, exd)
+    packed = gta_amd.pack_reps(exd, f_dims)
+    qd, kd, vd = (t.cuda().requires_grad_() for t in (q, k, v))
+    tcd = torch.tensor([0.37], device="cuda", requires_grad=True)
+    taud = torch.tensor([0.8], device="cuda", requires_grad=True)
+    out = gta_amd.gta_attention(qd, kd, vd, f_dims, packed, so3_degree=exd.get("gta_so3_degree", 0),
+                                trans_coeff=tcd if f_dims.get("se3", 0) > 0 else None, tau=taud, precise=True)
+    (out * w.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    _grad_check(out.detach().cpu(), out_o.detach().float(), "out", REL_MAX, REL_RMS)
+    for name, a, b in (("dq", qd, qo), ("dk", kd, ko), ("dv", vd, vo)):
+        _grad_check(a.grad.cpu(), b.grad.float(), name)
+    if f_dims.get("se3", 0) > 0:
+        ref, got = float(tco.grad.item()), float(tcd.grad.item())
+        assert abs(got - ref) <= 3e-4 * max(1.0, abs(ref)), (got, ref)
+    ref, got = float(taus.grad.item()), float(taud.grad.item())
+    assert abs(got - ref) <= 3e-4 * max(1.0, abs(ref)), (got, ref)

@@ -274,7 +274,7 @@ def test_item_stream_generator_simulates_and_is_current():
         assert g.assemble_check(full)
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "items.inc")
-        g.emit(out, full, g.ItemGen().program(pad4=True))
+        g.emit(out, full, g.ItemGen().program(pad4=True), g.ItemGen(phases=True).program())
         assert open(out).read() == open(os.path.join(d, "gta_attn64_items.inc")).read(), \
             "gta_attn64_items.inc is stale: make -C gta_amd/csrc regen"
 
@@ -289,7 +289,7 @@ def test_item_stream_simulation_catches_faults(fault):
     src = open(os.path.join(d, "gen_item64.py")).read()
     old, new = {
         "fragment_offset": ("a.ds_read(128, QR[rb][ks], V_XFR, 32 * ks)", "a.ds_read(128, QR[rb][ks], V_XFR, 16 * ks)"),
-        "early_wait": ("        a.waitcnt(vm=14)\n        # Q rows -> scratch", "        a.waitcnt(vm=20)\n        # Q rows -> scratch"),
+        "early_wait": ("        a.waitcnt(vm=14)\n        self.phase(a, 0)", "        a.waitcnt(vm=20)\n        self.phase(a, 0)"),
         "tile_order": ("out.append((ACC[rb][d], AT[6 * lo + tl], QR[rb][tl], 0 if i < 3 else ACC[rb][d]))",
                        "out.append((ACC[rb][d], AT[6 * lo + (tl ^ 1)], QR[rb][tl], 0 if i < 3 else ACC[rb][d]))"),
         "rotation_sign": ("ops.append(lambda x0=x0, c=c, tt=tt: a.v_fma_f32(x0, x0, c, tt, neg=(False, False, True)))",
