@@ -384,7 +384,7 @@ class _GenericAttn(torch.autograd.Function):
         # (with the bias in the augmented channels, <q', dq'> also carries the bias part of d tau)
         if _precise and dt == torch.float32:
             # fp32-faithful mode: exact-fp32 products and sums (gta_plain32.hip) -- the gradients of the reference's fp32 autograd
-            dqp, dkp, dvp = mk(Tq), mk(Tk), mk(Tk)
+            dqp, dkp, dvp = mk(Tq, dhp), mk(Tk, dhp), mk(Tk, dhp)
             pdesc = native.make_desc(qp, kp, vp, op, {"triv": dhp}, 0, 1, 1, scale, 0)
             native.attn_bwd_plain_f32(pdesc, qp, kp, vp, op, dop, lse, ta, dqp, dkp, dvp)
             # dL/dtau = -(1/tau) sum_i <q'_i, dq'_i>  (the kernels of the default mode form it in their epilogue)

@@ -232,7 +232,7 @@ def module_case(name, f_dims, so2, so3, dim, depth, H, dh, B, Nq, Pq, Nk, Pk, se
     np.savez_compressed(os.path.join(OUT, f"mod_{name}.npz"), **rec)
 
 
-def srt_case(name, seed, P=5):
+def srt_case(name, seed, P=5, layout="ms"):
     """Reference TransformingSRT (models_nvs.py:37-91) on a tiny gta_so3-style config: forward, loss of
     trainer.py:85-134 and every parameter gradient, with the reference's own initialisation.  P = rays per target view
     (ms_tiny: 2 x 5 rays per scene; ms_rays: 2 x 128 -- enough rays that single LeakyReLU sign flips of a bf16 run average
@@ -240,8 +240,12 @@ def srt_case(name, seed, P=5):
     torch.manual_seed(seed)
     g = gen(seed)
     dtype = torch.float64
-    f_dims = {"triv": 0, "se3": 8, "so3": 8, "so2": 8}
-    ak = attn_kwargs(f_dims, 2, 2)
+    if layout == "cl":        # the CLEVR-TR layout (runs/clevrtr/GTA/gta/config.yaml:19-52): se3 + so2, no so3 -- the config the reference trains in fp32
+        f_dims = {"triv": 0, "se3": 16, "so3": 0, "so2": 8}
+        ak = attn_kwargs(f_dims, 2, 0)
+    else:
+        f_dims = {"triv": 0, "se3": 8, "so3": 8, "so2": 8}
+        ak = attn_kwargs(f_dims, 2, 2)
     aa = {"method": {"name": "gta", "args": ak}}
     cfg = {"encoder": "isrt", "decoder": "isrt",
            "encoder_kwargs": dict(dim=48, attdim=48, num_conv_blocks=3, num_att_blocks=2, heads=2, dropout=0.0,
@@ -427,6 +431,7 @@ if __name__ == "__main__":
                   cross=False, euclid=True, tau=1.3)
     srt_case("ms_tiny", seed=30)
     srt_case("ms_rays", seed=31, P=128)
+    srt_case("cl_rays", seed=32, P=128, layout="cl")
     vecrep_case("vecrep_attn", seed=40)
     module_case("enc_cl", CL, 2, 0, dim=32, depth=2, H=2, dh=16, B=2, Nq=2, Pq=6, Nk=2, Pk=6, seed=20,
                 cross=False)

@@ -131,6 +131,39 @@ def test_srt_model_matches_reference(fixture, mixed):
     _srt_grad_check(model, d, mixed)
 
 
+def test_srt_clevr_layout_fp32_faithful_psnr_parity():
+    """The CLEVR-TR layout (se3 + so2, no so3: runs/clevrtr/GTA/gta/config.yaml:19-52), the config the reference trains in fp32
+    (`mixed_prec: False`, config.yaml:55): whole TransformingSRT under the reference's weights (fixture srt_cl_rays: 2 x 128 rays per
+    scene, generated by oracle/make_golden.py from the imported reference) with every attention module in the fp32-faithful mode
+    (`Attention.precise`: fp32 rho, split-bf16 forward products, exact-fp32 backward).  PSNR parity to 0.01 dB, loss to 1e-4, every
+    parameter gradient an order of magnitude inside the default mode's bounds -- and the default (bf16-product) mode measurably
+    further away on the same fixture."""
+    from gta_amd import layers, srt
+    res = {}
+    for mode in ("precise", "default"):
+        d, model, data = _srt(fixture="srt_cl_rays")
+        for m in model.modules():
+            if isinstance(m, layers.Attention):
+                m.precise = mode == "precise"
+        loss, terms = srt.compute_loss(model, data, mixed_prec=False)
+        loss.sum().backward()
+        torch.cuda.synchronize()
+        ref_loss = torch.from_numpy(d["loss"]).float()
+        ref_psnr = torch.from_numpy(d["psnr"]).float()
+        worst = 0.0
+        for n, p in model.named_parameters():
+            if n.endswith("trans_coeff"):
+                continue
+            st = C.err_stats(p.grad.cpu(), torch.from_numpy(d["grad." + n]).float())
+            assert st["finite"], (n, st)
+            worst = max(worst, st["max_abs"] / max(st["ref_max"], 1e-4))
+        res[mode] = ((loss.cpu() - ref_loss).abs().max().item() / ref_loss.abs().max().item(),
+                     (terms["psnr"].detach().cpu() - ref_psnr).abs().max().item(), worst)
+    dl, dp, dg = res["precise"]
+    assert dl <= 1e-4 and dp <= 0.01 and dg <= 5e-3, res
+    assert res["default"][2] > 3 * dg or res["default"][0] > 3 * dl, res       # (the default mode's bf16 products are visible on this fixture)
+
+
 def test_srt_bf16_gradient_bound_is_not_vacuous():
     """The mixed-precision bounds above reject a wrong decoder gradient: zeroed, doubled or sign-flipped by hand."""
     from gta_amd import srt
