@@ -325,10 +325,6 @@ def main():
                     help="fp32-faithful forward for fp32 inputs (GTA_FLAG_FP32_PRODUCTS: split-bf16 operands, three MFMAs per product, "
                          "single-kernel plan; the reference's mixed_prec: False configs); needs --dtype f32; its fwd_bwd leg: fp32 rho kernels, "
                          "split-bf16 plain forward, exact-fp32 backward (gta_plain32.hip)")
-    ap.add_argument("--rep-stream", dest="rep_stream", default="side", choices=["side", "main"],
-                    help="where the per-step rep build (gta_build_reps) is enqueued: side = one batch ahead on a second HIP stream "
-                         "(gta_amd.plan.RepPipeline: the tables depend on poses / coordinates only, their build runs beside the previous "
-                         "batch's kernels); main = in line on the compute stream, between two attention calls (r01-r03)")
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing check without a GPU: same launch contract, rendezvous (gloo), barriers, MAX-over-ranks and "
                          "JSON line, the step itself replaced by a host no-op (tests/test_ddp_gloo.py runs this at world size 2)")
@@ -375,11 +371,8 @@ def main():
     fused = args.kv_mode == "fused"
 
     # ---- the planned step: rep build(s) + one gta_attn_fwd ----
-    have_plans = need_view and f_dims.get("so2", 0) > 0
-    piped = have_plans and args.rep_stream == "side"
-    mk_reps = plan.RepPipeline if piped else plan.RepPlan
-    reps_k = mk_reps(B, Nk, Pk, so3_deg, so2, device=device) if have_plans else None
-    reps_q = mk_reps(B, Nq, Pq, so3_deg, so2, device=device) if (reps_k is not None and cross) else None
+    reps_k = plan.RepPlan(B, Nk, Pk, so3_deg, so2, device=device) if (need_view and f_dims.get("so2", 0) > 0) else None
+    reps_q = plan.RepPlan(B, Nq, Pq, so3_deg, so2, device=device) if (reps_k is not None and cross) else None
     fwd = plan.ForwardPlan(q, k, v, f_dims, so3_degree=so3_deg, Nq=Nq if need_view else 1, Nk=Nk if need_view else 1,
                            flags=(native.FLAG_FUSED_KV | (native.FLAG_FP32_PRODUCTS if args.precise else 0)) if fused
                            else native.FLAG_ROWS32 if args.kv_mode == "prepass_rows32"
@@ -393,19 +386,7 @@ def main():
     # the sampled launches also leave per-item start / end stamps (shader cycles + 100-MHz clock): kernel cycles and granted clock
     profs = [torch.zeros(max(n_it.value, 1), 8, dtype=torch.int64, device=device) for _ in sampled]
 
-    def submit_reps():
-        reps_k.submit(exd["input_transforms"], exd["input_coord"])
-        if cross:
-            reps_q.submit(exd["target_transforms"], exd["target_coord"])
-
     def build_reps():
-        if piped:
-            # the tables of THIS batch were submitted one step ago (gta_amd.plan.RepPipeline); the next batch's build is enqueued on the
-            # side stream now and runs beside this batch's kernels.  One build per step, all inside the timed region.
-            vk, ck = reps_k.get()
-            vq, cq = reps_q.get() if cross else (vk, ck)
-            submit_reps()
-            return vq, vk, cq, ck
         if reps_k is not None:
             vk, ck = reps_k(exd["input_transforms"], exd["input_coord"])
             vq, cq = reps_q(exd["target_transforms"], exd["target_coord"]) if cross else (vk, ck)
@@ -425,15 +406,8 @@ def main():
             L.gta_debug_time_next_attention_kernel(ctypes.c_void_p(e[0]), ctypes.c_void_p(e[1]))
             pb = profs[sampled[i]]
             L.gta_debug_profile_next_attention_kernel(ctypes.c_void_p(pb.data_ptr()), pb.shape[0])      # (one-shot: this launch only)
-        out = fwd(q, k, v, vq, vk, cq, ck, tc)
-        if piped:
-            reps_k.release()
-            if cross:
-                reps_q.release()
-        return out
-
-    if piped:
-        submit_reps()                                      # (the first batch's tables)
+            return fwd(q, k, v, vq, vk, cq, ck, tc)
+        return fwd(q, k, v, vq, vk, cq, ck, tc)
 
     for _ in range(args.warmup):
         step()
@@ -479,27 +453,6 @@ def main():
         dist.all_gather(g, torch.tensor([sclk_mhz or 0.0, kern_ms or 0.0], device=device, dtype=torch.float64))
         per_rank_sclk = [float(u[0].item()) or None for u in g]
         per_rank_kern = [float(u[1].item()) or None for u in g]
-
-    # for the record: the same step with the rep build IN LINE on the compute stream (what r01-r03 timed), a short untimed-for-`value` leg
-    serial_ms = None
-    if piped and rank == 0:
-        sk = plan.RepPlan(B, Nk, Pk, so3_deg, so2, device=device)
-        sq = plan.RepPlan(B, Nq, Pq, so3_deg, so2, device=device) if cross else None
-
-        def serial_step():
-            vk, ck = sk(exd["input_transforms"], exd["input_coord"])
-            vq, cq = sq(exd["target_transforms"], exd["target_coord"]) if cross else (vk, ck)
-            fwd(q, k, v, vq, vk, cq, ck, tc)
-        for _ in range(3):
-            serial_step()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            serial_step()
-        e1.record()
-        torch.cuda.synchronize()
-        serial_ms = e0.elapsed_time(e1) / 10
 
     parity = None
     if rank == 0 and not args.no_parity:
@@ -569,10 +522,7 @@ def main():
             "config": {"workload": f"{args.workload}: GTA attention forward (rep build + K/V rep pre-pass + attention kernel), "
                                    f"B={B}/GPU, H={H}, Tq={Tq}, Tk={Tk}, dh={dh}, f_dims={f_dims}, "
                                    f"views q/k={Nq}/{Nk}" + (", fp32-faithful products (GTA_FLAG_FP32_PRODUCTS)" if args.precise else ""),
-                       "rep_build": ("one batch ahead on a second HIP stream (gta_amd.plan.RepPipeline): one build per step inside the timed "
-                                     "region, enqueued beside the previous batch's kernels" if piped else "in line on the compute stream"),
                        "global_batch": n * B, "parallelism": f"dp{n}"},
-            "serial_ms_per_step": serial_ms,
             "host_ms_per_step": t_host / args.steps * 1e3, "per_rank_ms_per_step": per_rank,
             "per_rank_sclk_mhz": per_rank_sclk, "per_rank_kernel_ms": per_rank_kern,
             "dist": __import__("gta_amd.ddp", fromlist=["backend_info"]).backend_info(),

@@ -182,11 +182,10 @@ def auto_waits(prog):
 
 
 class ItemGen:
-    def __init__(self, loop_kw=None, stamps=True, head_wait=False, phases=False, o_aux=""):
+    def __init__(self, loop_kw=None, stamps=True, head_wait=False, phases=False):
         self.loop_kw = dict(G.BEST) if loop_kw is None else loop_kw
         self.stamps = stamps
         self.head_wait = head_wait     # keep the tile loop's own vmcnt(0) at its head (the item's prologue already waited for the tiles)
-        self.o_aux = o_aux             # cache policy of the O stores ("" | " nt" | " sc0 sc1")
         self.phases = phases           # diagnostic: shader-cycle stamps [1] inputs landed, [2] prologue done, [3] loop done, [7] epilogue done
 
     def phase(self, a, k):
@@ -592,7 +591,7 @@ class ItemGen:
             for i in range(KS):
                 ops.append(lambda i=i: a.ds_read(128, xs[i], V_XL[i % 3], row0(i) * XROW))
             for i in range(KS):
-                ops.append(lambda i=i, rb=rb: a.global_store(4, V_OG[i % 3], xs[i], S_B[2 * rb + i // 3], aux=self.o_aux))
+                ops.append(lambda i=i, rb=rb: a.global_store(4, V_OG[i % 3], xs[i], S_B[2 * rb + i // 3]))
             return ops
 
         def weave(mf, fill, first=0, pad_at=None, pad=0):
@@ -1088,4 +1087,4 @@ if __name__ == "__main__":
     full = ItemGen().program()
     assemble_check(full)
     if a_.out:
-        emit(a_.out, full, ItemGen(o_aux=" nt").program(), ItemGen(phases=True).program())
+        emit(a_.out, full, ItemGen().program(pad4=True), ItemGen(phases=True).program())

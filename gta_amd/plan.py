@@ -43,55 +43,6 @@ class RepPlan:
         return self.vrep, self.cs
 
 
-class RepPipeline:
-    """Rep builds one batch AHEAD, on a second HIP stream.
-
-    The tables of a batch (per-view records, per-token (cos, sin)) depend on its poses and patch coordinates only -- data the loader
-    delivers before the previous batch has finished -- so their build need not sit between two attention calls on the compute stream:
-    ``submit`` enqueues the build for an upcoming batch on a side stream, where the (tiny, latency-sized) kernel runs in the shadow of
-    whatever the compute stream is doing (the tail of the previous batch's attention kernel and the kernel boundary behind it);
-    ``get`` makes the compute stream wait for the oldest submitted build and returns its tables; ``release`` (after the kernels that
-    read them have been enqueued) lets the slot be rebuilt.  Two slots: the tables of batch i are read while those of batch i + 1 are
-    written.  Same kernels, same results as a RepPlan called in line."""
-
-    def __init__(self, *args, **kw):
-        self.plans = [RepPlan(*args, **kw), RepPlan(*args, **kw)]
-        dev = self.plans[0].vrep.device
-        self.side = torch.cuda.Stream(device=dev)
-        self.ready = [torch.cuda.Event(), torch.cuda.Event()]
-        self.free = [torch.cuda.Event(), torch.cuda.Event()]
-        self.n_sub = self.n_get = 0
-        self._held = None
-
-    def submit(self, transforms: torch.Tensor, coord: torch.Tensor):
-        if self.n_sub - self.n_get >= 2:
-            raise native.GtaError("RepPipeline: two builds are already in flight (get / release one first)")
-        slot = self.n_sub % 2
-        main = torch.cuda.current_stream()
-        if self.n_sub >= 2:
-            self.side.wait_event(self.free[slot])          # the kernels that read this slot two batches ago are done
-        self.side.wait_stream(main) if self.n_sub < 2 else None     # (first uses: whatever produced transforms / coord on the compute stream)
-        with torch.cuda.stream(self.side):
-            self.plans[slot](transforms, coord)
-            self.ready[slot].record(self.side)
-        self.n_sub += 1
-
-    def get(self):
-        if self.n_get >= self.n_sub:
-            raise native.GtaError("RepPipeline.get without a submitted build")
-        slot = self.n_get % 2
-        torch.cuda.current_stream().wait_event(self.ready[slot])
-        self._held = slot
-        self.n_get += 1
-        p = self.plans[slot]
-        return p.vrep, p.cs
-
-    def release(self):
-        if self._held is not None:
-            self.free[self._held].record(torch.cuda.current_stream())
-            self._held = None
-
-
 class ForwardPlan:
     """One fused-eligible attention shape, two-stage plan (K/V pre-pass + attention kernel).
 

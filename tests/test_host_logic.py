@@ -274,7 +274,7 @@ def test_item_stream_generator_simulates_and_is_current():
         assert g.assemble_check(full)
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "items.inc")
-        g.emit(out, full, g.ItemGen(o_aux=" nt").program(), g.ItemGen(phases=True).program())
+        g.emit(out, full, g.ItemGen().program(pad4=True), g.ItemGen(phases=True).program())
         assert open(out).read() == open(os.path.join(d, "gta_attn64_items.inc")).read(), \
             "gta_attn64_items.inc is stale: make -C gta_amd/csrc regen"
 
