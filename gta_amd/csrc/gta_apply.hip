@@ -1,10 +1,7 @@
 // gta_apply.hip -- generic rho application for ANY f_dims layout (ablation paths of the reference):
 // t2 slab (gta.py:221-238,272-274), euclid similarity (gta.py:146-156,251-253; layers.py:213-224),
-// so3 of degree 1, unaligned slabs -- and the rho legs of the fp32-faithful mode (gta_plain32.hip).  One thread per (batch, head,
-// token) row, block by block.  r04: the rows of a workgroup pass through LDS -- read and written with coalesced accesses (a wave moves
-// 64 consecutive elements of a row per instruction), transformed in place by the row's thread (rows dh + 1 floats apart: no bank
-// conflicts) -- where r03's threads walked their 256-byte rows in global memory element by element (184 us per call at the CLEVR-TR
-// encoder shape, B = 32; r04: see profiles/r04).
+// so3 of degree 1, unaligned slabs.  One thread per (batch, head, token) row, block by block straight
+// from/to global memory -- correctness path, HBM-bound at best; the shipped configs never come here.
 //   mode 0: q side      q' = blockdiag((E_q.m)^T | D(R_q) | R(th_q) | (T_q^-1)^T) q      (euclid: affine inv(E_q).m)
 //   mode 1: k side      k' = blockdiag(inv(E_k).m | D(R_k) | R(th_k) | T_k) k  (also v)  (euclid: affine inv(E_k).m)
 //   mode 2: output      o  = blockdiag(E_q.m | D(R_q)^T | R(th_q)^T | T_q^-1) o~        (euclid: affine E_q.m)
@@ -32,52 +29,22 @@ template <int ESZ> GTA_DEV void st(char* p, int i, float v) {
     reinterpret_cast<uint16_t*>(p)[i] = (uint16_t)(pack_bf16x2(v, 0.f) & 0xffffu);
 }
 
-// rows [row0, row0 + blockDim.x) of a [B, H, T, dh] tensor (element strides sb, sh, st) <-> LDS as fp32, rows dh + 1 floats apart
-template <int ESZ>
-GTA_DEV void rows_to_lds(float* lds, const void* base, long sb, long sh, long st_, long row0, long total, int T, int H, int dh) {
-    const int n = blockDim.x * dh;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const int r = i / dh, c = i - r * dh;
-        const long row = row0 + r;
-        if (row >= total) break;
-        const int t = (int)(row % T), h = (int)((row / T) % H), b = (int)(row / ((long)T * H));
-        lds[r * (dh + 1) + c] = ld<ESZ>((const char*)base + ((long)b * sb + (long)h * sh + (long)t * st_) * ESZ, c);
-    }
-}
-template <int ESZ>
-GTA_DEV void lds_to_rows(const float* lds, void* base, long sb, long sh, long st_, long row0, long total, int T, int H, int dh) {
-    const int n = blockDim.x * dh;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const int r = i / dh, c = i - r * dh;
-        const long row = row0 + r;
-        if (row >= total) break;
-        const int t = (int)(row % T), h = (int)((row / T) % H), b = (int)(row / ((long)T * H));
-        st<ESZ>((char*)base + ((long)b * sb + (long)h * sh + (long)t * st_) * ESZ, c, lds[r * (dh + 1) + c]);
-    }
-}
-constexpr int LE = 4;            // (the rows are fp32 in LDS whatever the tensors' element type)
-
 template <int ESZ>
 __global__ void gta_apply_kernel(const ApplyParams p) {
-    extern __shared__ float apply_lds[];
-    const long row0 = (long)blockIdx.x * blockDim.x;
-    const long row = row0 + threadIdx.x;
+    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)p.B * p.H * p.T;
-    const int dh = p.d_triv + p.d_se3 + p.d_so3 + p.d_so2 + p.d_t2;
-    rows_to_lds<ESZ>(apply_lds, p.x, p.x_sb, p.x_sh, p.x_st, row0, total, p.T, p.H, dh);
-    __syncthreads();
-    if (row < total) {
+    if (row >= total) return;
     const int t = (int)(row % p.T);
     const int h = (int)((row / p.T) % p.H);
     const int b = (int)(row / ((long)p.T * p.H));
-    char* y = (char*)(apply_lds + threadIdx.x * (dh + 1));        // the row is transformed in place (every block is read before it is written)
-    const char* x = y;
+    const char* x = (const char*)p.x + ((long)b * p.x_sb + (long)h * p.x_sh + (long)t * p.x_st) * ESZ;
+    char* y = (char*)p.y + ((long)b * p.y_sb + (long)h * p.y_sh + (long)t * p.y_st) * ESZ;
     const float tc = p.trans_coeff ? *p.trans_coeff : 1.0f;
     const int n = t / p.P;
     const float* vr = p.vrep ? p.vrep + ((long)b * p.N + n) * GTA_VREP_STRIDE : nullptr;
     float sq = 0.f;
     int ch = 0;
-    for (int i = 0; i < p.d_triv; ++i, ++ch) { const float v = ld<LE>(x, ch); st<LE>(y, ch, v); sq += v * v; }
+    for (int i = 0; i < p.d_triv; ++i, ++ch) { const float v = ld<ESZ>(x, ch); st<ESZ>(y, ch, v); sq += v * v; }
     if (p.d_se3 > 0) {
         // matrix used: mode 0 non-euclid: (E.m)^T ; mode 0 euclid: inv(E).m ; mode 1: inv(E).m ; mode 2: E.m
         float M[16];
@@ -91,18 +58,18 @@ __global__ void gta_apply_kernel(const ApplyParams p) {
             }
         if (p.euclid) {
             for (int blk = 0; blk < p.d_se3 / 3; ++blk, ch += 3) {
-                const float a = ld<LE>(x, ch), bb = ld<LE>(x, ch + 1), c = ld<LE>(x, ch + 2);
+                const float a = ld<ESZ>(x, ch), bb = ld<ESZ>(x, ch + 1), c = ld<ESZ>(x, ch + 2);
                 for (int r = 0; r < 3; ++r) {
                     const float v = M[r * 4] * a + M[r * 4 + 1] * bb + M[r * 4 + 2] * c + M[r * 4 + 3];   // homogenisation
-                    st<LE>(y, ch + r, v); sq += v * v;
+                    st<ESZ>(y, ch + r, v); sq += v * v;
                 }
             }
         } else {
             for (int blk = 0; blk < p.d_se3 / 4; ++blk, ch += 4) {
-                const float a = ld<LE>(x, ch), bb = ld<LE>(x, ch + 1), c = ld<LE>(x, ch + 2), d = ld<LE>(x, ch + 3);
+                const float a = ld<ESZ>(x, ch), bb = ld<ESZ>(x, ch + 1), c = ld<ESZ>(x, ch + 2), d = ld<ESZ>(x, ch + 3);
                 for (int r = 0; r < 4; ++r) {
                     const float v = M[r * 4] * a + M[r * 4 + 1] * bb + M[r * 4 + 2] * c + M[r * 4 + 3] * d;
-                    st<LE>(y, ch + r, v); sq += v * v;
+                    st<ESZ>(y, ch + r, v); sq += v * v;
                 }
             }
         }
@@ -114,11 +81,11 @@ __global__ void gta_apply_kernel(const ApplyParams p) {
                 const int dim = 2 * l + 1;
                 const float* D = vr + (l == 1 ? GTA_VREP_D1 : GTA_VREP_D2);
                 float in[5];
-                for (int i = 0; i < dim; ++i) in[i] = ld<LE>(x, ch + i);
+                for (int i = 0; i < dim; ++i) in[i] = ld<ESZ>(x, ch + i);
                 for (int r = 0; r < dim; ++r) {
                     float v = 0.f;
                     for (int c = 0; c < dim; ++c) v += (p.mode == 2 ? D[c * dim + r] : D[r * dim + c]) * in[c];
-                    st<LE>(y, ch + r, v); sq += v * v;
+                    st<ESZ>(y, ch + r, v); sq += v * v;
                 }
                 ch += dim;
             }
@@ -129,26 +96,23 @@ __global__ void gta_apply_kernel(const ApplyParams p) {
         const float* cs = p.cs + ((long)b * p.T + t) * 2 * nblk;
         for (int blk = 0; blk < nblk; ++blk, ch += 2) {
             const float c = cs[2 * blk], s = (p.mode == 2 ? -1.f : 1.f) * cs[2 * blk + 1];
-            const float a = ld<LE>(x, ch), bb = ld<LE>(x, ch + 1);
+            const float a = ld<ESZ>(x, ch), bb = ld<ESZ>(x, ch + 1);
             const float v0 = c * a - s * bb, v1 = s * a + c * bb;
-            st<LE>(y, ch, v0); st<LE>(y, ch + 1, v1); sq += v0 * v0 + v1 * v1;
+            st<ESZ>(y, ch, v0); st<ESZ>(y, ch + 1, v1); sq += v0 * v0 + v1 * v1;
         }
     }
     if (p.d_t2 > 0) {
         const float cx = p.coord[((long)b * p.T + t) * 2], cy = p.coord[((long)b * p.T + t) * 2 + 1];
         for (int blk = 0; blk < p.d_t2 / 3; ++blk, ch += 3) {
-            const float a = ld<LE>(x, ch), bb = ld<LE>(x, ch + 1), c = ld<LE>(x, ch + 2);
+            const float a = ld<ESZ>(x, ch), bb = ld<ESZ>(x, ch + 1), c = ld<ESZ>(x, ch + 2);
             float v0, v1, v2;
             if (p.mode == 0)      { v0 = a - cx * c; v1 = bb - cy * c; v2 = c; }                   // (T^-1)^T
             else if (p.mode == 1) { v0 = a; v1 = bb; v2 = cx * a + cy * bb + c; }                  // T
             else                  { v0 = a; v1 = bb; v2 = c - cx * a - cy * bb; }                  // T^-1
-            st<LE>(y, ch, v0); st<LE>(y, ch + 1, v1); st<LE>(y, ch + 2, v2); sq += v0 * v0 + v1 * v1 + v2 * v2;
+            st<ESZ>(y, ch, v0); st<ESZ>(y, ch + 1, v1); st<ESZ>(y, ch + 2, v2); sq += v0 * v0 + v1 * v1 + v2 * v2;
         }
     }
     if (p.key_bias) p.key_bias[((long)b * p.H + h) * p.bias_pitch + t] = -0.5f * p.bias_scale * sq;
-    }
-    __syncthreads();
-    lds_to_rows<ESZ>(apply_lds, p.y, p.y_sb, p.y_sh, p.y_st, row0, total, p.T, p.H, dh);
 }
 
 // Adjoint of the above: dx = M^T dy for the block-diagonal M of `mode`, plus (optionally) this row's contribution
@@ -166,29 +130,22 @@ struct ApplyBwdParams {
 template <int ESZ>
 __global__ void gta_apply_bwd_kernel(const ApplyBwdParams q) {
     const ApplyParams& p = q.f;
-    extern __shared__ float apply_lds[];
-    const long row0 = (long)blockIdx.x * blockDim.x;
-    const long row = row0 + threadIdx.x;
+    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)p.B * p.H * p.T;
-    const int dh = p.d_triv + p.d_se3 + p.d_so3 + p.d_so2 + p.d_t2;
-    float* lds_dy = apply_lds + blockDim.x * (dh + 1);
-    rows_to_lds<ESZ>(apply_lds, p.x, p.x_sb, p.x_sh, p.x_st, row0, total, p.T, p.H, dh);
-    rows_to_lds<ESZ>(lds_dy, q.dy, q.dy_sb, q.dy_sh, q.dy_st, row0, total, p.T, p.H, dh);
-    __syncthreads();
-    if (row < total) {
+    if (row >= total) return;
     const int t = (int)(row % p.T);
     const int h = (int)((row / p.T) % p.H);
     const int b = (int)(row / ((long)p.T * p.H));
-    const char* x = (const char*)(apply_lds + threadIdx.x * (dh + 1));
-    char* dx = (char*)(lds_dy + threadIdx.x * (dh + 1));          // dx takes dy's place (every block of dy is read before it is written)
-    const char* dy = dx;
+    const char* x = (const char*)p.x + ((long)b * p.x_sb + (long)h * p.x_sh + (long)t * p.x_st) * ESZ;
+    const char* dy = (const char*)q.dy + ((long)b * q.dy_sb + (long)h * q.dy_sh + (long)t * q.dy_st) * ESZ;
+    char* dx = (char*)q.dx + ((long)b * q.dx_sb + (long)h * q.dx_sh + (long)t * q.dx_st) * ESZ;
     const float tc = p.trans_coeff ? *p.trans_coeff : 1.0f;
     const int n = t / p.P;
     const float* vr = p.vrep ? p.vrep + ((long)b * p.N + n) * GTA_VREP_STRIDE : nullptr;
     const float kb = q.dbias ? -p.bias_scale * q.dbias[((long)b * p.H + h) * p.bias_pitch + t] : 0.f;   // d/dy of the bias = kb * y
     float dc = 0.f;
     int ch = 0;
-    for (int i = 0; i < p.d_triv; ++i, ++ch) st<LE>(dx, ch, ld<LE>(dy, ch) + kb * ld<LE>(x, ch));
+    for (int i = 0; i < p.d_triv; ++i, ++ch) st<ESZ>(dx, ch, ld<ESZ>(dy, ch) + kb * ld<ESZ>(x, ch));
     if (p.d_se3 > 0) {
         float M[16];                                     // the forward's matrix, row-major (y = M x)
         const bool use_inv_slot = (p.mode == 2) || (p.mode == 0 && !p.euclid);
@@ -201,24 +158,24 @@ __global__ void gta_apply_bwd_kernel(const ApplyBwdParams q) {
             }
         if (p.euclid) {
             for (int blk = 0; blk < p.d_se3 / 3; ++blk, ch += 3) {
-                const float a = ld<LE>(x, ch), bb = ld<LE>(x, ch + 1), c = ld<LE>(x, ch + 2);
+                const float a = ld<ESZ>(x, ch), bb = ld<ESZ>(x, ch + 1), c = ld<ESZ>(x, ch + 2);
                 float g[3];
                 for (int r = 0; r < 3; ++r) {
                     const float y = M[r * 4] * a + M[r * 4 + 1] * bb + M[r * 4 + 2] * c + M[r * 4 + 3];
-                    g[r] = ld<LE>(dy, ch + r) + kb * y;
+                    g[r] = ld<ESZ>(dy, ch + r) + kb * y;
                     dc += g[r] * src[r * 4 + 3];                            // y_r = ... + c * t_r
                 }
-                for (int col = 0; col < 3; ++col) st<LE>(dx, ch + col, M[col] * g[0] + M[4 + col] * g[1] + M[8 + col] * g[2]);
+                for (int col = 0; col < 3; ++col) st<ESZ>(dx, ch + col, M[col] * g[0] + M[4 + col] * g[1] + M[8 + col] * g[2]);
             }
         } else {
             for (int blk = 0; blk < p.d_se3 / 4; ++blk, ch += 4) {
                 float xi[4], g[4];
-                for (int i = 0; i < 4; ++i) { xi[i] = ld<LE>(x, ch + i); g[i] = ld<LE>(dy, ch + i); }
+                for (int i = 0; i < 4; ++i) { xi[i] = ld<ESZ>(x, ch + i); g[i] = ld<ESZ>(dy, ch + i); }
                 if (kb != 0.f)
                     for (int r = 0; r < 4; ++r)
                         g[r] += kb * (M[r * 4] * xi[0] + M[r * 4 + 1] * xi[1] + M[r * 4 + 2] * xi[2] + M[r * 4 + 3] * xi[3]);
                 for (int col = 0; col < 4; ++col)
-                    st<LE>(dx, ch + col, M[col] * g[0] + M[4 + col] * g[1] + M[8 + col] * g[2] + M[12 + col] * g[3]);
+                    st<ESZ>(dx, ch + col, M[col] * g[0] + M[4 + col] * g[1] + M[8 + col] * g[2] + M[12 + col] * g[3]);
                 if (p.mode == 0) dc += g[3] * (src[3] * xi[0] + src[7] * xi[1] + src[11] * xi[2]);       // y_3 = sum_c E[c][3] c x_c + x_3
                 else             dc += (g[0] * src[3] + g[1] * src[7] + g[2] * src[11]) * xi[3];           // y_r = ... + M[r][3] c x_3
             }
@@ -231,11 +188,11 @@ __global__ void gta_apply_bwd_kernel(const ApplyBwdParams q) {
                 const int dim = 2 * l + 1;
                 const float* D = vr + (l == 1 ? GTA_VREP_D1 : GTA_VREP_D2);
                 float in[5];
-                for (int i = 0; i < dim; ++i) in[i] = ld<LE>(dy, ch + i);
+                for (int i = 0; i < dim; ++i) in[i] = ld<ESZ>(dy, ch + i);
                 for (int r = 0; r < dim; ++r) {
-                    float v = kb * ld<LE>(x, ch + r);                     // D orthogonal: D^T (kb D x) = kb x
+                    float v = kb * ld<ESZ>(x, ch + r);                     // D orthogonal: D^T (kb D x) = kb x
                     for (int c = 0; c < dim; ++c) v += (p.mode == 2 ? D[r * dim + c] : D[c * dim + r]) * in[c];
-                    st<LE>(dx, ch + r, v);
+                    st<ESZ>(dx, ch + r, v);
                 }
                 ch += dim;
             }
@@ -246,16 +203,16 @@ __global__ void gta_apply_bwd_kernel(const ApplyBwdParams q) {
         const float* cs = p.cs + ((long)b * p.T + t) * 2 * nblk;
         for (int blk = 0; blk < nblk; ++blk, ch += 2) {
             const float c = cs[2 * blk], s = (p.mode == 2 ? -1.f : 1.f) * cs[2 * blk + 1];
-            const float a = ld<LE>(dy, ch), bb = ld<LE>(dy, ch + 1);
-            st<LE>(dx, ch, c * a + s * bb + kb * ld<LE>(x, ch)); st<LE>(dx, ch + 1, -s * a + c * bb + kb * ld<LE>(x, ch + 1));
+            const float a = ld<ESZ>(dy, ch), bb = ld<ESZ>(dy, ch + 1);
+            st<ESZ>(dx, ch, c * a + s * bb + kb * ld<ESZ>(x, ch)); st<ESZ>(dx, ch + 1, -s * a + c * bb + kb * ld<ESZ>(x, ch + 1));
         }
     }
     if (p.d_t2 > 0) {
         const float cx = p.coord[((long)b * p.T + t) * 2], cy = p.coord[((long)b * p.T + t) * 2 + 1];
         for (int blk = 0; blk < p.d_t2 / 3; ++blk, ch += 3) {
-            float a = ld<LE>(dy, ch), bb = ld<LE>(dy, ch + 1), c = ld<LE>(dy, ch + 2);
+            float a = ld<ESZ>(dy, ch), bb = ld<ESZ>(dy, ch + 1), c = ld<ESZ>(dy, ch + 2);
             if (kb != 0.f) {                                               // y = T x recomputed for the bias term
-                const float xa = ld<LE>(x, ch), xb = ld<LE>(x, ch + 1), xc = ld<LE>(x, ch + 2);
+                const float xa = ld<ESZ>(x, ch), xb = ld<ESZ>(x, ch + 1), xc = ld<ESZ>(x, ch + 2);
                 float y0, y1, y2;
                 if (p.mode == 0)      { y0 = xa - cx * xc; y1 = xb - cy * xc; y2 = xc; }
                 else if (p.mode == 1) { y0 = xa; y1 = xb; y2 = cx * xa + cy * xb + xc; }
@@ -266,13 +223,10 @@ __global__ void gta_apply_bwd_kernel(const ApplyBwdParams q) {
             if (p.mode == 0)      { v0 = a; v1 = bb; v2 = c - cx * a - cy * bb; }
             else if (p.mode == 1) { v0 = a + cx * c; v1 = bb + cy * c; v2 = c; }
             else                  { v0 = a - cx * c; v1 = bb - cy * c; v2 = c; }
-            st<LE>(dx, ch, v0); st<LE>(dx, ch + 1, v1); st<LE>(dx, ch + 2, v2);
+            st<ESZ>(dx, ch, v0); st<ESZ>(dx, ch + 1, v1); st<ESZ>(dx, ch + 2, v2);
         }
     }
     if (q.dtc_rows) q.dtc_rows[row] = dc;
-    }
-    __syncthreads();
-    lds_to_rows<ESZ>(lds_dy, q.dx, q.dx_sb, q.dx_sh, q.dx_st, row0, total, p.T, p.H, dh);
 }
 
 }  // namespace
@@ -303,18 +257,10 @@ extern "C" int gta_rep_apply(const GtaAttnDesc* d, int32_t mode, const void* x, 
     p.d_triv = d->d_triv; p.d_se3 = d->d_se3; p.d_so3 = d->d_so3; p.d_so2 = d->d_so2; p.d_t2 = d->d_t2; p.L = d->so3_degree;
     p.mode = mode; p.euclid = euclid ? 1 : 0; p.esz = d->dtype == GTA_DTYPE_BF16 ? 2 : 4;
     const long total = (long)p.B * p.H * p.T;
-    int th = 256;                                        // rows per workgroup: as many as the LDS holds (dh + 1 floats each)
-    while (th > 64 && (long)th * (d->dh + 1) * 4 > 150 * 1024) th >>= 1;
-    const int lds = th * (d->dh + 1) * 4;
-    if (lds > 150 * 1024) return GTA_E_UNSUPPORTED;
+    const int th = 256;
     const unsigned nb = (unsigned)((total + th - 1) / th);
-    if (p.esz == 2) {
-        if (int rc = gta_lds_optin<&gta_apply_kernel<2>>(150 * 1024)) return rc;
-        hipLaunchKernelGGL(gta_apply_kernel<2>, dim3(nb), dim3(th), lds, (hipStream_t)stream, p);
-    } else {
-        if (int rc = gta_lds_optin<&gta_apply_kernel<4>>(150 * 1024)) return rc;
-        hipLaunchKernelGGL(gta_apply_kernel<4>, dim3(nb), dim3(th), lds, (hipStream_t)stream, p);
-    }
+    if (p.esz == 2) hipLaunchKernelGGL(gta_apply_kernel<2>, dim3(nb), dim3(th), 0, (hipStream_t)stream, p);
+    else            hipLaunchKernelGGL(gta_apply_kernel<4>, dim3(nb), dim3(th), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH;
 }
 
@@ -349,17 +295,9 @@ extern "C" int gta_rep_apply_bwd(const GtaAttnDesc* d, int32_t mode, const void*
     q.dx_sb = dx_stride[0]; q.dx_sh = dx_stride[1]; q.dx_st = dx_stride[2];
     q.dbias = dkey_bias; q.dtc_rows = dtc_rows;
     const long total = (long)p.B * p.H * p.T;
-    int th = 256;                                        // rows per workgroup: x and dy rows in LDS (dh + 1 floats each)
-    while (th > 64 && 2L * th * (d->dh + 1) * 4 > 150 * 1024) th >>= 1;
-    const int lds = 2 * th * (d->dh + 1) * 4;
-    if (lds > 150 * 1024) return GTA_E_UNSUPPORTED;
+    const int th = 256;
     const unsigned nb = (unsigned)((total + th - 1) / th);
-    if (p.esz == 2) {
-        if (int rc = gta_lds_optin<&gta_apply_bwd_kernel<2>>(150 * 1024)) return rc;
-        hipLaunchKernelGGL(gta_apply_bwd_kernel<2>, dim3(nb), dim3(th), lds, (hipStream_t)stream, q);
-    } else {
-        if (int rc = gta_lds_optin<&gta_apply_bwd_kernel<4>>(150 * 1024)) return rc;
-        hipLaunchKernelGGL(gta_apply_bwd_kernel<4>, dim3(nb), dim3(th), lds, (hipStream_t)stream, q);
-    }
+    if (p.esz == 2) hipLaunchKernelGGL(gta_apply_bwd_kernel<2>, dim3(nb), dim3(th), 0, (hipStream_t)stream, q);
+    else            hipLaunchKernelGGL(gta_apply_bwd_kernel<4>, dim3(nb), dim3(th), 0, (hipStream_t)stream, q);
     return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH;
 }
