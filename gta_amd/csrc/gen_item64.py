@@ -491,17 +491,24 @@ class ItemGen:
         CSP = [[V(188 + 16 * rb + 8 * sl, 8) for sl in range(2)] for rb in range(RB)]     # slot 0: channels 8..15 of the lane's last block, slot 1: 0..7 (lanes 32..63)
         INV, LT = ["v220", "v221"], ["v222", "v223"]
         ET = [V(224, 8), V(232, 8)]
-        # Cq tiles of this item's view, then the next item's inputs: everything flies under the arithmetic below
-        self.tile_bases(a, cur, 1)
-        for i in range(12):
-            a.global_load(4, CT[i], V_LANE16, S_B[i // 4], 1024 * (i % 4))
-        self.request(a)
-        # this item's (cos, sin) pairs for rho_q^-1: channels 8..15 of the lane's block 2 = chunk 9 + 2 lh; 0..7 (lanes 32..63) = chunk 10
+        # Two instruction lists, woven: (i) the memory side -- Cq tiles of this item's view, the next item's inputs (Q rows, Aq tiles, key
+        # norms: request), its (cos, sin) rows by LDS-DMA -- 43 vector-memory instructions whose address processing would stall one
+        # another back to back; (ii) the arithmetic that needs none of it yet: l, 1 / l, LSE, and (below) row block 0's B fragments.
+        main = a
+        # this item's (cos, sin) pairs for rho_q^-1 first: channels 8..15 of the lane's block 2 = chunk 9 + 2 lh; 0..7 (lanes 32..63) = chunk 10
         for rb in range(RB):
             for h in range(2):
                 a.ds_read(128, CSP[rb][0][4 * h:4 * h + 4], V_CSRB, rb * 32 * CS_ROW + 16 * h)
             for h in range(2):
                 a.ds_read(128, CSP[rb][1][4 * h:4 * h + 4], V_CSR, rb * 32 * CS_ROW + 32 + 16 * h)
+        mem = Asm()
+        self.tile_bases(mem, cur, 1)
+        for i in range(12):
+            mem.global_load(4, CT[i], V_LANE16, S_B[i // 4], 1024 * (i % 4))
+        self.request(mem)
+        mem.waitcnt(lgkm=0)                # the pairs are in registers: the (cos, sin) region may take the next item's rows
+        self.cs_dma(mem)
+        a = Asm()
         # l = l(lane) + l(lane ^ 32); 1 / l by hipcc's IEEE division sequence (bit-compatible with the C++ epilogue);
         # LSE = (m + log2 l) ln 2
         for rb in range(RB):
@@ -529,8 +536,6 @@ class ItemGen:
         for rb in range(RB):
             a.v_add_f32(t[8 + rb], V_MR[rb], t[8 + rb])
             a.v_mul_f32(t[8 + rb], LN2_BITS, t[8 + rb])
-        a.waitcnt(lgkm=0)                  # the pairs are in registers: the (cos, sin) region may take the next item's rows
-        self.cs_dma(a)
 
         def build_of(rb):
             """the normalised accumulators of a lane, packed pairwise, ARE the B fragments of rho_q^-1"""
@@ -613,6 +618,16 @@ class ItemGen:
 
         for op in build_of(0):
             op()
+        # weave: one memory-side instruction per three of the arithmetic
+        arith, a = a.out, main
+        mi, per = 0, max(1, len(arith) // max(len(mem.out), 1))
+        for i, ins in enumerate(arith):
+            a.raw(ins)
+            if (i + 1) % per == 0 and mi < len(mem.out):
+                a.raw(mem.out[mi])
+                mi += 1
+        for ins in mem.out[mi:]:
+            a.raw(ins)
         # O stores: four bases (row block, half): this item's O rows + (64 wave + 32 rb + 16 j) rows
         a.s_lshl_b32(S_T[0], "%[wave]", 2)
         a.s_mul_i32(S_T[0], S_T[0], S_O16)                    # 64 wave rows
