@@ -157,11 +157,11 @@ extern "C" const char* gta_debug_attention_kernel(const GtaAttnDesc* d, int32_t*
     if (build_ctab(d, p.ctab)) return "";
     const int esz = d->dtype == GTA_DTYPE_BF16 ? 2 : 4;
     const bool need_view = d->d_se3 > 0 || d->d_so3 > 0;
-    p.B = d->B; p.H = d->H; p.Tq = d->Tq; p.Tk = d->Tk; p.dh = d->dh; p.flags = d->flags; p.kn = (float*)1; p.cs_q = d->d_so2 ? (const float*)1 : nullptr;
+    p.B = d->B; p.H = d->H; p.Tq = d->Tq; p.Tk = d->Tk; p.dh = d->dh; p.flags = d->flags; p.kn = (float*)256; p.cs_q = d->d_so2 ? (const float*)256 : nullptr; p.kp = (void*)256;
     // (what gta_attn_fwd would hand the dispatch for a full call with LSE: only null / non-null matters here)
-    p.Nq = d->Nq; p.Nk = d->Nk; p.Pq = d->Tq / d->Nq; p.Pk = d->Tk / d->Nk; p.nso2 = d->d_so2 / 2; p.lse = (float*)1;
-    p.vrep_q = need_view ? (const float*)1 : nullptr; p.q_st = d->q_stride[2]; p.o_st = d->o_stride[2];
-    p.qtiles = (padded_dh(d->dh) == 96 && esz == 2 && need_view) ? (void*)1 : nullptr;
+    p.Nq = d->Nq; p.Nk = d->Nk; p.Pq = d->Tq / d->Nq; p.Pk = d->Tk / d->Nk; p.nso2 = d->d_so2 / 2; p.lse = (float*)256;
+    p.vrep_q = need_view ? (const float*)256 : nullptr; p.q_st = d->q_stride[2]; p.o_st = d->o_stride[2];
+    p.qtiles = (padded_dh(d->dh) == 96 && esz == 2 && need_view) ? (void*)256 : nullptr;
     const bool two_stage = !(d->flags & (GTA_FLAG_FUSED_KV | GTA_FLAG_FP32_PRODUCTS | GTA_FLAG_PRETRANSFORMED));
     const int rows = !two_stage ? 128 : gta_fwd2_rows_per_item(p, padded_dh(d->dh), esz);
     if (n_items) *n_items = d->B * d->H * ((d->Tq + rows - 1) / rows);
