@@ -194,7 +194,8 @@ class ItemGen:
         if not self.phases:
             return
         t = TMP
-        lab = f"L_noph{k}_%="
+        self._nph = getattr(self, "_nph", 0) + 1
+        lab = f"L_noph{k}_{self._nph}_%="
         a.waitcnt(lgkm=0)
         a.s_or_b32(S_T[0], "%[prof_lo]", "%[prof_hi]")
         a.branch("s_cbranch_scc0", lab)
@@ -218,6 +219,9 @@ class ItemGen:
 
     # ---- once per statement: lane constants, the loop's address table, the first item's inputs ------------------------
     def chunk_prologue(self, a):
+        """once per statement.  First what the first item's request needs (lane ids, the gather offsets of the coalesced accesses, the
+        (cos, sin) source offsets), then the request itself; every other lane constant and the tile loop's offset table are set up while
+        those loads fly (r04: done in this order the launch reaches its first tile loop ~2 us sooner)."""
         t = TMP
         lane, l31, lh = t[0], t[1], t[2]
         a.v_mbcnt_lane(lane)
@@ -232,13 +236,6 @@ class ItemGen:
         a.s_lshl_b32(S_O16, "%[orb]", 4)
         a.s_mov_b32(S_HI[0], 0)
         a.s_mov_b32(S_HI[1], -1)
-        # scratch rows: XW + l31 * 208 (+ 16 lh: the lane's fragment column; + 32 lh: its 16 output channels of a block)
-        a.v_mul_u32_u24(t[3], XROW, l31)
-        a.v_add_u32(t[3], S_XW, t[3])
-        a.v_lshlrev_b32(t[4], 4, lh)
-        a.v_add_u32(V_XFR, t[3], t[4])
-        a.v_lshlrev_b32(t[4], 5, lh)
-        a.v_add_u32(V_OXW, t[3], t[4])
         # coalesced access i of a block of 192-byte rows: unit 64 i + lane = row row0(i) + g, column Lm - 12 g, Lm = lane + 4 (i % 3),
         # g = Lm / 12 (= (43 Lm) >> 9 for Lm < 76); the wave's block starts at row 64 wave of the item.  row0(i) = row0(i % 3) +
         # 16 (i / 3): the row0(i % 3) part rides in the lane offset, the 16-row steps in four scalar bases
@@ -264,6 +261,26 @@ class ItemGen:
         a.s_mul_i32(S_T[1], "%[wave]", CS_WAVE)
         a.v_add_u32(V_CSG, S_T[1], V_LANE16)
         a.v_add_u32(V_CSG2, 4096, V_CSG)
+        a.s_mov_b32(S_K, 0)
+        a.s_mov_b32(S_TAB, "%[tabl]")
+        if self.phases:
+            a.s_mov_b64(S_PH3, 0)
+        self.read_desc(a, 0)                                  # item 0's descriptor, as "next" ...
+        self.request(a)                                       # ... its inputs requested ...
+        self.cs_dma(a)
+        self.advance_desc(a)                                  # ... and it becomes the current item
+        # ---- under the loads' flight: the rest of the lane constants, the tile loop's LDS offsets, the second descriptor ----
+        a.v_mbcnt_lane(lane)                                  # (the descriptor read used the temporaries)
+        a.v_and_b32(l31, 31, lane)
+        a.v_lshrrev_b32(lh, 5, lane)
+        # scratch rows: XW + l31 * 208 (+ 16 lh: the lane's fragment column; + 32 lh: its 16 output channels of a block)
+        a.v_mul_u32_u24(t[3], XROW, l31)
+        a.v_add_u32(t[3], S_XW, t[3])
+        a.v_lshlrev_b32(t[4], 4, lh)
+        a.v_add_u32(V_XFR, t[3], t[4])
+        a.v_lshlrev_b32(t[4], 5, lh)
+        a.v_add_u32(V_OXW, t[3], t[4])
+        a.s_mul_i32(S_T[1], "%[wave]", CS_WAVE)
         a.s_add_u32(S_T[1], S_T[1], OFF_CS)
         a.v_mul_u32_u24(t[3], CS_ROW, l31)
         a.v_add_u32(V_CSR, S_T[1], t[3])
@@ -271,21 +288,14 @@ class ItemGen:
         a.v_add_u32(V_CSRA, V_CSR, t[4])
         a.v_lshlrev_b32(t[4], 6, lh)
         a.v_add_u32(V_CSRB, V_CSR, t[4])
+        a.s_lshl_b32(S_T[0], "%[wave]", 6)
         a.v_add_u32(t[3], S_T[0], l31)
         a.v_lshlrev_b32(V_LSE, 2, t[3])
         # the tile loop's per-lane LDS offsets (written by the C++ side once per kernel): read back ONCE per statement
         a.v_add_u32(t[3], OFF_TAB, V_LANE4)
         for i, r in enumerate(G.KOFF + [G.VOFF[d][h] for d in range(DB) for h in range(2)]):
             a.ds_read(32, [r], t[3], 256 * i)
-        a.s_mov_b32(S_K, 0)
-        a.s_mov_b32(S_TAB, "%[tabl]")
-        if self.phases:
-            a.s_mov_b64(S_PH3, 0)
         a.waitcnt(lgkm=0)
-        self.read_desc(a, 0)                                  # item 0's descriptor, as "next" ...
-        self.request(a)                                       # ... its inputs requested ...
-        self.cs_dma(a)
-        self.advance_desc(a)                                  # ... and it becomes the current item
         self.read_desc(a, 1)
         self.stamp_row(a, S_PREV)                             # (the first boundary's "previous item" is the item itself)
         a.waitcnt(vm=0)
@@ -484,7 +494,9 @@ class ItemGen:
             a.s_addc_u32(dst[1], src[1], 0)
 
     # ---- item epilogue ---------------------------------------------------------------------------------------------------
-    def epilogue(self, a):
+    def epilogue(self, a, last=False):
+        """last: the statement's final item -- nothing is requested for an item after it (the launch ends with its stores, not with loads
+        nobody reads)"""
         t = TMP
         OF = [[[V(44 + 24 * rb + 8 * d + 4 * kk, 4) for kk in range(2)] for d in range(DB)] for rb in range(RB)]     # v44..v91: packed O~ B fragments
         ACC = [[V(92 + 48 * rb + 16 * d, 16) for d in range(DB)] for rb in range(RB)]                                 # v92..v187
@@ -505,9 +517,10 @@ class ItemGen:
         self.tile_bases(mem, cur, 1)
         for i in range(12):
             mem.global_load(4, CT[i], V_LANE16, S_B[i // 4], 1024 * (i % 4))
-        self.request(mem)
-        mem.waitcnt(lgkm=0)                # the pairs are in registers: the (cos, sin) region may take the next item's rows
-        self.cs_dma(mem)
+        if not last:
+            self.request(mem)
+            mem.waitcnt(lgkm=0)            # the pairs are in registers: the (cos, sin) region may take the next item's rows
+            self.cs_dma(mem)
         a = Asm()
         # l = l(lane) + l(lane ^ 32); 1 / l by hipcc's IEEE division sequence (bit-compatible with the C++ epilogue);
         # LSE = (m + log2 l) ln 2
@@ -636,7 +649,7 @@ class ItemGen:
         for j in range(1, 4):
             a.s_add_u32(S_B[j][0], S_B[j - 1][0], S_O16)
             a.s_addc_u32(S_B[j][1], S_B[j - 1][1], 0)
-        a.waitcnt(vm=31)                   # the Cq tiles (behind them: 12 Q quads, 12 Aq tiles, the key norms, six DMA pieces)
+        a.waitcnt(vm=0 if last else 31)    # the Cq tiles (behind them: 12 Q quads, 12 Aq tiles, the key norms, six DMA pieces)
         weave(mfmas(0), build_of(1))
         weave(mfmas(1), post(0) + stores(0), first=3, pad_at=2, pad=8)
         a.nop(8)
@@ -682,6 +695,9 @@ class ItemGen:
         head = auto_waits(a.out)
         a = Asm()
         self.phase(a, 2)
+        a.s_add_u32(S_T[0], S_K, 1)
+        a.s_cmp("ge", "u32", S_T[0], "%[nit]")
+        a.branch("s_cbranch_scc1", "L_last_%=")
         self.epilogue(a)
         # next item: its descriptor becomes the current one, the one after it is read from the table
         a.waitcnt(lgkm=0)
@@ -690,8 +706,11 @@ class ItemGen:
         a.s_add_u32(S_K, S_K, 1)
         a.s_add_u32(S_TAB, S_TAB, ITEM_BYTES)
         self.read_desc(a, 1)
-        a.s_cmp("lt", "u32", S_K, "%[nit]")
-        a.branch("s_cbranch_scc1", "L_item_%=")
+        a.branch("s_branch", "L_item_%=")
+        a.label("L_last_%=")
+        self.epilogue(a, last=True)
+        a.waitcnt(lgkm=0)
+        self.phase(a, 3)
         self.stamp(a, "end", last=True)
         a.waitcnt(vm=0)
         a.pseudo("end")

@@ -268,7 +268,9 @@ def test_item_stream_generator_simulates_and_is_current():
     import tempfile
     g, d = _load_csrc_module("gen_item64")
     st = g.check()
-    assert st["mfma"] == 48 and st["instructions"] < 1400, st          # 2 x 12 MFMAs per item side; ~1 200 instructions incl. the per-launch setup
+    # 2 x 12 MFMAs in the prologue and in each of the two epilogue copies (the statement's last item has its own: no request behind it);
+    # ~1 100 instructions per item besides the tile loop, ~200 of per-launch setup
+    assert st["mfma"] == 72 and st["instructions"] < 1900, st
     full = g.ItemGen().program()
     if os.path.exists("/opt/rocm/lib/llvm/bin/clang"):
         assert g.assemble_check(full)
