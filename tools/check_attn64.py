@@ -292,6 +292,56 @@ def phases(workload):
               f"rho_q {ph[1]:6.0f} loop {ph[2]:6.0f} epi {ph[3]:6.0f} total {ph[4]:6.0f}", flush=True)
 
 
+def ramp(workload):
+    """where the launch's time outside its items goes: workgroup begin -> first item start, item durations by position in the
+    workgroup's walk, the spread of the workgroups' ends, and what the dispatch's own events add around all of it"""
+    import ctypes
+    import bench
+    H, Nq, Pq, Nk, Pk, f_dims, so2, so3, B = bench.WORKLOADS[workload]
+    _, dev = build(B, H, Nq, Pq, Nk, Pk, torch.bfloat16, layout=(f_dims, so2, so3))
+    fn_fill, _, _, ws = run(dev, 0)
+    fn_fill()
+    torch.cuda.synchronize()
+    fn = run(dev, native.FLAG_KV_READY, ws=ws)[0]
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 100
+    n_items = B * H * ((Nq * Pq + 255) // 256)
+    for rep in range(2):
+        prof = torch.zeros(n_items, 8, dtype=torch.int64, device="cuda")
+        native.lib().gta_debug_profile_next_attention_kernel(ctypes.c_void_p(prof.data_ptr()), prof.shape[0])
+        torch.cuda.synchronize()
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us1 = e0.elapsed_time(e1) * 1000
+        P = prof.cpu().double()
+        G = int((P[:, 2] > 0).sum().item())                 # workgroups (rows of first items carry the begin stamp)
+        k = torch.arange(n_items) // G
+        rt0 = P[:G, 2].min()
+        begin = (P[:G, 2] - rt0) / 100.0                     # us
+        first = (P[:G, 5] - rt0) / 100.0
+        end_wg = torch.stack([P[(torch.arange(n_items) % G) == g, 6].max() for g in range(G)])
+        end = (end_wg - rt0) / 100.0
+        ghz = ((P[:, 4] - P[:, 0]) / (P[:, 6] - P[:, 5])).mean().item() * 0.1
+        cyc_first = (P[:G, 0] - P[:G, 1])
+        print(f"{workload} run {rep}: back-to-back {us:6.1f} us per launch, this (profiled, alone) {us1:6.1f} us | {G} workgroups, {n_items} items, {ghz:.3f} GHz")
+        print(f"  workgroup begin     : {begin.min():6.2f} .. {begin.max():6.2f} us (median {begin.median():.2f})")
+        print(f"  first item starts   : {first.min():6.2f} .. {first.max():6.2f} us (median {first.median():.2f}); begin -> first item {cyc_first.median():.0f} cycles median, {cyc_first.max():.0f} max")
+        print(f"  workgroup ends      : {end.min():6.2f} .. {end.max():6.2f} us (median {end.median():.2f})")
+        for kk in range(int(k.max().item()) + 1):
+            d = (P[k == kk, 4] - P[k == kk, 0])
+            print(f"  item {kk} of the walk  : {d.median():7.0f} cycles median ({d.min():.0f} .. {d.max():.0f})")
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     ok = True
@@ -314,6 +364,8 @@ if __name__ == "__main__":
     if which == "phases":
         for w in (sys.argv[2] if len(sys.argv) > 2 else "dit,ms-dec").split(","):
             phases(w)
+    if which == "ramp":
+        ramp(sys.argv[2] if len(sys.argv) > 2 else "ms-enc")
     if which == "variants":
         variants((sys.argv[2] if len(sys.argv) > 2 else "0,2,3,4,5,6,7,8").split(","))
     print("ALL OK" if ok else "FAILURES")

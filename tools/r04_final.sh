@@ -9,3 +9,5 @@ bash tools/workloads_r04.sh > $OUT/workloads.log 2>&1; tail -8 $OUT/workloads.lo
 bash tools/prof_bwd.sh > $OUT/prof_bwd.log 2>&1; tail -8 $OUT/prof_bwd.log
 cat gpurun_out/prof_r04/step_gaps.txt
 tail -c 1500 gpurun_out/prof_r04/bench_line.json
+python tools/check_attn64.py ramp ms-enc > $OUT/ramp.txt 2>&1; grep -v amdgpu.ids $OUT/ramp.txt | tail -20
+GTA_HIP_LIB=$R/gta_amd/csrc/libgta_hip_diag.so GTA_ATTN64_VARIANT=5 timeout 200 python tools/check_attn64.py phases ms-enc 2>&1 | grep "attn64" | tee $OUT/phases_items.txt
