@@ -16,7 +16,7 @@
 //
 // Kernels (all tiles are the same rotation-swizzled bf16 "tile images" the forward streams):
 //   gta_bwd_prep_kernel  per 64-query tile: raw q, do, o -> LDS (LDS-DMA); rho on q (prescaled by
-//                        c1*log2e) and on do; writes Q''/dO~ images + [lse*log2e | D] per row
+//                        c1*log2e) and on do; writes Q''/dO~ images + [-lse*log2e | -D] per row
 //   gta_bwd_dq_kernel    128 query rows / workgroup, loops over K'/V' images (forward workspace):
 //                        S^T, dP^T = V' dO~^T, dS^T, dQ'^T += K'^T dS^T (K'^T by transpose-read);
 //                        epilogue applies A_q^T per chunk and stores dq
@@ -43,6 +43,13 @@ GTA_DEV u32x2_t lds_tr16_b64(uint32_t addr) {
     u32x2_t v;
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(IMM));
     return v;
+}
+// transpose-read at register address + constant: the constant rides in the instruction's 16-bit offset field; beyond it, in a second
+// address register 32 KiB further on (loop-invariant: the compiler keeps it)
+template <int OFF>
+GTA_DEV u32x2_t lds_tr16_at(uint32_t addr) {
+    if constexpr (OFF < 65536) return lds_tr16_b64<OFF>(addr);
+    else return lds_tr16_b64<OFF - 32768>(addr + 32768u);
 }
 GTA_DEV uint32_t lds_addr(const void* p) {
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
@@ -314,12 +321,13 @@ __global__ __launch_bounds__(256) void gta_bwd_prep_kernel(const GtaBwdParams p)
             *reinterpret_cast<u32x4_t*>(gimg + piece * 1024 + lane * 16) = *reinterpret_cast<const u32x4_t*>(src);
         }
     }
-    // per-row statistics: [lse * log2e | D]; rows past Tq get lse = +big so that P == 0 there
+    // per-row statistics, NEGATED: [-lse * log2e | -D] -- the dQ and dK/dV kernels start their S and dP accumulators from them (the
+    // MFMA's C operand), so S - lse and dP - D cost no instruction; rows past Tq get -lse = -big so that P == 0 there
     float* st = p.stats + tile * 128;
     if (tid < 64) {
         const int tt = j * BN + tid;
-        st[tid] = tt < p.Tq ? p.lse[((long)b * p.H + h) * p.Tq + tt] * LOG2E : 1e30f;
-        st[64 + tid] = tt < p.Tq ? (dsum[tid] + dsum[64 + tid]) + (dsum[128 + tid] + dsum[192 + tid]) : 0.f;
+        st[tid] = tt < p.Tq ? -(p.lse[((long)b * p.H + h) * p.Tq + tt] * LOG2E) : -1e30f;
+        st[64 + tid] = tt < p.Tq ? -((dsum[tid] + dsum[64 + tid]) + (dsum[128 + tid] + dsum[192 + tid])) : 0.f;
     }
     if (tid == 0) p.dc_partial[p.dc_off_prep + tile] = dc_wg;
 }
@@ -349,7 +357,8 @@ GTA_DEV void dma_linear4(char* dst, const char* src, int wave, int lane) {     /
 }
 
 template <int DHP, int ESZ>
-__global__ __launch_bounds__(256, 2) void gta_bwd_dq_kernel(const GtaBwdParams p) {
+// (dh = 128: the 96-KiB ring admits one workgroup per CU anyway -- no reason to hold the kernel to 256 registers)
+__global__ __launch_bounds__(256, (DHP > 96 ? 1 : 2)) void gta_bwd_dq_kernel(const GtaBwdParams p) {
     using S = DqSmem<DHP>;
     constexpr int CHP = S::CHP, KS = DHP / 16, DB = DHP / 32, BM = 128;
     constexpr int DMA_PER_WAVE = S::STAGE / 1024 / 4;
@@ -391,11 +400,11 @@ __global__ __launch_bounds__(256, 2) void gta_bwd_dq_kernel(const GtaBwdParams p
     // per-row statistics of my query row
     const int my_row = wave * 32 + l31;                 // 0..127 in the workgroup
     const int my_tile = my_row >> 6;
-    float lse2 = 1e30f, Drow = 0.f;
+    float lse2n = -1e30f, Dn = 0.f;                      // (-lse * log2e, -D: gta_bwd_prep_kernel)
     if (my_tile < n_my_qt) {
         const float* st = p.stats + (qtile0 + my_tile) * 128;
-        lse2 = st[my_row & 63];
-        Drow = st[64 + (my_row & 63)];
+        lse2n = st[my_row & 63];
+        Dn = st[64 + (my_row & 63)];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -444,17 +453,21 @@ __global__ __launch_bounds__(256, 2) void gta_bwd_dq_kernel(const GtaBwdParams p
         }
     }
 
-    for (int j = 0; j < n_tiles; ++j) {
+    // one key tile.  ST >= 0: the ring stage as a constant (the tile loop is unrolled by NSTAGE, so the fragment reads' stage offsets are
+    // immediates instead of per-tile address arithmetic); ST < 0: taken from j.  TAIL: the variant that may hold the masked last tile
+    auto tile_step = [&](int j, auto STC, auto TAILC) __attribute__((always_inline)) {
+        constexpr int ST = decltype(STC)::value;
+        constexpr bool TAIL = decltype(TAILC)::value;
         if (j + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
         else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (j + 2 < n_tiles) dma_linear4<S::STAGE>(ring + ((j + 2) % NSTAGE) * S::STAGE, kvimg + (long)(j + 2) * S::STAGE, wave, lane);
-        const char* kf = ring + (j % NSTAGE) * S::STAGE;
+        if (j + 2 < n_tiles) dma_linear4<S::STAGE>(ring + (ST < 0 ? (j + 2) % NSTAGE : (ST + 2) % NSTAGE) * S::STAGE, kvimg + (long)(j + 2) * S::STAGE, wave, lane);
+        const char* kf = ring + (ST < 0 ? j % NSTAGE : ST) * S::STAGE;
         const char* vf = kf + S::IMG;
 
         f32x16_t s0, s1, e0, e1;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; e0[i] = 0.f; e1[i] = 0.f; }
+        for (int i = 0; i < 16; ++i) { s0[i] = lse2n; s1[i] = lse2n; e0[i] = Dn; e1[i] = Dn; }      // accumulators start at -lse2, -D
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(kf + koff[ks]);
@@ -480,18 +493,18 @@ __global__ __launch_bounds__(256, 2) void gta_bwd_dq_kernel(const GtaBwdParams p
         };
         tr_reads(0, 0);
         // P = exp2(S - lse2);  dS = P (dP - D);  keys past Tk contribute nothing
-        const bool tail = (j == n_tiles - 1) && (p.Tk & (BN - 1));
+        const bool tail = TAIL && (j == n_tiles - 1) && (p.Tk & (BN - 1));
         const int kbase = j * BN + 4 * lh;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float p0 = __builtin_amdgcn_exp2f(s0[r] - lse2), p1 = __builtin_amdgcn_exp2f(s1[r] - lse2);
+            float p0 = __builtin_amdgcn_exp2f(s0[r]), p1 = __builtin_amdgcn_exp2f(s1[r]);
             if (tail) {
                 const int key = kbase + (r & 3) + 8 * (r >> 2);
                 if (key >= p.Tk) p0 = 0.f;
                 if (key + 32 >= p.Tk) p1 = 0.f;
             }
-            s0[r] = p0 * (e0[r] - Drow);
-            s1[r] = p1 * (e1[r] - Drow);
+            s0[r] = p0 * e0[r];
+            s1[r] = p1 * e1[r];
         }
         bf16x8_t dsf[2][2];
         dsf[0][0] = __builtin_bit_cast(bf16x8_t, pack_acc8(s0, 0)); dsf[0][1] = __builtin_bit_cast(bf16x8_t, pack_acc8(s0, 1));
@@ -513,6 +526,16 @@ __global__ __launch_bounds__(256, 2) void gta_bwd_dq_kernel(const GtaBwdParams p
             }
             __builtin_amdgcn_sched_barrier(0);
         });
+        };
+    {
+        int j = 0;
+        for (; j + NSTAGE < n_tiles; j += NSTAGE) {          // (never the last tile)
+            tile_step(j, std::integral_constant<int, 0>{}, std::false_type{});
+            tile_step(j + 1, std::integral_constant<int, 1>{}, std::false_type{});
+            tile_step(j + 2, std::integral_constant<int, 2>{}, std::false_type{});
+        }
+#pragma unroll 1
+        for (; j < n_tiles; ++j) tile_step(j, std::integral_constant<int, -1>{}, std::true_type{});
     }
 
     // ---- epilogue: dq = A_q^T (c1 dQ') ; d trans_coeff through A_q ----
@@ -593,8 +616,8 @@ struct DkvSmem {
     // ring stages 1..2, so the kernel needs just the ring and two workgroups share a CU
     static constexpr int OFF_RING = 0;
     static constexpr int OFF_KV = STAGE;
-    static constexpr int OFF_STATS = OFF_RING + RING;      // [2][128] floats
-    static constexpr int OFF_SCR = OFF_STATS + 2 * 128 * 4;
+    static constexpr int OFF_STATS = OFF_RING + RING;      // [NSTAGE][128] floats: tile j's statistics in slot j % NSTAGE, like its images
+    static constexpr int OFF_SCR = OFF_STATS + NSTAGE * 128 * 4;
     static constexpr int OFF_REC = OFF_SCR + 32;
     static constexpr int OROW = DHP + 4;
     static constexpr int OST = 128 * OROW * 4;             // staging of dK' (then dV'): 128 keys
@@ -694,8 +717,14 @@ __global__ __launch_bounds__(256, (DHP > 96 ? 1 : 2)) void gta_bwd_dkv_kernel(co
             voff[d][hf] = (r * CHP + swz<CHP>(r, u)) * 16 + (p16 & 1) * 8;
         }
     }
+    uint32_t vaddr[DB][2];                               // ... as LDS addresses of the ring's stage 0, Q'' image, row block 0
+#pragma unroll
+    for (int d = 0; d < DB; ++d) { vaddr[d][0] = lds_addr(ring) + voff[d][0]; vaddr[d][1] = lds_addr(ring) + voff[d][1]; }
 
-    for (int j = 0; j < n_qt; ++j) {
+    // one query tile.  ST >= 0: the ring stage as a constant (the tile loop is unrolled by NSTAGE: the fragment reads' stage offsets
+    // are immediates instead of per-tile address arithmetic); ST < 0: taken from j
+    auto tile_step = [&](int j, auto STC) __attribute__((always_inline)) {
+        constexpr int ST = decltype(STC)::value;
         // statistics of tile j+1: fetched now, written to LDS at the end of this iteration
         // (every thread issues exactly one load so the counted vmcnt below is wave-uniform)
         float st_next = 0.f;
@@ -706,56 +735,61 @@ __global__ __launch_bounds__(256, (DHP > 96 ? 1 : 2)) void gta_bwd_dkv_kernel(co
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-        if (j + 2 < n_qt) dma_linear4<S::STAGE>(ring + ((j + 2) % NSTAGE) * S::STAGE, qimg + (long)(j + 2) * S::STAGE, wave, lane);
-        const char* qi = ring + (j % NSTAGE) * S::STAGE;       // Q'' image
+        if (j + 2 < n_qt) dma_linear4<S::STAGE>(ring + (ST < 0 ? (j + 2) % NSTAGE : (ST + 2) % NSTAGE) * S::STAGE, qimg + (long)(j + 2) * S::STAGE, wave, lane);
+        const char* qi = ring + (ST < 0 ? j % NSTAGE : ST) * S::STAGE;       // Q'' image
         const char* di = qi + S::IMG;                           // dO~ image
-        const float* stj = stats + (j & 1) * 128;
+        const float* stj = stats + (ST < 0 ? j % NSTAGE : ST) * 128;
         constexpr int SL = 16 * CHP * 16;
 
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {                        // 32 query rows at a time
+        static_for_bwd<2>([&](auto QBC) {                       // 32 query rows at a time
+            constexpr int qb = decltype(QBC)::value;
+            // register r <-> query row 32qb + 8(r>>2) + 4lh + (r&3): the accumulators start at the rows' -lse2 and -D (float4 groups
+            // of the statistics, the MFMA's C operand), so S - lse2 and dP - D cost no instruction
             f32x16_t s, e;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { s[i] = 0.f; e[i] = 0.f; }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(qi + koff[ks] + qb * 32 * CHP * 16);
-                const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(di + koff[ks] + qb * 32 * CHP * 16);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, kfr[ks], s, 0, 0, 0);    // S  = Q'' K'^T
-                e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, vfr[ks], e, 0, 0, 0);    // dP = dO~ V'^T
-            }
-            // register r <-> query row 32qb + 8(r>>2) + 4lh + (r&3): statistics come as float4 groups
-            f32x16_t ds;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(stj + 32 * qb + 8 * g + 4 * lh);
                 const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(stj + 64 + 32 * qb + 8 * g + 4 * lh);
-                const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+                s[4 * g] = l4.x; s[4 * g + 1] = l4.y; s[4 * g + 2] = l4.z; s[4 * g + 3] = l4.w;
+                e[4 * g] = d4.x; e[4 * g + 1] = d4.y; e[4 * g + 2] = d4.z; e[4 * g + 3] = d4.w;
+            }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float pv = __builtin_amdgcn_exp2f(s[4 * g + i] - ll[i]);
-                    s[4 * g + i] = pv;
-                    ds[4 * g + i] = pv * (e[4 * g + i] - dd[i]);
-                }
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(qi + koff[ks] + qb * 32 * CHP * 16);
+                const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(di + koff[ks] + qb * 32 * CHP * 16);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, kfr[ks], s, 0, 0, 0);    // S - lse2  = Q'' K'^T - lse2
+                e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, vfr[ks], e, 0, 0, 0);    // dP - D    = dO~ V'^T - D
+            }
+            f32x16_t ds;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float pv = __builtin_amdgcn_exp2f(s[i]);
+                s[i] = pv;
+                ds[i] = pv * e[i];
             }
             bf16x8_t pf[2], dsf[2];
             pf[0] = __builtin_bit_cast(bf16x8_t, pack_acc8(s, 0));   pf[1] = __builtin_bit_cast(bf16x8_t, pack_acc8(s, 1));
             dsf[0] = __builtin_bit_cast(bf16x8_t, pack_acc8(ds, 0)); dsf[1] = __builtin_bit_cast(bf16x8_t, pack_acc8(ds, 1));
             // dV'^T += dO~^T P ; dK'^T += Q''^T dS   (A operands by transpose-read of the row-major images)
-            const uint32_t qb_l = lds_addr(qi) + qb * 32 * CHP * 16, db_l = lds_addr(di) + qb * 32 * CHP * 16;
-            // the transpose-reads of channel block d + 1 are requested before the MFMAs of block d (two register sets)
+            // the transpose-reads of channel block d + 1 are requested before the MFMAs of block d (two register sets).  Addresses: the
+            // lane's offset (+ the ring's LDS base) in ONE register per (d, half) for the whole loop; stage, image and row-block offsets
+            // are immediates where the stage is a constant (one address register per (stage, image, block, d, half) spilled otherwise)
+            constexpr int QOFF = (ST < 0 ? 0 : ST * S::STAGE) + qb * 32 * CHP * 16, DOFF = QOFF + S::IMG;
+            const uint32_t rt = ST < 0 ? (uint32_t)((j % NSTAGE) * S::STAGE) : 0u;
             u32x2_t qlo[2][2], qhi[2][2], dlo[2][2], dhi[2][2];
-            auto tr_reads = [&](int d, int set) {
-                qlo[set][0] = lds_tr16_b64<0>(qb_l + voff[d][0]);  qhi[set][0] = lds_tr16_b64<0>(qb_l + voff[d][1]);
-                qlo[set][1] = lds_tr16_b64<SL>(qb_l + voff[d][0]); qhi[set][1] = lds_tr16_b64<SL>(qb_l + voff[d][1]);
-                dlo[set][0] = lds_tr16_b64<0>(db_l + voff[d][0]);  dhi[set][0] = lds_tr16_b64<0>(db_l + voff[d][1]);
-                dlo[set][1] = lds_tr16_b64<SL>(db_l + voff[d][0]); dhi[set][1] = lds_tr16_b64<SL>(db_l + voff[d][1]);
+            auto tr_reads = [&](auto DC2, int set) {
+                constexpr int d2 = decltype(DC2)::value;
+                const uint32_t a0 = vaddr[d2][0] + rt, a1 = vaddr[d2][1] + rt;
+                qlo[set][0] = lds_tr16_at<QOFF>(a0);      qhi[set][0] = lds_tr16_at<QOFF>(a1);
+                qlo[set][1] = lds_tr16_at<QOFF + SL>(a0); qhi[set][1] = lds_tr16_at<QOFF + SL>(a1);
+                dlo[set][0] = lds_tr16_at<DOFF>(a0);      dhi[set][0] = lds_tr16_at<DOFF>(a1);
+                dlo[set][1] = lds_tr16_at<DOFF + SL>(a0); dhi[set][1] = lds_tr16_at<DOFF + SL>(a1);
             };
-            tr_reads(0, 0);
+            tr_reads(std::integral_constant<int, 0>{}, 0);
             static_for_bwd<DB>([&](auto DC) {
                 constexpr int d = decltype(DC)::value, set = d & 1;
                 if constexpr (d + 1 < DB) {
-                    tr_reads(d + 1, set ^ 1);
+                    tr_reads(std::integral_constant<int, d + 1>{}, set ^ 1);
                     asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
                 } else {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -770,8 +804,18 @@ __global__ __launch_bounds__(256, (DHP > 96 ? 1 : 2)) void gta_bwd_dkv_kernel(co
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
+        });
+        if (j + 1 < n_qt && tid < 128) stats[(ST < 0 ? (j + 1) % NSTAGE : (ST + 1) % NSTAGE) * 128 + tid] = st_next;
+        };
+    {
+        int j = 0;
+        for (; j + NSTAGE <= n_qt; j += NSTAGE) {
+            tile_step(j, std::integral_constant<int, 0>{});
+            tile_step(j + 1, std::integral_constant<int, 1>{});
+            tile_step(j + 2, std::integral_constant<int, 2>{});
         }
-        if (j + 1 < n_qt && tid < 128) stats[((j + 1) & 1) * 128 + tid] = st_next;
+#pragma unroll 1
+        for (; j < n_qt; ++j) tile_step(j, std::integral_constant<int, -1>{});
     }
 
     // ---- epilogue: dk = B_k^T (ln2 dK'), dv = B_k^T dV' ; d trans_coeff through B_k ----
