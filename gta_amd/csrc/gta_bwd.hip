@@ -356,6 +356,13 @@ GTA_DEV void dma_linear4(char* dst, const char* src, int wave, int lane) {     /
     dma_linear_4waves<BYTES>(dst, src, wave, lane);      // scalar-base asm form (gta_common.h): no per-piece vector arithmetic
 }
 
+// the 512 bytes of a query tile's statistics by LDS-DMA: one dword per lane, waves 0 / 1 carry the halves, waves 2 / 3 repeat them (same
+// bytes to the same place: every wave issues the same number of vector-memory operations, which the counted waits rely on)
+GTA_DEV void dma_stats(float* dst, const float* src, int wave, int lane) {
+    const uint32_t lds = lds_addr(dst + 64 * (wave & 1));
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(lds), "v"((unsigned)lane * 4u), "s"(src + 64 * (wave & 1)) : "memory");
+}
+
 template <int DHP, int ESZ>
 // (dh = 128: the 96-KiB ring admits one workgroup per CU anyway -- no reason to hold the kernel to 256 registers)
 __global__ __launch_bounds__(256, (DHP > 96 ? 1 : 2)) void gta_bwd_dq_kernel(const GtaBwdParams p) {
@@ -661,13 +668,13 @@ __global__ __launch_bounds__(256, (DHP > 96 ? 1 : 2)) void gta_bwd_dkv_kernel(co
     dma_linear4<S::STAGE>(smem + S::OFF_KV, (const char*)p.kvimg + ktile0 * S::STAGE, wave, lane);
     if (n_my_kt == 2) dma_linear4<S::STAGE>(smem + S::OFF_KV + S::STAGE, (const char*)p.kvimg + (ktile0 + 1) * S::STAGE, wave, lane);
     dma_linear4<S::STAGE>(ring, qimg, wave, lane);
+    dma_stats(stats, gstats, wave, lane);
 
     const int t_last = (k0 + BK - 1 < p.Tk ? k0 + BK - 1 : p.Tk - 1);
     const int n_first = k0 / p.Pk;
     const int n_cnt = t_last / p.Pk - n_first + 1;
     const float tc = p.trans_coeff ? *p.trans_coeff : 1.0f;
     if (p.vrep_k) stage_brec(rec, p.vrep_k, (long)b * p.Nk + n_first, n_cnt, 1, tc, tid, 256);
-    if (tid < 128) stats[tid] = gstats[tid];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -695,7 +702,10 @@ __global__ __launch_bounds__(256, (DHP > 96 ? 1 : 2)) void gta_bwd_dkv_kernel(co
         }
     }
     __syncthreads();      // every wave holds its K'/V' fragments: ring stages 1..2 are free
-    if (n_qt > 1) dma_linear4<S::STAGE>(ring + S::STAGE, qimg + (long)S::STAGE, wave, lane);
+    if (n_qt > 1) {
+        dma_linear4<S::STAGE>(ring + S::STAGE, qimg + (long)S::STAGE, wave, lane);
+        dma_stats(stats + 128, gstats + 128, wave, lane);
+    }
 
     f32x16_t dk[DB], dv[DB];
 #pragma unroll
@@ -725,17 +735,19 @@ __global__ __launch_bounds__(256, (DHP > 96 ? 1 : 2)) void gta_bwd_dkv_kernel(co
     // are immediates instead of per-tile address arithmetic); ST < 0: taken from j
     auto tile_step = [&](int j, auto STC) __attribute__((always_inline)) {
         constexpr int ST = decltype(STC)::value;
-        // statistics of tile j+1: fetched now, written to LDS at the end of this iteration
-        // (every thread issues exactly one load so the counted vmcnt below is wave-uniform)
-        float st_next = 0.f;
-        if (j + 1 < n_qt) st_next = gstats[(long)(j + 1) * 128 + (tid & 127)];
+        // tile j's images and statistics have landed when only tile j + 1's (requested one tile ago) are in flight.  No compiler-visible
+        // load in the loop: one would be waited for with vmcnt(0) -- the compiler does not count the DMA -- and drain the request
+        // made two tiles ahead after one
         if (j + 1 < n_qt) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE + 1) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-        if (j + 2 < n_qt) dma_linear4<S::STAGE>(ring + (ST < 0 ? (j + 2) % NSTAGE : (ST + 2) % NSTAGE) * S::STAGE, qimg + (long)(j + 2) * S::STAGE, wave, lane);
+        if (j + 2 < n_qt) {
+            dma_linear4<S::STAGE>(ring + (ST < 0 ? (j + 2) % NSTAGE : (ST + 2) % NSTAGE) * S::STAGE, qimg + (long)(j + 2) * S::STAGE, wave, lane);
+            dma_stats(stats + (ST < 0 ? (j + 2) % NSTAGE : (ST + 2) % NSTAGE) * 128, gstats + (long)(j + 2) * 128, wave, lane);
+        }
         const char* qi = ring + (ST < 0 ? j % NSTAGE : ST) * S::STAGE;       // Q'' image
         const char* di = qi + S::IMG;                           // dO~ image
         const float* stj = stats + (ST < 0 ? j % NSTAGE : ST) * 128;
@@ -805,7 +817,6 @@ __global__ __launch_bounds__(256, (DHP > 96 ? 1 : 2)) void gta_bwd_dkv_kernel(co
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
-        if (j + 1 < n_qt && tid < 128) stats[(ST < 0 ? (j + 1) % NSTAGE : (ST + 1) % NSTAGE) * 128 + tid] = st_next;
         };
     {
         int j = 0;
