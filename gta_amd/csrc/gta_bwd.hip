@@ -356,6 +356,16 @@ GTA_DEV void dma_linear4(char* dst, const char* src, int wave, int lane) {     /
     dma_linear_4waves<BYTES>(dst, src, wave, lane);      // scalar-base asm form (gta_common.h): no per-piece vector arithmetic
 }
 
+// one LDS-DMA operation with per-lane source offsets: LDS bytes [dst, dst + 64 N) <- N bytes at base + voff(lane) + IMM per lane (the
+// instruction's immediate moves the LDS address too: M0 = dst - IMM)
+template <int IMM>
+GTA_DEV void dma_lanes_dword(uint32_t dst, uint32_t voff, const void* base) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 offset:%3" ::"s"(dst - (uint32_t)IMM), "v"(voff), "s"(base), "n"(IMM) : "memory");
+}
+template <int IMM>
+GTA_DEV void dma_lanes_x4(uint32_t dst, uint32_t voff, const void* base) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3" ::"s"(dst - (uint32_t)IMM), "v"(voff), "s"(base), "n"(IMM) : "memory");
+}
 // the 512 bytes of a query tile's statistics by LDS-DMA: one dword per lane, waves 0 / 1 carry the halves, waves 2 / 3 repeat them (same
 // bytes to the same place: every wave issues the same number of vector-memory operations, which the counted waits rely on)
 GTA_DEV void dma_stats(float* dst, const float* src, int wave, int lane) {
@@ -893,6 +903,203 @@ __global__ __launch_bounds__(256, (DHP > 96 ? 1 : 2)) void gta_bwd_dkv_kernel(co
     if (tid == 0) p.dc_partial[p.dc_off_dkv + w] = dc_wg;
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3b. dK, dV with 64 keys per wave, one wave per SIMD, the tile loop as ONE generated instruction stream (gen_bwd64.py ->
+// gta_bwd64_dkv.inc; r04).  A workgroup owns 256 keys of one (b, h); its four waves keep the K' / V' fragments of 64 keys and the
+// dK'^T / dV'^T accumulators in registers (all 256 AGPRs + 232 VGPRs are the stream's) and walk the (b, h)'s Q'' / dO~ tile images
+// through a ring of four LDS stages.  Every streamed fragment feeds the wave's two 32-key blocks -- half the LDS bytes per MFMA of
+// gta_bwd_dkv_kernel -- and each block's softmax runs in the gaps of the MFMAs of the two neighbouring segments (the generator's
+// header has the schedule).  The compiler's part: operands (lane offsets of the image layout), the view records, and the epilogue
+// (B_k^T per chunk, stores, d trans_coeff) on the accumulators the stream leaves in a[0:191].  bf16 images, dh = 96.
+// ------------------------------------------------------------------------------------------------
+#include "gta_bwd64_dkv.inc"
+struct Dkv64Smem {
+    static constexpr int STAGE = 2 * BN * 96 * 2;
+    static constexpr int RING = GTA_BWD64_STAGES * STAGE;
+    static constexpr int OFF_STATS = RING;
+    // what the epilogue reads per key besides the accumulators, per wave: 24 x 64 dwords the stream leaves at its end (elements 3 and 7 of the
+    // se3 chunks of its keys' K' / V' fragments = of the raw rows: d trans_coeff) and the six 16-byte pieces of the keys' 96-byte (cos, sin)
+    // rows, fetched by LDS-DMA before the walk (their latency lies under it)
+    static constexpr int OFF_SIDE = OFF_STATS + GTA_BWD64_STAGES * 512;
+    static constexpr int SIDE_RAW = 24 * 256, SIDE_W = SIDE_RAW + 6 * 1024;
+    static constexpr int OFF_SCR = OFF_SIDE + 4 * SIDE_W;
+    static constexpr int OFF_REC = OFF_SCR + 32;
+    static_assert(OFF_STATS == GTA_BWD64_OFF_STATS && GTA_BWD64_HI_BASE == 2 * STAGE, "gen_bwd64.py's LDS map");
+    static int total(int nviews) { return OFF_REC + nviews * BREC * 4; }
+};
+
+template <int ESZ>
+__global__ __launch_bounds__(256, 1) void gta_bwd_dkv64_kernel(const GtaBwdParams p) {
+    using S = Dkv64Smem;
+    constexpr int CHP = 12, DB = 3, KB = 2, BK = 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    int w;
+    {
+        const int nwg = gridDim.x, L = blockIdx.x;
+        const int xcd = L & 7, idx = L >> 3, q8 = nwg >> 3, r8 = nwg & 7;
+        w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int n_kblk = (p.Tk + BK - 1) / BK;
+    const int bh = w / n_kblk, kt = w - bh * n_kblk;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int k0 = kt * BK;
+    const int n_kt64 = (p.Tk + BN - 1) / BN;
+    const int n_qt = (p.Tq + BN - 1) / BN;
+    char* ring = smem;
+    float* rec = reinterpret_cast<float*>(smem + S::OFF_REC);
+
+    const int t_last = (k0 + BK - 1 < p.Tk ? k0 + BK - 1 : p.Tk - 1);
+    const int n_first = k0 / p.Pk;
+    const int n_cnt = t_last / p.Pk - n_first + 1;
+    const float tc = p.trans_coeff ? *p.trans_coeff : 1.0f;
+    if (p.vrep_k) stage_brec(rec, p.vrep_k, (long)b * p.Nk + n_first, n_cnt, 1, tc, tid, 256);
+
+    {
+        // operands of the stream: the lane's offsets in a tile image (rows of 12 rotation-swizzled 16-byte units) as LDS addresses of ring
+        // stage 0 (and of stage 2: immediates stay inside the 16-bit field); fragment rows: lane (row l31, unit 2 ks + lh) -- linear in ks
+        // up to ks = 3, the rotation wraps for ks = 4, 5; transpose-reads: 4-row groups, linear over channel blocks 0, 1
+        const uint32_t rb = lds_addr(ring);
+        auto koff_of = [&](int ks) { return (uint32_t)((l31 * CHP + swz<CHP>(l31, 2 * ks + lh)) * 16) + rb; };
+        const int g16 = lane >> 4, p16 = lane & 15;
+        auto voff_of = [&](int d, int hf) {
+            const int r = 4 * lh + (p16 >> 2) + 8 * hf, u = 4 * d + 2 * (g16 & 1) + ((p16 & 3) >> 1);
+            return (uint32_t)((r * CHP + swz<CHP>(r, u)) * 16 + (p16 & 1) * 8) + rb;
+        };
+        const uint32_t koffl = koff_of(0), koff4 = koff_of(4), koff5 = koff_of(5);
+        const uint32_t voff00 = voff_of(0, 0), voff01 = voff_of(0, 1), voff20 = voff_of(2, 0), voff21 = voff_of(2, 1);
+        constexpr uint32_t HB = GTA_BWD64_HI_BASE;
+        const uint32_t koffl_h = koffl + HB, koff4_h = koff4 + HB, koff5_h = koff5 + HB;
+        const uint32_t voff00_h = voff00 + HB, voff01_h = voff01 + HB, voff20_h = voff20 + HB, voff21_h = voff21 + HB;
+        const uint32_t lane16 = (uint32_t)lane * 16u, lane4 = (uint32_t)lane * 4u;
+        const uint32_t stoff = rb + (uint32_t)S::OFF_STATS + 16u * (uint32_t)lh;
+        const char* qimg = (const char*)p.qimg + ((long)b * p.H + h) * n_qt * (long)S::STAGE;
+        const float* gstats = p.stats + ((long)b * p.H + h) * n_qt * 128;
+        // this wave's 64 keys = 64-key tile 4 kt + wave (a tile past the end: the last one's images again -- nothing of it is stored)
+        int my_tile = 4 * kt + wave;
+        my_tile = my_tile < n_kt64 ? my_tile : n_kt64 - 1;
+        const char* kv = (const char*)p.kvimg + (((long)b * p.H + h) * n_kt64 + my_tile) * (long)S::STAGE;
+        const uint32_t q_lo = (uint32_t)(uintptr_t)qimg, q_hi = (uint32_t)((uintptr_t)qimg >> 32);
+        const uint32_t st_lo = (uint32_t)(uintptr_t)gstats, st_hi = (uint32_t)((uintptr_t)gstats >> 32);
+        const uint32_t kv_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)kv), kv_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)kv >> 32));
+        const uint32_t n = (uint32_t)n_qt, ring_s = __builtin_amdgcn_readfirstlane(rb), stats_s = ring_s + (uint32_t)S::OFF_STATS;
+        const uint32_t ring = ring_s, stats = stats_s;
+        const uint32_t side = ring_s + (uint32_t)(S::OFF_SIDE + wave * S::SIDE_W);
+        {
+            // the (cos, sin) rows of this wave's 64 keys -> its side buffer, six 16-byte pieces per key (lane <-> key k0 + 64 wave + lane; rows
+            // past Tk: the last row's): the epilogue reads them from LDS, their latency lies under the walk
+            int tk = k0 + 64 * wave + lane;
+            tk = tk < p.Tk ? tk : p.Tk - 1;
+            if (p.cs_k) {
+                const uint32_t cro = (uint32_t)(((long)b * p.Tk + tk) * 2 * p.nso2 * 4 - (long)b * p.Tk * 2 * p.nso2 * 4);
+                const float* csb = p.cs_k + (long)b * p.Tk * 2 * p.nso2;
+                static_for_bwd<6>([&](auto PC) {
+                    constexpr int pc = decltype(PC)::value;
+                    dma_lanes_x4<pc * 16>(side + (uint32_t)(S::SIDE_RAW + pc * 1024), cro, csb);
+                });
+            }
+        }
+        asm volatile(GTA_BWD64_DKV : : GTA_BWD64_OPERANDS : GTA_BWD64_CLOBBERS);
+    }
+    // the accumulators: dK'^T[kb][d] = a[16 (3 kb + d) ..], dV'^T[kb][d] = a[96 + 16 (3 kb + d) ..]
+    f32x16_t dk[KB][DB], dv[KB][DB];
+#define GTA_ACC16(DST, BASE) asm volatile( \
+        "v_accvgpr_read_b32 %0, a[" #BASE "+0]\n\tv_accvgpr_read_b32 %1, a[" #BASE "+1]\n\tv_accvgpr_read_b32 %2, a[" #BASE "+2]\n\tv_accvgpr_read_b32 %3, a[" #BASE "+3]\n\t" \
+        "v_accvgpr_read_b32 %4, a[" #BASE "+4]\n\tv_accvgpr_read_b32 %5, a[" #BASE "+5]\n\tv_accvgpr_read_b32 %6, a[" #BASE "+6]\n\tv_accvgpr_read_b32 %7, a[" #BASE "+7]\n\t" \
+        "v_accvgpr_read_b32 %8, a[" #BASE "+8]\n\tv_accvgpr_read_b32 %9, a[" #BASE "+9]\n\tv_accvgpr_read_b32 %10, a[" #BASE "+10]\n\tv_accvgpr_read_b32 %11, a[" #BASE "+11]\n\t" \
+        "v_accvgpr_read_b32 %12, a[" #BASE "+12]\n\tv_accvgpr_read_b32 %13, a[" #BASE "+13]\n\tv_accvgpr_read_b32 %14, a[" #BASE "+14]\n\tv_accvgpr_read_b32 %15, a[" #BASE "+15]" \
+        : "=v"(DST[0]), "=v"(DST[1]), "=v"(DST[2]), "=v"(DST[3]), "=v"(DST[4]), "=v"(DST[5]), "=v"(DST[6]), "=v"(DST[7]), \
+          "=v"(DST[8]), "=v"(DST[9]), "=v"(DST[10]), "=v"(DST[11]), "=v"(DST[12]), "=v"(DST[13]), "=v"(DST[14]), "=v"(DST[15]))
+    {
+        float t[16];
+#define GTA_ACC(ARR, KBI, D, BASE) GTA_ACC16(t, BASE); _Pragma("unroll") for (int i = 0; i < 16; ++i) ARR[KBI][D][i] = t[i];
+        GTA_ACC(dk, 0, 0, 0) GTA_ACC(dk, 0, 1, 16) GTA_ACC(dk, 0, 2, 32) GTA_ACC(dk, 1, 0, 48) GTA_ACC(dk, 1, 1, 64) GTA_ACC(dk, 1, 2, 80)
+        GTA_ACC(dv, 0, 0, 96) GTA_ACC(dv, 0, 1, 112) GTA_ACC(dv, 0, 2, 128) GTA_ACC(dv, 1, 0, 144) GTA_ACC(dv, 1, 1, 160) GTA_ACC(dv, 1, 2, 176)
+#undef GTA_ACC
+#undef GTA_ACC16
+    }
+
+    // ---- epilogue: dk = B_k^T (ln2 dK'), dv = B_k^T dV' ; d trans_coeff through B_k.  No staging: lane (key l31, half lh) of a 32-key
+    // block holds channels 32 d + 8 g + 4 lh + i of ITS key, one v_permlane32_swap per value hands lanes 0-31 the whole even chunk of a
+    // pair (g, g + 1) and lanes 32-63 the odd one (as the forward's epilogue); every lane then transforms and stores whole 8-channel
+    // chunks of its key -- no LDS round trip, no barrier, every load of the 24 chunks in flight at once (one workgroup per CU: there is
+    // no second workgroup to hide a serial epilogue behind; with the staged form it was 28 % of the kernel) ----
+    const bool xv = (p.flags & GTA_FLAG_V_TRANSFORM) != 0;
+    char* dkg = (char*)p.dk + ((long)b * p.dk_sb + (long)h * p.dk_sh) * ESZ;
+    char* dvg = (char*)p.dv + ((long)b * p.dv_sb + (long)h * p.dv_sh) * ESZ;
+    float dcpart = 0.f;
+    __syncthreads();                                     // (the view records: written before the stream, whose barriers ordered them too)
+    const char* side = smem + S::OFF_SIDE + wave * S::SIDE_W;
+#pragma unroll
+    for (int pass = 0; pass < 2 * KB; ++pass) {          // (0: dK, 1: dV) x key block
+        const int which = pass >> 1, kb = pass & 1;
+        const float sc = which == 0 ? LN2 : 1.0f;
+        const bool xf = which == 0 || xv;
+        char* outg = which == 0 ? dkg : dvg;
+        const long out_st = (which == 0 ? p.dk_st : p.dv_st) * ESZ;
+        const int kl = 32 * kb + l31;                    // the lane's key of this pass, within the wave
+        const int t = k0 + 64 * wave + kl;
+        const bool valid = t < p.Tk;
+        const float* rc = rec + (view_of(valid ? t : p.Tk - 1, p.Pk, p.invPk) - n_first) * BREC;
+        // slot sl = the chunk pair (2 sl, 2 sl + 1) of the MSN layout: 0..2 se3 | se3, 3 so3 | so3, 4 so3 | so2, 5 so2 | so2; the low lane half
+        // takes the even chunk, the high half the odd one
+        static_for_bwd<2 * DB>([&](auto SC) {
+            constexpr int sl = decltype(SC)::value, d = sl >> 1, gp = sl & 1;
+            constexpr uint32_t DE = gta_layout_desc(GTA_LAYOUT_MS, 2 * sl), DO = gta_layout_desc(GTA_LAYOUT_MS, 2 * sl + 1);
+            const f32x16_t& acc = which == 0 ? dk[kb][d] : dv[kb][d];
+            float x[1][8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float fa = acc[8 * gp + i] * sc, fb = acc[8 * gp + 4 + i] * sc;       // half lh of the even / of the odd chunk
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(fa), __float_as_uint(fb), false, false);   // fa[32..63] <-> fb[0..31]
+                x[0][i] = __uint_as_float(sw[0]);
+                x[0][4 + i] = __uint_as_float(sw[1]);
+            }
+            const int c = 2 * sl + lh;
+            if (xf) {
+                if constexpr (sl < 3) {                  // se3 | se3: d trans_coeff through B_k (raw elements 3 and 7 of the chunk), then B_k^T
+                    // (raw elements 3 and 7 of the lane's chunk = those of its K' / V' fragment, left by the stream: gen_bwd64.py)
+                    const uint32_t w1 = *reinterpret_cast<const uint32_t*>(side + (((which * 2 + kb) * 3 + sl) * 2) * 256 + lane * 4);
+                    const uint32_t w3 = *reinterpret_cast<const uint32_t*>(side + (((which * 2 + kb) * 3 + sl) * 2 + 1) * 256 + lane * 4);
+                    const float r3 = ESZ == 2 ? bf16_hi(w1) : 0.f, r7 = ESZ == 2 ? bf16_hi(w3) : 0.f;
+                    const float t0 = rc[BREC_T], t1 = rc[BREC_T + 1], t2 = rc[BREC_T + 2];
+                    if (valid) {
+                        dcpart += (x[0][0] * t0 + x[0][1] * t1 + x[0][2] * t2) * r3;
+                        dcpart += (x[0][4] * t0 + x[0][5] * t1 + x[0][6] * t2) * r7;
+                    }
+                    chunk_apply<true, 1>(DE, rc + BREC_MT, rc + BREC_D1T, rc + BREC_D2T, nullptr, x);
+                } else if constexpr (sl == 3) {          // so3 | so3
+                    chunk_apply<true, 1>(DE, rc + BREC_MT, rc + BREC_D1T, rc + BREC_D2T, nullptr, x);
+                } else {                                 // so2 chunks 9 (sl 4, high half), 10, 11: pieces 2 (c - 9), 2 (c - 9) + 1 of the key's (cos, sin) row
+                    f32x2_t cs[4];
+                    const int pc = 2 * (c - 9);
+                    const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(side + S::SIDE_RAW + (pc < 0 ? 0 : pc) * 1024 + kl * 16);
+                    const f32x4_t c1 = *reinterpret_cast<const f32x4_t*>(side + S::SIDE_RAW + (pc < 0 ? 1 : pc + 1) * 1024 + kl * 16);
+                    cs[0] = f32x2_t{c0.x, c0.y}; cs[1] = f32x2_t{c0.z, c0.w}; cs[2] = f32x2_t{c1.x, c1.y}; cs[3] = f32x2_t{c1.z, c1.w};
+                    if constexpr (sl == 4) {
+                        if (lh == 0) chunk_apply<true, 1>(DE, rc + BREC_MT, rc + BREC_D1T, rc + BREC_D2T, cs, x);        // chunk 8: so3
+                        else chunk_apply<true, 1>(DO, rc + BREC_MT, rc + BREC_D1T, rc + BREC_D2T, cs, x);                 // chunk 9: so2
+                    } else {
+                        chunk_apply<true, 1>(DE, rc + BREC_MT, rc + BREC_D1T, rc + BREC_D2T, cs, x);                      // (the halves differ in cs only)
+                    }
+                }
+            }
+            if (valid) g_store_chunk<ESZ>(outg + (long)t * out_st, c, x[0]);
+        });
+    }
+    __syncthreads();
+    const float dc_wg = wg_sum256(dcpart, reinterpret_cast<float*>(smem + S::OFF_SCR), tid);
+    // the partials' slots are per 128 keys (gta_abi.cpp): this workgroup owns two of them
+    if (tid == 0) {
+        const int n_k128 = (p.Tk + 127) / 128;
+        p.dc_partial[p.dc_off_dkv + bh * n_k128 + 2 * kt] = dc_wg;
+        if (2 * kt + 1 < n_k128) p.dc_partial[p.dc_off_dkv + bh * n_k128 + 2 * kt + 1] = 0.f;
+    }
+}
+
 // deterministic two-level sum: 1024 threads each take a fixed strided subset, then a fixed tree
 __global__ __launch_bounds__(1024) void gta_reduce_kernel(const float* __restrict__ part, int n, float* __restrict__ out,
                                                           const float* __restrict__ neg_div) {
@@ -923,7 +1130,25 @@ int run_bwd(const GtaBwdParams& p, hipStream_t stream) {
     const int n_dq = p.B * p.H * ((p.Tq + 127) / 128);
     const int n_dkv = p.B * p.H * ((p.Tk + 127) / 128);
     hipLaunchKernelGGL((gta_bwd_dq_kernel<DHP, ESZ>), dim3(n_dq), dim3(256), DqSmem<DHP>::total(p.vrep_q ? p.Nq : 0), stream, p);
-    hipLaunchKernelGGL((gta_bwd_dkv_kernel<DHP, ESZ>), dim3(n_dkv), dim3(256), DkvSmem<DHP>::total(p.vrep_k ? p.Nk : 0), stream, p);
+    bool dkv64 = false;
+    if constexpr (DHP == 96 && ESZ == 2) {
+        // 64 keys per wave / 256 per workgroup (the generated stream) where that fills the chip at one workgroup per CU; otherwise the
+        // 128-key kernel's finer grain
+        const long n_dkv64 = (long)p.B * p.H * ((p.Tk + 255) / 256);
+        bool ms = p.dh == 96 && p.nso2 == 12 && Dkv64Smem::total(p.vrep_k ? p.Nk : 0) <= 160 * 1024 && (long)p.Tk * p.k_st * ESZ < (1L << 31) &&
+                  (long)p.Tk * p.v_st * ESZ < (1L << 31);          // (the kernel's epilogue is written for the MSN chunk layout)
+        for (int c = 0; c < 12; ++c) ms = ms && p.ctab[c] == gta_layout_desc(GTA_LAYOUT_MS, c);
+        dkv64 = ms && (n_dkv64 >= 2 * 256 || (p.flags & GTA_FLAG_BWD_KEYS64)) && !(p.flags & GTA_FLAG_BWD_KEYS32);
+#ifdef GTA_ATTN64_DIAG
+        if (const char* e = getenv("GTA_BWD_DKV64")) dkv64 = atoi(e) != 0;
+#endif
+        if (dkv64) {
+            if (int rc = gta_lds_optin<&gta_bwd_dkv64_kernel<ESZ>>(Dkv64Smem::total(GTA_MAX_VIEWS))) return rc;
+            hipLaunchKernelGGL((gta_bwd_dkv64_kernel<ESZ>), dim3((unsigned)n_dkv64), dim3(256), Dkv64Smem::total(p.vrep_k ? p.Nk : 0), stream, p);
+        }
+    }
+    if (!dkv64)
+        hipLaunchKernelGGL((gta_bwd_dkv_kernel<DHP, ESZ>), dim3(n_dkv), dim3(256), DkvSmem<DHP>::total(p.vrep_k ? p.Nk : 0), stream, p);
     if (p.dtrans_coeff)
         hipLaunchKernelGGL(gta_reduce_kernel, dim3(1), dim3(1024), 0, stream, p.dc_partial, p.dc_total, p.dtrans_coeff,
                            (const float*)nullptr);

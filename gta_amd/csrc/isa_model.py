@@ -217,6 +217,12 @@ class Asm:
         assert len(d) == n and 0 <= off < 65536
         self.add(f"ds_read_b{width} {rtext(d)}, {addr}" + (f" offset:{off}" if off else ""), "ds", [addr], list(d), ("ds_read", n, list(d), addr, off))
 
+    def ds_read_tr(self, d2, addr, off=0):
+        """ds_read_b64_tr_b16: within each group of 16 lanes, lane l receives element (l & 3) of the four 16-bit elements addressed by
+        lanes 4 j + (l >> 2), j = 0..3 (cdna_hip_programming.md, LDS: column l of the 4 x 16 block the group's addresses describe)"""
+        assert len(d2) == 2 and 0 <= off < 65536
+        self.add(f"ds_read_b64_tr_b16 {rtext(d2)}, {addr}" + (f" offset:{off}" if off else ""), "ds", [addr], list(d2), ("ds_read_tr", list(d2), addr, off))
+
     def ds_write(self, width, addr, s, off=0):
         n = {32: 1, 64: 2, 128: 4}[width]
         assert len(s) == n and 0 <= off < 65536
@@ -258,6 +264,9 @@ class Asm:
 
     def s_mul_i32(self, d, a, b):
         self._s(f"s_mul_i32 {d}, {otext(a)}, {otext(b)}", rdset(a, b), [d], ("s_mul_i32", d, a, b))
+
+    def s_and_b32(self, d, a, b):
+        self._s(f"s_and_b32 {d}, {otext(a)}, {otext(b)}", rdset(a, b), [d, "scc"], ("s_and_b32", d, a, b))
 
     def s_or_b32(self, d, a, b):
         self._s(f"s_or_b32 {d}, {otext(a)}, {otext(b)}", rdset(a, b), [d, "scc"], ("s_or_b32", d, a, b))
@@ -431,6 +440,9 @@ class Wave:
         if isinstance(x, str) and x[0] in "va" and is_reg(x):
             self.touch(x, ins, False)
             return self.v[self.ridx(x)].copy()
+        vin = getattr(self, "vector_inputs", None)
+        if vin is not None and isinstance(x, str) and x in vin:          # a named statement operand held in a VGPR
+            return np.asarray(vin[x], dtype=np.uint32).copy()
         return np.full(LANES, self.sval(x, ins), np.uint32)
 
     def setv(self, r, arr, ins, masked=True):
@@ -500,7 +512,14 @@ class Wave:
             if h is None:
                 raise CheckError(f"no hook for pseudo {fx[1]}")
             return h(self, *fx[2:])
-        if op in ("nop", "barrier"):
+        if op == "barrier":
+            h = getattr(self, "barrier_hook", None)
+            if h is not None:
+                if self.lgkm:
+                    raise CheckError("s_barrier with LDS operations outstanding (the streams wait for them first)")
+                h(self)
+            return None
+        if op == "nop":
             return None
         if op == "waitcnt":
             self.wait(fx[1], fx[2])
@@ -612,6 +631,25 @@ class Wave:
             self.lgkm.append(("ds", list(d)))
             for r in d:
                 self.poison[r] = f"LDS read ({ins.text})"
+        elif op == "ds_read_tr":
+            d2, addr, off = fx[1:]
+            a = self.val(addr, ins).astype(np.int64) + off
+            if (a % 8).any() or (a < 0).any() or (a + 8 > len(self.lds)).any():
+                raise CheckError(f"ds_read_b64_tr_b16 address   at: {ins.text}")
+            elems = np.zeros((LANES, 4), np.uint32)                    # what each lane's address points at: four 16-bit elements
+            for lane in range(LANES):
+                p = int(a[lane])
+                elems[lane] = np.frombuffer(self.lds[p:p + 8].tobytes(), np.uint16)
+            res = np.zeros((LANES, 4), np.uint32)
+            for lane in range(LANES):
+                g, l = lane & ~15, lane & 15
+                for j in range(4):
+                    res[lane, j] = elems[g + 4 * j + (l >> 2), l & 3]
+            self.setv(d2[0], res[:, 0] | (res[:, 1] << 16), ins)
+            self.setv(d2[1], res[:, 2] | (res[:, 3] << 16), ins)
+            self.lgkm.append(("ds", list(d2)))
+            for r in d2:
+                self.poison[r] = f"LDS read ({ins.text})"
         elif op == "ds_write":
             n, addr, src, off = fx[1:]
             a = self.val(addr, ins).astype(np.int64) + off
@@ -669,6 +707,28 @@ class Wave:
                 for lane in range(LANES):
                     self.lds[dst + 16 * lane:dst + 16 * lane + 16] = data[lane]
             self.vm.append({"apply": apply})
+        elif op == "global_load_lds_dword":
+            voff, sbase, off = fx[1:]
+            base = self.s64(sbase, ins)
+            vo = self.val(voff, ins).astype(np.int64)
+            data = []
+            for lane in range(LANES):
+                arr, o = self._g(base + int(vo[lane]) + off, 4)
+                data.append(arr[o:o + 4].copy())
+            dst = self.m0 + off
+            if dst % 4 or dst + 256 > len(self.lds):
+                raise CheckError(f"LDS-DMA destination {dst}   at: {ins.text}")
+
+            def apply4(dst=dst, data=data):
+                for lane in range(LANES):
+                    self.lds[dst + 4 * lane:dst + 4 * lane + 4] = data[lane]
+            self.vm.append({"apply": apply4})
+        elif op == "s_cselect_b32":
+            self.sets(fx[1], self.sval(fx[2], ins) if self.scc else self.sval(fx[3], ins), ins)
+        elif op == "s_min_u32":
+            a_, b_ = self.sval(fx[2], ins), self.sval(fx[3], ins)
+            self.sets(fx[1], min(a_, b_), ins)
+            self.scc = int(a_ <= b_)
         elif op == "s_add_m0":
             self.m0 = (self.sval(fx[1], ins) + fx[2]) & 0xffffffff
         elif op in ("s_or_b32", "s_and_b32"):
@@ -745,6 +805,12 @@ def check_wait_states(hist, cur):
                     need = 12                            # XDL (8 pass) write -> VALU / memory read or write of the result
                 elif set(prev.rd) & cwr:
                     need = 8                             # XDL reads its operands over its passes -> overwrite by a later instruction
+                    if cur.kind in ("ds", "vmem") and prev.fx is not None and prev.fx[0] == "mfma":
+                        # a LOAD's data arrives tens of cycles after it issues, and it issues after the MFMA has (in-order issue): only the C
+                        # operand, read late, keeps the margin
+                        c16 = prev.fx[4]
+                        if c16 == 0 or not (set(c16) & cwr):
+                            need = 0
             else:
                 ov = pwr & crd
                 if ov and not (pwr == cwr and ov == pwr):

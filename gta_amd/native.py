@@ -29,6 +29,8 @@ FLAG_PERSIST = 1 << 9
 FLAG_FP32_PRODUCTS = 1 << 10
 FLAG_ROWS32 = 1 << 11
 FLAG_ITEM_CXX = 1 << 12
+FLAG_BWD_KEYS32 = 1 << 13
+FLAG_BWD_KEYS64 = 1 << 14
 VREP_STRIDE = 72
 VREP_INV, VREP_REP, VREP_D1, VREP_D2 = 0, 16, 32, 41
 MAX_VIEWS = 16

@@ -158,3 +158,35 @@ def test_backward_is_bit_reproducible(shape, dtype):
         torch.cuda.synchronize()
         res[run] = (qd.grad.float().cpu(), kd.grad.float().cpu(), vd.grad.float().cpu(), float(tcd.grad.item()) if tcd.grad is not None else 0.0)
     assert all(torch.equal(res[0][i], res[1][i]) for i in range(3)) and res[0][3] == res[1][3]
+
+
+@pytest.mark.parametrize("shape", ["MS-enc", "MS-dec", "ragged-ms"])
+def test_dkv64_stream_matches_keys32_kernel_bit_for_bit(shape):
+    """gta_bwd_dkv64_kernel (64 keys per wave, the tile loop ONE generated instruction stream: gen_bwd64.py) against gta_bwd_dkv_kernel
+    (32 keys per wave, compiled): per (key, query) the same arithmetic and per accumulator the same order of query tiles, so dk and dv agree
+    bit for bit (dq comes from the same kernel in both runs; d trans_coeff sums the same per-key terms in another grouping)."""
+    shapes = dict(SHAPES)
+    shapes["ragged-ms"] = (2, 3, 3, 100, 3, 150, {"se3": 48, "so3": 24, "so2": 24}, 6, 2)      # Tq = 300 (5 query tiles, the last ragged), Tk = 450 (2 key blocks, ragged)
+    B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3 = shapes[shape]
+    assert sum(f_dims.values()) == 96
+    q, k, v, ex, ak, cross = C.synth_inputs(B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, torch.bfloat16, seed=41)
+    w = torch.randn(q.shape, generator=torch.Generator().manual_seed(43)).cuda()
+    exd = {kk: vv.cuda() for kk, vv in ex.items()}
+    gta_amd.pre_compute_reps_encoder(ak, exd)
+    if cross:
+        gta_amd.pre_compute_reps_decoder(ak, exd)
+    packed = gta_amd.pack_reps(exd, f_dims)
+    res = {}
+    for mode in ("prepass_bwd_keys32", "prepass_bwd_keys64"):
+        qd, kd, vd = (t.bfloat16().cuda().requires_grad_() for t in (q, k, v))
+        tcd = torch.tensor([0.37], device="cuda", requires_grad=True)
+        out = gta_amd.gta_attention(qd, kd, vd, f_dims, packed, so3_degree=exd.get("gta_so3_degree", 0), trans_coeff=tcd, kv_mode=mode)
+        (out.float() * w).sum().backward()
+        torch.cuda.synchronize()
+        res[mode] = (qd.grad.float().cpu(), kd.grad.float().cpu(), vd.grad.float().cpu(), float(tcd.grad.item()))
+    a, b = res["prepass_bwd_keys32"], res["prepass_bwd_keys64"]
+    assert torch.isfinite(b[1]).all() and torch.isfinite(b[2]).all() and b[1].abs().max() > 0
+    assert torch.equal(a[0], b[0])
+    assert torch.equal(a[2], b[2]), (a[2] - b[2]).abs().max()
+    assert torch.equal(a[1], b[1]), (a[1] - b[1]).abs().max()
+    assert abs(a[3] - b[3]) <= 1e-4 * max(1.0, abs(a[3])), (a[3], b[3])
