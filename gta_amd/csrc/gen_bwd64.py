@@ -35,7 +35,10 @@ Register map
   v[248:255]  temporaries               v[0:23], s[0:19] and what the statement names as operands: the compiler's
 """
 import argparse
+import os
+import subprocess
 import sys
+import tempfile
 
 import numpy as np
 
@@ -555,6 +558,31 @@ def emit(path, prog, prog_plain=None):
         regs_ = [f"v{i}" for i in CLOBBER_V] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in CLOBBER_S]
         f.write("#define GTA_BWD64_CLOBBERS \\\n    " + ", ".join(f'"{r}"' for r in regs_) + ', "vcc", "scc", "memory"\n')
         f.write("#define GTA_BWD64_OPERANDS \\\n    " + ", ".join(f'[{n}] "v"({n})' for n in VOPS) + ", \\\n    " + ", ".join(f'[{n}] "s"({n})' for n in SOPS) + "\n")
+
+
+def assemble_check(prog):
+    """the text through the assembler alone (operands replaced by registers hipcc could pick): syntax, encodable operands"""
+    rep = {f"%[{n}]": f"v{i}" for i, n in enumerate(VOPS)}
+    rep.update({f"%[{n}]": f"s{i}" for i, n in enumerate(SOPS)})
+    lines = [".amdgcn_target \"amdgcn-amd-amdhsa--gfx950\"", ".text", "k:"]
+    for ins in prog:
+        if ins.kind == "pseudo":
+            continue
+        t = ins.text.replace("%=", "0")
+        for k in sorted(rep, key=len, reverse=True):
+            t = t.replace(k, rep[k])
+        lines.append("  " + t)
+    clang = "/opt/rocm/lib/llvm/bin/clang"
+    if not os.path.exists(clang):
+        return None
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "k.s")
+        open(src, "w").write("\n".join(lines) + "\n")
+        r = subprocess.run([clang, "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", src, "-o", os.path.join(td, "k.o")],
+                           capture_output=True, text=True)
+        if r.returncode:
+            raise CheckError("the assembler rejects the stream:\n" + r.stderr[:3000])
+    return True
 
 
 if __name__ == "__main__":

@@ -309,6 +309,69 @@ def test_item_stream_simulation_catches_faults(fault):
         ns["check"](waves=(1,))
 
 
+def test_dkv64_stream_generator_simulates_and_is_current():
+    """gen_bwd64.py emits the tile loop of gta_bwd_dkv64_kernel (dK/dV of the backward, 64 keys per wave) as one instruction stream.  Its
+    check() EXECUTES the whole statement on the functional wave simulator of isa_model.py -- K'/V' fragment loads, the LDS-DMA ring (the
+    harness verifies at every barrier that the wave's own pieces of the tile have landed, and stands in for the other three waves), every
+    MFMA, transpose-read, exp2 and pack -- for 1, 2, 5 and 6 query tiles (the walk's entry, all four stage copies, every exit) and compares
+    the 192 accumulator registers and the values handed to the epilogue with a numpy model; the ISA's manual wait states are checked on the
+    executed order.  The assembler must accept the text, and the committed gta_bwd64_dkv.inc must be what the generator emits now."""
+    import os
+    import tempfile
+    g, d = _load_csrc_module("gen_bwd64")
+    st = g.check()
+    assert st["mfma"] == 480 and st["instructions"] < 2700, st          # tile 0: 48; four stage copies of 96; the tail: 48
+    prog = g.Gen().program()
+    if os.path.exists("/opt/rocm/lib/llvm/bin/clang"):
+        assert g.assemble_check(prog)
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "dkv.inc")
+        g.emit(out, prog)
+        assert open(out).read() == open(os.path.join(d, "gta_bwd64_dkv.inc")).read(), "gta_bwd64_dkv.inc is stale: make -C gta_amd/csrc regen"
+
+
+@pytest.mark.parametrize("fault", ["fragment_offset", "tr_offset", "early_wait", "operand_swap", "pack_order", "init_rows", "stage_reuse"])
+def test_dkv64_stream_simulation_catches_faults(fault):
+    """the simulation objects to what it is there for: a wrong fragment or transpose-read offset, a DMA wait that lets a tile's pieces be
+    late, dK fed with P instead of dS, a bf16 pack that overwrites a value it still needs, statistics of the wrong rows, a request that
+    overwrites the stage the walk still reads"""
+    import os
+    g, d = _load_csrc_module("gen_bwd64")
+    src = open(os.path.join(d, "gen_bwd64.py")).read()
+    old, new = {
+        "fragment_offset": ("a.ds_read(128, slot[4:8], reg, base + IMG + qb * HALF + imm)", "a.ds_read(128, slot[4:8], reg, base + IMG + qb * HALF + imm + 16)"),
+        "tr_offset": ("imm = base + qb * HALF + t * SL + (64 if d == 1 else 0)", "imm = base + qb * HALF + t * SL + (32 if d == 1 else 0)"),
+        "early_wait": ("        a.waitcnt(vm=7, lgkm=0)\n        a.barrier()", "        a.waitcnt(vm=9, lgkm=0)\n        a.barrier()"),
+        "operand_swap": ("a.mfma(DK[kb][d], slot[0:4], se[\"e\"][kb][4 * t:4 * t + 4], DK[kb][d])", "a.mfma(DK[kb][d], slot[0:4], se[\"s\"][kb][4 * t:4 * t + 4], DK[kb][d])"),
+        "pack_order": ("ops.append(lambda a, i=i, s=s: a.v_cvt_pk_bf16_f32(s[i], s[2 * i], s[2 * i + 1]))", "ops.append(lambda a, i=i, s=s: a.v_cvt_pk_bf16_f32(s[7 - i], s[2 * i], s[2 * i + 1]))"),
+        "init_rows": ("st * 512 + (32 * qb + 8 * g) * 4))", "st * 512 + (32 * qb + 8 * (g ^ 1)) * 4))"),
+        "stage_reuse": ("        self.dma_tile(a, (st + 2) % R)", "        self.dma_tile(a, (st + 3) % R)"),
+    }[fault]
+    assert old in src, fault
+    ns = {"__name__": "gen_bwd64_fault"}
+    exec(compile(src.replace(old, new, 1), "gen_bwd64_fault.py", "exec"), ns)
+    with pytest.raises(g.CheckError):
+        ns["check"](cases=((5, 3),))
+
+
+def test_dkv64_kernel_leaves_the_register_files_to_the_stream():
+    """tools/audit_spills.py audit_dkv64: around the generated statement of gta_bwd_dkv64_kernel hipcc must not touch an accumulator register
+    (the stream owns all 256 and leaves dK'^T / dV'^T in a[0:191], read out by statements of literal v_accvgpr_read right behind it), and the
+    statement's operands must have found room in v0..v23."""
+    import importlib.util
+    import os
+    import shutil
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("audit_spills", os.path.join(root, "tools", "audit_spills.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    report, problems = mod.audit_dkv64()
+    assert report and report[0]["loop_statements"] == 1, report
+    assert not problems, problems
+
+
 def test_attn64_kernel_leaves_the_accumulator_file_to_the_loop_statement():
     """tools/audit_spills.py audit_attn64: hipcc must not touch accumulator registers in gta_attn64_kernel (the loop statement and
     the fragment writes / O reads around it own them by literal number), one loop statement, 256 + 256 register split."""

@@ -98,6 +98,46 @@ def audit_others():
     return report, problems
 
 
+def audit_dkv64():
+    """gta_bwd_dkv64_kernel (gta_bwd.hip): ONE generated statement (gen_bwd64.py) owns v24..v255 and every accumulator register; it leaves
+    dK'^T / dV'^T in a[0:191], which twelve statements of literal v_accvgpr_read right behind it hand to the compiled epilogue.  hipcc does
+    not know: it must not touch an accumulator register itself anywhere in the kernel, and at most a handful of scratch accesses (the epilogue
+    holds 192 accumulator values beside its own)."""
+    text = _asm("gta_bwd.hip", ("-fno-slp-vectorize",))
+    report, problems = [], []
+    for m in re.finditer(r"^(_ZN\w*gta_bwd_dkv64_kernel\w+):", text, re.M):
+        name = m.group(1)
+        body = text[m.start():text.index(".Lfunc_end", m.start())]
+        meta = text[text.index(".amdhsa_kernel " + name):][:4000]
+        vgpr = int(re.search(r"\.amdhsa_next_free_vgpr\s+(\d+)", meta).group(1))
+        accum = int(re.search(r"\.amdhsa_accum_offset\s+(\d+)", meta).group(1))
+        inasm, compiler_acc, scratch, long_stmts, cur_len = False, 0, 0, 0, 0
+        for line in body.split("\n"):
+            if "#ASMSTART" in line:
+                inasm, cur_len = True, 0
+                continue
+            if "#ASMEND" in line:
+                inasm = False
+                long_stmts += cur_len > 1000
+                continue
+            if inasm:
+                cur_len += 1
+                continue
+            compiler_acc += len(re.findall(r"\ba\[?\d+", line.split(";")[0]))
+            scratch += "scratch_" in line
+        report.append({"kernel": name, "vgpr": vgpr, "accum_offset": accum, "compiler_agpr_uses": compiler_acc, "scratch": scratch,
+                       "loop_statements": long_stmts})
+        if compiler_acc:
+            problems.append(f"gta_bwd_dkv64_kernel: hipcc touches accumulator registers itself ({compiler_acc} operands)")
+        if long_stmts != 1:
+            problems.append(f"gta_bwd_dkv64_kernel: {long_stmts} generated statements (expected one)")
+        if vgpr != 512 or accum != 256:
+            problems.append(f"gta_bwd_dkv64_kernel: register file split {accum} / {vgpr} (expected 256 / 512)")
+        if scratch > 8:
+            problems.append(f"gta_bwd_dkv64_kernel: {scratch} scratch accesses")
+    return report, problems
+
+
 def audit_attn64():
     """gta_attn64_kernel (gta_fwd64.hip): the tile loop statement owns v32-v255 and the whole accumulator file by literal
     register number, the Q' fragments are written into a[96:143] by separate statements in front of it and O is read out of
@@ -173,7 +213,8 @@ if __name__ == "__main__":
     rep, prob = audit()
     rep2, prob2 = audit_others()
     rep3, prob3 = audit_attn64()
-    for r in rep + rep2 + rep3:
+    rep4, prob4 = audit_dkv64()
+    for r in rep + rep2 + rep3 + rep4:
         print(r)
-    print("problems:", (prob + prob2 + prob3) or "none")
-    sys.exit(1 if prob or prob2 or prob3 else 0)
+    print("problems:", (prob + prob2 + prob3 + prob4) or "none")
+    sys.exit(1 if prob or prob2 or prob3 or prob4 else 0)
