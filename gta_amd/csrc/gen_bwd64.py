@@ -192,8 +192,8 @@ class Gen:
         return ops
 
     # ---- LDS-DMA of a tile (this wave's 6 KiB of the 24-KiB stage + its share of the statistics): 7 operations ----
-    def dma_tile(self, a, st):
-        """source: tile S_JF (clamped to the last one: the count of operations per iteration is what the counted waits rely on)"""
+    def dma_addr(self, a):
+        """source pointers of tile S_JF (clamped to the last one: the count of operations per iteration is what the counted waits rely on)"""
         a.s_mul_i32(S_T0, S_JF, STAGE)
         a.s_add_u32(S_QP[0], op("q_lo"), S_T0)
         a.s_addc_u32(S_QP[1], op("q_hi"), 0)
@@ -205,23 +205,32 @@ class Gen:
         a.s_add_u32(S_SP[0], S_SP[0], S_WST)
         a.s_addc_u32(S_SP[1], S_SP[1], 0)
         a.s_add_u32(S_M, op("ring"), S_WIMG)
+        a.s_add_u32(S_T2, op("stats"), S_WST)
+
+    def dma_ops(self, st):
+        """the requests themselves, one closure per instruction (they ride in the gaps of an iteration's first MFMA groups)"""
+        ops = []
+
+        def m0(reg, off):
+            ops.append(lambda a: a.add(f"s_add_u32 m0, {reg}, {off}", "salu", [reg], ["m0", "scc"], ("s_add_m0", reg, off)))
+            ops.append(lambda a: a.nop(1))
         for g in range(2):
-            off = st * STAGE + 4096 * g
-            a.add(f"s_add_u32 m0, {S_M}, {off}", "salu", [S_M], ["m0", "scc"], ("s_add_m0", S_M, off))
-            a.nop(1)
             if g == 1:
-                a.s_add_u32(S_QP[0], S_QP[0], 4096)
-                a.s_addc_u32(S_QP[1], S_QP[1], 0)
-                a.add(f"s_add_u32 m0, {S_M}, {off}", "salu", [S_M], ["m0", "scc"], ("s_add_m0", S_M, off))      # (scc was clobbered; m0 again)
-                a.nop(1)
+                ops.append(lambda a: a.s_add_u32(S_QP[0], S_QP[0], 4096))
+                ops.append(lambda a: a.s_addc_u32(S_QP[1], S_QP[1], 0))
+            m0(S_M, st * STAGE + 4096 * g)
             for p in range(4 if g == 0 else 2):
-                a.add(f"global_load_lds_dwordx4 {op('lane16')}, {rtext(S_QP)}" + (f" offset:{1024 * p}" if p else ""), "dma",
-                      ["m0", op("lane16")] + S_QP, [], ("global_load_lds", op("lane16"), S_QP, 1024 * p))
-        a.s_add_u32(S_M, op("stats"), S_WST)
-        a.add(f"s_add_u32 m0, {S_M}, {st * 512}", "salu", [S_M], ["m0", "scc"], ("s_add_m0", S_M, st * 512))
-        a.nop(1)
-        a.add(f"global_load_lds_dword {op('lane4')}, {rtext(S_SP)}", "dma", ["m0", op("lane4")] + S_SP, [],
-              ("global_load_lds_dword", op("lane4"), S_SP, 0))
+                ops.append(lambda a, p=p: a.add(f"global_load_lds_dwordx4 {op('lane16')}, {rtext(S_QP)}" + (f" offset:{1024 * p}" if p else ""), "dma",
+                                               ["m0", op("lane16")] + S_QP, [], ("global_load_lds", op("lane16"), S_QP, 1024 * p)))
+        m0(S_T2, st * 512)
+        ops.append(lambda a: a.add(f"global_load_lds_dword {op('lane4')}, {rtext(S_SP)}", "dma", ["m0", op("lane4")] + S_SP, [],
+                                   ("global_load_lds_dword", op("lane4"), S_SP, 0)))
+        return ops
+
+    def dma_tile(self, a, st):
+        self.dma_addr(a)
+        for c in self.dma_ops(st):
+            c(a)
 
     # ---- weaving: MFMA groups with the loads PF groups ahead and a share of the VALU list in their gaps ----
     def weave(self, a, groups, valu, first_slot, extra=None, preloaded=0):
@@ -299,21 +308,23 @@ class Gen:
         a.add(f"s_cselect_b32 {S_JF}, 1, 0", "salu", ["scc"], [S_JF], ("s_cselect_b32", S_JF, 1, 0))
         self.dma_tile(a, 1)
 
-    def top(self, a, st, jf_next):
-        """iteration top of tile j (stage st): its DMA has landed everywhere; request tile min(j + 2, n - 1)"""
-        a.waitcnt(vm=7, lgkm=0)
+    def top(self, a, st):
+        """iteration top of tile j (stage st): its DMA has landed everywhere; the pointers of tile min(j + 2, n - 1), whose request follows"""
+        a.waitcnt(vm=7)
         a.barrier()
         a.s_add_u32(S_JF, S_J, 2)
         a.s_sub_u32(S_T1, S_N, 1)
         a.add(f"s_min_u32 {S_JF}, {S_JF}, {S_T1}", "salu", [S_JF, S_T1], [S_JF, "scc"], ("s_min_u32", S_JF, S_JF, S_T1))
-        self.dma_tile(a, (st + 2) % R)
+        self.dma_addr(a)
 
     def program(self, n_static=None):
         a = Asm()
         self.head(a)
         # ---- tile 0: A, C (nothing to add to dK / dV yet) ----
         a.s_mov_b32(S_J, 0)
-        self.top(a, 0, None)
+        self.top(a, 0)
+        for c in self.dma_ops(2):
+            c(a)
         for c in self.init_loads(0, 0):
             c(a)
         slot = 0
@@ -321,17 +332,22 @@ class Gen:
         g = self.s_segment(0, 0) + self.s_segment(0, 1)
         slot = self.weave(a, g, [(7, 11, sm0)], slot, extra={2: self.init_loads(0, 1)})
         a.s_mov_b32(S_J, 1)
-        # ---- tiles 1 .. n - 1: four copies, one per ring stage; the walk enters at stage 1 ----
+        # ---- tiles 1 .. n - 1: four copies, one per ring stage; the walk enters at stage 1.  An iteration starts with the transpose-reads of
+        # its first three groups (tile j - 1: nothing to wait for), THEN waits for tile j and meets the other waves; the requests for tile j + 2
+        # ride in the gaps of its first groups ----
         a.label("L_top_%=")
         for c in (1, 2, 3, 0):
             a.s_cmp("ge", "u32", S_J, S_N)
             a.branch("s_cbranch_scc1", "L_tail_%=")
-            self.top(a, c, None)
             prev = (c - 1) % R
             g = self.d_segment(prev, 0) + self.s_segment(c, 0) + self.d_segment(prev, 1) + self.s_segment(c, 1)
+            for i in range(PF):
+                g[i].loads(a, SLOT[(slot + i) % 4])
+            self.top(a, c)
+            dma = self.dma_ops((c + 2) % R)
             sm1, sm0 = self.softmax(1), self.softmax(0)
-            slot = self.weave(a, g, [(0, 11, sm1), (13, 23, sm0)], slot,
-                              extra={0: self.init_loads(c, 0), 10: self.init_loads(c, 1)})
+            slot = self.weave(a, g, [(0, 11, sm1), (13, 23, sm0)], slot, preloaded=PF,
+                              extra={0: self.init_loads(c, 0), 1: dma[:8], 2: dma[8:], 10: self.init_loads(c, 1)})
             a.s_add_u32(S_J, S_J, 1)
         a.branch("s_branch", "L_top_%=")
         # ---- after the last tile: its D and B; the tile's stage is (S_J - 1) % 4, known at run time ----
