@@ -341,7 +341,7 @@ def test_dkv64_stream_simulation_catches_faults(fault):
     old, new = {
         "fragment_offset": ("a.ds_read(128, slot[4:8], reg, base + IMG + qb * HALF + imm)", "a.ds_read(128, slot[4:8], reg, base + IMG + qb * HALF + imm + 16)"),
         "tr_offset": ("imm = base + qb * HALF + t * SL + (64 if d == 1 else 0)", "imm = base + qb * HALF + t * SL + (32 if d == 1 else 0)"),
-        "early_wait": ("        a.waitcnt(vm=7, lgkm=0)\n        a.barrier()", "        a.waitcnt(vm=9, lgkm=0)\n        a.barrier()"),
+        "early_wait": ("        a.waitcnt(vm=7)\n        a.barrier()", "        a.waitcnt(vm=9)\n        a.barrier()"),
         "operand_swap": ("a.mfma(DK[kb][d], slot[0:4], se[\"e\"][kb][4 * t:4 * t + 4], DK[kb][d])", "a.mfma(DK[kb][d], slot[0:4], se[\"s\"][kb][4 * t:4 * t + 4], DK[kb][d])"),
         "pack_order": ("ops.append(lambda a, i=i, s=s: a.v_cvt_pk_bf16_f32(s[i], s[2 * i], s[2 * i + 1]))", "ops.append(lambda a, i=i, s=s: a.v_cvt_pk_bf16_f32(s[7 - i], s[2 * i], s[2 * i + 1]))"),
         "init_rows": ("st * 512 + (32 * qb + 8 * g) * 4))", "st * 512 + (32 * qb + 8 * (g ^ 1)) * 4))"),
