@@ -345,7 +345,7 @@ def test_dkv64_stream_simulation_catches_faults(fault):
         "operand_swap": ("a.mfma(DK[kb][d], slot[0:4], se[\"e\"][kb][4 * t:4 * t + 4], DK[kb][d])", "a.mfma(DK[kb][d], slot[0:4], se[\"s\"][kb][4 * t:4 * t + 4], DK[kb][d])"),
         "pack_order": ("ops.append(lambda a, i=i, s=s: a.v_cvt_pk_bf16_f32(s[i], s[2 * i], s[2 * i + 1]))", "ops.append(lambda a, i=i, s=s: a.v_cvt_pk_bf16_f32(s[7 - i], s[2 * i], s[2 * i + 1]))"),
         "init_rows": ("st * 512 + (32 * qb + 8 * g) * 4))", "st * 512 + (32 * qb + 8 * (g ^ 1)) * 4))"),
-        "stage_reuse": ("        self.dma_tile(a, (st + 2) % R)", "        self.dma_tile(a, (st + 3) % R)"),
+        "stage_reuse": ("dma = self.dma_ops((c + 2) % R)", "dma = self.dma_ops((c + 3) % R)"),
     }[fault]
     assert old in src, fault
     ns = {"__name__": "gen_bwd64_fault"}
