@@ -375,6 +375,268 @@ class Gen:
         return auto_waits(a.out)
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# dQ: 64 query rows per wave (gta_bwd_dq64_kernel).  The same machinery with the roles turned: the wave's Q'' / dO~ fragments (row blocks
+# rb = 0, 1 of 32 rows) are stationary, the (b, h)'s K' / V' tile images are streamed; per 32-key half hh of a tile
+#     S^T = K' Q''^T - lse2,  dP^T = V' dO~^T - D   (the seeds are per-lane constants here: a lane is a query row),
+#     dS^T = exp2(S^T) dP^T  (bf16 pairs in place of dP^T),   dQ'^T[d] += K'^T dS^T   (K'^T by transpose-reads, 2 k-steps of 16 keys)
+# Groups: S/dP k-step ks = K' and V' row fragments of the half (one slot) -> 4 MFMAs (2 row blocks x S, dP); dQ: two transposed operands
+# (t, d) per slot -> 4 MFMAs (2 row blocks each).  An iteration: dQ of (j-1, hh 0) [3 groups] | S/dP of (j, 0) [6] | dQ of (j-1, 1) [3] |
+# S/dP of (j, 1) [6].  Key tiles in whole (Tk % 64 == 0: the kernel keeps the compiled form otherwise).
+# Registers: a[0:95] dQ'^T[rb][d], a[96:143] Q'' fragments [rb][ks], a[144:191] dO~ fragments; v[56:183] the two S / dP sets (per half),
+# v[184:215] slots, v[216:247] -lse2 splats [rb], v[24:55] -D splats [rb].
+# ------------------------------------------------------------------------------------------------------------------
+DQ = [[A((rb * DB + d) * 16, 16) for d in range(DB)] for rb in range(2)]
+QF = [[A(96 + (rb * KS + ks) * 4, 4) for ks in range(KS)] for rb in range(2)]
+DOF = [[A(144 + (rb * KS + ks) * 4, 4) for ks in range(KS)] for rb in range(2)]
+QINIT_L = [V(216 + 16 * rb, 16) for rb in range(2)]
+QINIT_D = [V(24 + 16 * rb, 16) for rb in range(2)]
+Q_VOPS = ("koffl", "koff4", "koff5", "voff00", "voff01", "voff20", "voff21",
+          "koffl_h", "koff4_h", "koff5_h", "voff00_h", "voff01_h", "voff20_h", "voff21_h", "lane16", "lrow4")
+Q_SOPS = ("kv_lo", "kv_hi", "qi_lo", "qi_hi", "st_lo", "st_hi", "n", "wave", "ring")
+DQ_PAIRS = (((0, 0), (0, 1)), ((0, 2), (1, 0)), ((1, 1), (1, 2)))       # the (t, d) operands of a half's three dQ groups
+
+
+class GenDQ(Gen):
+    def kv_loads(self, st, hh, ks):
+        """row fragments of K' (slot[0:4]) and V' (slot[4:8]) of key half hh, k-step ks"""
+        base, h = self.stage_imm(st)
+        reg, imm = (op("koffl" + h), 32 * ks) if ks < 4 else (op(f"koff{ks}" + h), 0)
+
+        def emit(a, slot):
+            a.ds_read(128, slot[0:4], reg, base + hh * HALF + imm)
+            a.ds_read(128, slot[4:8], reg, base + IMG + hh * HALF + imm)
+        return emit
+
+    def ktr_loads(self, st, hh, pair, rt=None):
+        """K'^T operands (t, d) of the pair: slot[0:4], slot[4:8]"""
+        base, h = self.stage_imm(st) if rt is None else (0, "")
+
+        def emit(a, slot):
+            for i, (t, d) in enumerate(pair):
+                names = ("voff00", "voff01") if d < 2 else ("voff20", "voff21")
+                imm = base + hh * HALF + t * SL + (64 if d == 1 else 0)
+                for hf in range(2):
+                    reg = op(names[hf] + h) if rt is None else rt[(0 if d < 2 else 2) + hf]
+                    a.ds_read_tr(slot[4 * i + 2 * hf:4 * i + 2 * hf + 2], reg, imm)
+        return emit
+
+    def s_group(self, st, hh, ks):
+        se = SE[hh]
+
+        def mf(a, slot):
+            for rb in range(2):
+                a.mfma(se["s"][rb], slot[0:4], QF[rb][ks], QINIT_L[rb] if ks == 0 else se["s"][rb])      # S^T  = K' Q''^T - lse2
+                a.mfma(se["e"][rb], slot[4:8], DOF[rb][ks], QINIT_D[rb] if ks == 0 else se["e"][rb])     # dP^T = V' dO~^T - D
+        return Group(self.kv_loads(st, hh, ks), mf)
+
+    def s_segment(self, st, hh):
+        return [self.s_group(st, hh, ks) for ks in range(KS)]
+
+    def d_segment(self, st, hh, rt=None):
+        se = SE[hh]
+        out = []
+        for pair in DQ_PAIRS:
+            def mf(a, slot, pair=pair):
+                for i, (t, d) in enumerate(pair):
+                    for rb in range(2):
+                        a.mfma(DQ[rb][d], slot[4 * i:4 * i + 4], se["e"][rb][4 * t:4 * t + 4], DQ[rb][d])   # dQ'^T += K'^T dS^T
+            out.append(Group(self.ktr_loads(st, hh, pair, rt), mf))
+        return out
+
+    def softmax(self, hh):
+        se = SE[hh]
+        ops = []
+        for t in range(2):
+            for rb in range(2):
+                s, e = se["s"][rb], se["e"][rb]
+                rr = range(8 * t, 8 * t + 8)
+                for r in rr:
+                    ops.append(lambda a, r=r, s=s: a.v_exp_f32(s[r], s[r]))
+                for r in rr:
+                    ops.append(lambda a, r=r, s=s, e=e: a.v_mul_f32(e[r], s[r], e[r]))
+                for i in range(4 * t, 4 * t + 4):
+                    ops.append(lambda a, i=i, e=e: a.v_cvt_pk_bf16_f32(e[i], e[2 * i], e[2 * i + 1]))
+        return ops
+
+    def dma_addr(self, a):
+        a.s_mul_i32(S_T0, S_JF, STAGE)
+        a.s_add_u32(S_QP[0], op("kv_lo"), S_T0)
+        a.s_addc_u32(S_QP[1], op("kv_hi"), 0)
+        a.s_add_u32(S_QP[0], S_QP[0], S_WIMG)
+        a.s_addc_u32(S_QP[1], S_QP[1], 0)
+        a.s_add_u32(S_M, op("ring"), S_WIMG)
+
+    def dma_ops(self, st):
+        return Gen.dma_ops(self, st)[:-3]                              # (no statistics with a key tile)
+
+    def head(self, a):
+        a.s_mov_b32(S_N, op("n"))
+        a.s_mul_i32(S_WIMG, op("wave"), IMG // 2)
+        for i, nm in enumerate(("koffl", "koff4", "koff5")):
+            a.v_sub_u32(TMP[i], op(nm), op("ring"))
+        a.s_mov_b32(S_QP[0], op("qi_lo"))                              # this wave's 64 rows: Q'' image; dO~ image 12 KiB on
+        a.s_mov_b32(S_QP[1], op("qi_hi"))
+        a.s_add_u32(S_SP[0], op("qi_lo"), IMG)
+        a.s_addc_u32(S_SP[1], op("qi_hi"), 0)
+        for rb in range(2):
+            if rb == 1:
+                for pr in (S_QP, S_SP):
+                    a.s_add_u32(pr[0], pr[0], HALF)
+                    a.s_addc_u32(pr[1], pr[1], 0)
+            for ks in range(KS):
+                reg, imm = (TMP[0], 32 * ks) if ks < 4 else (TMP[ks - 3], 0)
+                a.global_load(4, QF[rb][ks], reg, S_QP, imm)
+                a.global_load(4, DOF[rb][ks], reg, S_SP, imm)
+        # the rows' -lse2 / -D (the wave's 128 statistics: -lse2 of rows 0..63, then -D), splat over the 16 registers of a C operand
+        st = [op("st_lo"), op("st_hi")]
+        a.s_mov_b32(S_SP[0], st[0])
+        a.s_mov_b32(S_SP[1], st[1])
+        for rb in range(2):
+            a.global_load(1, [TMP[4 + rb]], op("lrow4"), S_SP, 128 * rb)
+            a.global_load(1, [TMP[6 + rb]], op("lrow4"), S_SP, 256 + 128 * rb)
+        for acc in [x for rb in range(2) for x in DQ[rb]]:
+            for r in acc:
+                a.v_accvgpr_write_b32(r, 0)
+        for rb in range(2):
+            for r in QINIT_L[rb]:
+                a.v_mov_b32(r, TMP[4 + rb])
+            for r in QINIT_D[rb]:
+                a.v_mov_b32(r, TMP[6 + rb])
+        a.s_mov_b32(S_JF, 0)
+        self.dma_tile(a, 0)
+        a.s_cmp("gt", "u32", S_N, 1)
+        a.add(f"s_cselect_b32 {S_JF}, 1, 0", "salu", ["scc"], [S_JF], ("s_cselect_b32", S_JF, 1, 0))
+        self.dma_tile(a, 1)
+
+    def top(self, a, st):
+        a.waitcnt(vm=6)
+        a.barrier()
+        a.s_add_u32(S_JF, S_J, 2)
+        a.s_sub_u32(S_T1, S_N, 1)
+        a.add(f"s_min_u32 {S_JF}, {S_JF}, {S_T1}", "salu", [S_JF, S_T1], [S_JF, "scc"], ("s_min_u32", S_JF, S_JF, S_T1))
+        self.dma_addr(a)
+
+    def program(self):
+        a = Asm()
+        self.head(a)
+        a.s_mov_b32(S_J, 0)
+        self.top(a, 0)
+        for c in self.dma_ops(2):
+            c(a)
+        slot = 0
+        g = self.s_segment(0, 0) + self.s_segment(0, 1)
+        slot = self.weave(a, g, [(7, 11, self.softmax(0))], slot)
+        a.s_mov_b32(S_J, 1)
+        a.label("L_top_%=")
+        for c in (1, 2, 3, 0):
+            a.s_cmp("ge", "u32", S_J, S_N)
+            a.branch("s_cbranch_scc1", "L_tail_%=")
+            prev = (c - 1) % R
+            g = self.d_segment(prev, 0) + self.s_segment(c, 0) + self.d_segment(prev, 1) + self.s_segment(c, 1)
+            for i in range(PF):
+                g[i].loads(a, SLOT[(slot + i) % 4])
+            self.top(a, c)
+            dma = self.dma_ops((c + 2) % R)
+            slot = self.weave(a, g, [(0, 8, self.softmax(1)), (10, 17, self.softmax(0))], slot, preloaded=PF, extra={1: dma[:7], 2: dma[7:]})
+            a.s_add_u32(S_J, S_J, 1)
+        a.branch("s_branch", "L_top_%=")
+        a.label("L_tail_%=")
+        a.waitcnt(vm=0, lgkm=0)
+        a.s_sub_u32(S_T0, S_J, 1)
+        a.s_and_b32(S_T0, S_T0, 3)
+        a.s_mul_i32(S_T0, S_T0, STAGE)
+        rt = TMP[0:4]
+        for i, nm in enumerate(("voff00", "voff01", "voff20", "voff21")):
+            a.v_add_u32(rt[i], S_T0, op(nm))
+        g = self.d_segment(0, 0, rt) + self.d_segment(0, 1, rt)
+        self.weave(a, g, [(0, 2, self.softmax(1))], slot)
+        a.pseudo("end")
+        return auto_waits(a.out)
+
+
+def model_dq(kt, vt, qrows, dorows, stats):
+    """kt, vt: [n][64][96] (K', V' tiles), qrows, dorows: [64][96] (the wave's rows), stats [128] (-lse2 | -D).  dQ'^T as [rb][96][32]"""
+    n = kt.shape[0]
+    out = np.zeros((2, 96, 32), np.float64)
+    for j in range(n):
+        for rb in range(2):
+            q, do = qrows[32 * rb:32 * rb + 32].astype(np.float64), dorows[32 * rb:32 * rb + 32].astype(np.float64)
+            s = (kt[j].astype(np.float64) @ q.T + stats[None, 32 * rb:32 * rb + 32]).astype(np.float32)             # [key][row]
+            e = (vt[j].astype(np.float64) @ do.T + stats[None, 64 + 32 * rb:64 + 32 * rb + 32]).astype(np.float32)
+            with np.errstate(all="ignore"):
+                p = np.exp2(s.astype(np.float64)).astype(np.float32)
+            ds = bf16_to_f32(bf16_rne((p * e).astype(np.float32))).astype(np.float64)
+            out[rb] += kt[j].astype(np.float64).T @ ds
+    return out
+
+
+def run_case_dq(prog, n, wave, seed=0):
+    rng = np.random.default_rng(seed + 100)
+
+    def rb_(shape, scale):
+        return bf16_to_f32(bf16_rne((rng.standard_normal(shape) * scale).astype(np.float32)))
+    kt, vt = rb_((n, 64, 96), 0.6), rb_((n, 64, 96), 0.6)
+    qrows, dorows = rb_((64, 96), 0.6), rb_((64, 96), 0.6)
+    stats = np.concatenate([-(rng.uniform(3.0, 6.0, size=64)), rng.standard_normal(64) * 0.3]).astype(np.float32)
+    stats[61:64] = -1e30
+    A_KV, A_QI, A_ST = 0x1000000, 0x2000000, 0x3000000
+    kvbuf = np.concatenate([np.concatenate([image_of(bf16_rne(kt[j]).astype(np.uint16)), image_of(bf16_rne(vt[j]).astype(np.uint16))]) for j in range(n)])
+    qibuf = np.concatenate([image_of(bf16_rne(qrows).astype(np.uint16)), image_of(bf16_rne(dorows).astype(np.uint16))])
+    stbuf = stats.view(np.uint8).copy()
+    lo = lane_offsets(0)
+    lo["lrow4"] = ((np.arange(LANES) & 31) * 4).astype(np.uint32)
+    inputs = {op("kv_lo"): A_KV & 0xffffffff, op("kv_hi"): A_KV >> 32, op("qi_lo"): A_QI & 0xffffffff, op("qi_hi"): A_QI >> 32,
+              op("st_lo"): A_ST & 0xffffffff, op("st_hi"): A_ST >> 32, op("n"): n, op("wave"): wave, op("ring"): 0}
+    w = Wave(inputs=inputs, seed=wave + 5)
+    w.vector_inputs = {op(k): lo[k] for k in Q_VOPS}
+    for base, arr in ((A_KV, kvbuf), (A_QI, qibuf), (A_ST, stbuf)):
+        w.map_buffer(base, arr)
+    state = {"barriers": 0}
+
+    def barrier_hook(wv):
+        j = state["barriers"]
+        state["barriers"] += 1
+        if j >= n:
+            raise CheckError(f"barrier {j} with {n} tiles")
+        st = j % R
+        own = slice(wave * 6144, wave * 6144 + 6144)
+        src = kvbuf[j * STAGE:(j + 1) * STAGE]
+        dst = wv.lds[st * STAGE:(st + 1) * STAGE]
+        if not (dst[own] == src[own]).all():
+            raise CheckError(f"wave {wave}: its share of key tile {j} has not landed at the tile's barrier")
+        dst[:] = src
+    w.hooks = {"end": lambda wv: "__end__"}
+    w.barrier_hook = barrier_hook
+    w.run(prog, checker=check_wait_states)
+    if w.vm or w.lgkm:
+        raise CheckError("memory operations outstanding at the end of the statement")
+    if state["barriers"] != n:
+        raise CheckError(f"{state['barriers']} barriers for {n} tiles")
+    want = model_dq(kt, vt, qrows, dorows, stats.astype(np.float64))
+    for rb in range(2):
+        for d in range(DB):
+            got = np.stack([u2f(w.v[w.ridx(r)]) for r in DQ[rb][d]])
+            for lane in range(LANES):
+                jn, h = lane & 31, lane >> 5
+                for r in range(16):
+                    ch = 32 * d + (r & 3) + 8 * (r >> 2) + 4 * h
+                    ref = want[rb][ch, jn]
+                    if not abs(float(got[r, lane]) - ref) <= 2e-3 * max(1.0, abs(ref)):
+                        raise CheckError(f"wave {wave} n {n}: dQ'[rb {rb}][channel {ch}][row {jn}] = {got[r, lane]}, expected {ref}")
+    return w
+
+
+def check_dq(verbose=False, cases=((1, 0), (2, 1), (5, 3), (6, 2))):
+    prog = GenDQ().program()
+    stats = {"instructions": sum(1 for x in prog if x.kind not in ("label", "pseudo")), "mfma": sum(1 for x in prog if x.kind == "mfma")}
+    for n, wave in cases:
+        run_case_dq(prog, n, wave, seed=n)
+        if verbose:
+            print(f"  ok (dQ): {n} key tiles, wave {wave}")
+    return stats
+
+
 def auto_waits(prog):
     """lgkmcnt waits in front of the first use of every LDS read's destination (LDS operations complete in order); vmcnt waits for the
     global loads of the head.  Labels and branches sit where nothing is outstanding (the generator's iteration tops)."""
@@ -554,32 +816,25 @@ def check(verbose=False, cases=((1, 0), (2, 1), (5, 3), (6, 2))):
 # ------------------------------------------------------------------------------------------------------------------
 # emission
 # ------------------------------------------------------------------------------------------------------------------
-def emit(path, prog, prog_plain=None):
+def emit(path, prog, macro="GTA_BWD64_DKV", vops=VOPS, sops=SOPS):
     with open(path, "w") as f:
         f.write("// generated by gen_bwd64.py (make regen) -- do not edit\n")
         for name, val in (("STAGES", R), ("OFF_STATS", OFF_STATS), ("HI_BASE", HI_BASE)):
-            f.write(f"#define GTA_BWD64_{name} {val}\n")
-        for macro, p in (("GTA_BWD64_DKV", prog), ("GTA_BWD64_DKV_PLAIN", prog_plain)):
-            if p is None:
-                continue
-            if macro.endswith("PLAIN"):
-                f.write("#ifdef GTA_ATTN64_DIAG\n")
-            f.write(f"#define {macro} \\\n")
-            for ins in p:
-                if ins.kind != "pseudo":
-                    f.write(f'    "{ins.text}\\n\\t" \\\n')
-            f.write('    ""\n')
-            if macro.endswith("PLAIN"):
-                f.write("#endif\n")
+            f.write(f"#ifndef GTA_BWD64_{name}\n#define GTA_BWD64_{name} {val}\n#endif\n")
+        f.write(f"#define {macro} \\\n")
+        for ins in prog:
+            if ins.kind != "pseudo":
+                f.write(f'    "{ins.text}\\n\\t" \\\n')
+        f.write('    ""\n')
         regs_ = [f"v{i}" for i in CLOBBER_V] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in CLOBBER_S]
-        f.write("#define GTA_BWD64_CLOBBERS \\\n    " + ", ".join(f'"{r}"' for r in regs_) + ', "vcc", "scc", "memory"\n')
-        f.write("#define GTA_BWD64_OPERANDS \\\n    " + ", ".join(f'[{n}] "v"({n})' for n in VOPS) + ", \\\n    " + ", ".join(f'[{n}] "s"({n})' for n in SOPS) + "\n")
+        f.write(f"#define {macro}_CLOBBERS \\\n    " + ", ".join(f'"{r}"' for r in regs_) + ', "vcc", "scc", "memory"\n')
+        f.write(f"#define {macro}_OPERANDS \\\n    " + ", ".join(f'[{n}] "v"({n})' for n in vops) + ", \\\n    " + ", ".join(f'[{n}] "s"({n})' for n in sops) + "\n")
 
 
-def assemble_check(prog):
+def assemble_check(prog, vops=VOPS, sops=SOPS):
     """the text through the assembler alone (operands replaced by registers hipcc could pick): syntax, encodable operands"""
-    rep = {f"%[{n}]": f"v{i}" for i, n in enumerate(VOPS)}
-    rep.update({f"%[{n}]": f"s{i}" for i, n in enumerate(SOPS)})
+    rep = {f"%[{n}]": f"v{i}" for i, n in enumerate(vops)}
+    rep.update({f"%[{n}]": f"s{i}" for i, n in enumerate(sops)})
     lines = [".amdgcn_target \"amdgcn-amd-amdhsa--gfx950\"", ".text", "k:"]
     for ins in prog:
         if ins.kind == "pseudo":
@@ -604,9 +859,14 @@ def assemble_check(prog):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--out")
+    ap.add_argument("--out-dq")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
     st = check(args.verbose)
-    print(f"gen_bwd64: {st['instructions']} instructions, {st['mfma']} MFMAs; simulation ok", file=sys.stderr)
+    print(f"gen_bwd64: dK/dV {st['instructions']} instructions, {st['mfma']} MFMAs; simulation ok", file=sys.stderr)
+    st = check_dq(args.verbose)
+    print(f"gen_bwd64: dQ {st['instructions']} instructions, {st['mfma']} MFMAs; simulation ok", file=sys.stderr)
     if args.out:
         emit(args.out, Gen().program())
+    if args.out_dq:
+        emit(args.out_dq, GenDQ().program(), "GTA_BWD64_DQ", Q_VOPS, Q_SOPS)

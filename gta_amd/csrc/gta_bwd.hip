@@ -989,20 +989,20 @@ __global__ __launch_bounds__(256, 1) void gta_bwd_dkv64_kernel(const GtaBwdParam
         const uint32_t ring = ring_s, stats = stats_s;
         const uint32_t side = ring_s + (uint32_t)(S::OFF_SIDE + wave * S::SIDE_W);
         {
-            // the (cos, sin) rows of this wave's 64 keys -> its side buffer, six 16-byte pieces per key (lane <-> key k0 + 64 wave + lane; rows
-            // past Tk: the last row's): the epilogue reads them from LDS, their latency lies under the walk
-            int tk = k0 + 64 * wave + lane;
-            tk = tk < p.Tk ? tk : p.Tk - 1;
+            // the (cos, sin) rows of this wave's 64 keys -> its side buffer, row-major [key][96 B] (the rows of consecutive tokens are contiguous:
+            // six linear KiB; keys past Tk: clamped into the table): the epilogue reads them from LDS, their latency lies under the walk
             if (p.cs_k) {
-                const uint32_t cro = (uint32_t)(((long)b * p.Tk + tk) * 2 * p.nso2 * 4 - (long)b * p.Tk * 2 * p.nso2 * 4);
                 const float* csb = p.cs_k + (long)b * p.Tk * 2 * p.nso2;
+                const long last = (long)p.Tk * 96 - 16;                       // (96 bytes per token: nso2 = 12)
                 static_for_bwd<6>([&](auto PC) {
                     constexpr int pc = decltype(PC)::value;
-                    dma_lanes_x4<pc * 16>(side + (uint32_t)(S::SIDE_RAW + pc * 1024), cro, csb);
+                    long off = (long)(k0 + 64 * wave) * 96 + pc * 1024 + lane * 16;
+                    off = off < last ? off : last;
+                    dma_lanes_x4<0>(side + (uint32_t)(S::SIDE_RAW + pc * 1024), (uint32_t)off, csb);
                 });
             }
         }
-        asm volatile(GTA_BWD64_DKV : : GTA_BWD64_OPERANDS : GTA_BWD64_CLOBBERS);
+        asm volatile(GTA_BWD64_DKV : : GTA_BWD64_DKV_OPERANDS : GTA_BWD64_DKV_CLOBBERS);
     }
     // the accumulators: dK'^T[kb][d] = a[16 (3 kb + d) ..], dV'^T[kb][d] = a[96 + 16 (3 kb + d) ..]
     f32x16_t dk[KB][DB], dv[KB][DB];
@@ -1076,8 +1076,8 @@ __global__ __launch_bounds__(256, 1) void gta_bwd_dkv64_kernel(const GtaBwdParam
                 } else {                                 // so2 chunks 9 (sl 4, high half), 10, 11: pieces 2 (c - 9), 2 (c - 9) + 1 of the key's (cos, sin) row
                     f32x2_t cs[4];
                     const int pc = 2 * (c - 9);
-                    const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(side + S::SIDE_RAW + (pc < 0 ? 0 : pc) * 1024 + kl * 16);
-                    const f32x4_t c1 = *reinterpret_cast<const f32x4_t*>(side + S::SIDE_RAW + (pc < 0 ? 1 : pc + 1) * 1024 + kl * 16);
+                    const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(side + S::SIDE_RAW + kl * 96 + (pc < 0 ? 0 : pc) * 16);
+                    const f32x4_t c1 = *reinterpret_cast<const f32x4_t*>(side + S::SIDE_RAW + kl * 96 + (pc < 0 ? 1 : pc + 1) * 16);
                     cs[0] = f32x2_t{c0.x, c0.y}; cs[1] = f32x2_t{c0.z, c0.w}; cs[2] = f32x2_t{c1.x, c1.y}; cs[3] = f32x2_t{c1.z, c1.w};
                     if constexpr (sl == 4) {
                         if (lh == 0) chunk_apply<true, 1>(DE, rc + BREC_MT, rc + BREC_D1T, rc + BREC_D2T, cs, x);        // chunk 8: so3
@@ -1097,6 +1097,188 @@ __global__ __launch_bounds__(256, 1) void gta_bwd_dkv64_kernel(const GtaBwdParam
         const int n_k128 = (p.Tk + 127) / 128;
         p.dc_partial[p.dc_off_dkv + bh * n_k128 + 2 * kt] = dc_wg;
         if (2 * kt + 1 < n_k128) p.dc_partial[p.dc_off_dkv + bh * n_k128 + 2 * kt + 1] = 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2b. dQ with 64 query rows per wave, one wave per SIMD, the walk over the key tiles ONE generated instruction stream (gen_bwd64.py:
+// GenDQ -> gta_bwd64_dq.inc; r04).  A workgroup owns 256 query rows of one (b, h); its waves keep the Q'' / dO~ fragments of 64 rows and
+// the dQ'^T accumulators in registers and stream the (b, h)'s K' / V' tile images through a ring of four LDS stages; every streamed
+// fragment feeds the wave's two 32-row blocks.  Whole key tiles (Tk % 64 == 0), bf16, dh = 96, MSN layout, no d tau (the compiled kernel
+// serves the rest).  Epilogue as gta_bwd_dkv64_kernel's: no staging, compile-time chunk descriptors, the rows' raw q chunks (d
+// trans_coeff) and (cos, sin) rows fetched by LDS-DMA before the walk.
+// ------------------------------------------------------------------------------------------------
+#include "gta_bwd64_dq.inc"
+struct Dq64Smem {
+    static constexpr int STAGE = 2 * BN * 96 * 2;
+    static constexpr int RING = GTA_BWD64_STAGES * STAGE;
+    static constexpr int OFF_SIDE = RING;
+    static constexpr int SIDE_RAW = 7 * 1024, SIDE_W = SIDE_RAW + 6 * 1024;      // per wave, row-major [row][96 B]: the se3 chunks of its 64 raw q rows, the rows' (cos, sin) rows
+    static constexpr int OFF_SCR = OFF_SIDE + 4 * SIDE_W;
+    static constexpr int OFF_REC = OFF_SCR + 32;
+    static_assert(GTA_BWD64_HI_BASE == 2 * STAGE, "gen_bwd64.py's LDS map");
+    static int total(int nviews) { return OFF_REC + nviews * BREC * 4; }
+};
+
+template <int ESZ>
+__global__ __launch_bounds__(256, 1) void gta_bwd_dq64_kernel(const GtaBwdParams p) {
+    using S = Dq64Smem;
+    constexpr int CHP = 12, DB = 3, BM = 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    int w;
+    {
+        const int nwg = gridDim.x, L = blockIdx.x;
+        const int xcd = L & 7, idx = L >> 3, q8 = nwg >> 3, r8 = nwg & 7;
+        w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int n_qblk = (p.Tq + BM - 1) / BM;
+    const int bh = w / n_qblk, qt = w - bh * n_qblk;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int q0 = qt * BM;
+    const int n_kt64 = (p.Tk + BN - 1) / BN;
+    const int n_qt64 = (p.Tq + BN - 1) / BN;
+    char* ring = smem;
+    float* rec = reinterpret_cast<float*>(smem + S::OFF_REC);
+
+    const int t_last = (q0 + BM - 1 < p.Tq ? q0 + BM - 1 : p.Tq - 1);
+    const int n_first = q0 / p.Pq;
+    const int n_cnt = t_last / p.Pq - n_first + 1;
+    const float tc = p.trans_coeff ? *p.trans_coeff : 1.0f;
+    if (p.vrep_q) stage_brec(rec, p.vrep_q, (long)b * p.Nq + n_first, n_cnt, 0, tc, tid, 256);
+
+    {
+        const uint32_t rb = lds_addr(ring);
+        auto koff_of = [&](int ks) { return (uint32_t)((l31 * CHP + swz<CHP>(l31, 2 * ks + lh)) * 16) + rb; };
+        const int g16 = lane >> 4, p16 = lane & 15;
+        auto voff_of = [&](int d, int hf) {
+            const int r = 4 * lh + (p16 >> 2) + 8 * hf, u = 4 * d + 2 * (g16 & 1) + ((p16 & 3) >> 1);
+            return (uint32_t)((r * CHP + swz<CHP>(r, u)) * 16 + (p16 & 1) * 8) + rb;
+        };
+        const uint32_t koffl = koff_of(0), koff4 = koff_of(4), koff5 = koff_of(5);
+        const uint32_t voff00 = voff_of(0, 0), voff01 = voff_of(0, 1), voff20 = voff_of(2, 0), voff21 = voff_of(2, 1);
+        constexpr uint32_t HB = GTA_BWD64_HI_BASE;
+        const uint32_t koffl_h = koffl + HB, koff4_h = koff4 + HB, koff5_h = koff5 + HB;
+        const uint32_t voff00_h = voff00 + HB, voff01_h = voff01 + HB, voff20_h = voff20 + HB, voff21_h = voff21 + HB;
+        const uint32_t lane16 = (uint32_t)lane * 16u, lrow4 = (uint32_t)l31 * 4u;
+        // this wave's 64 rows = 64-row tile 4 qt + wave of the (b, h) (a tile past the end: the last one's images again -- nothing of it is stored)
+        int my_tile = 4 * qt + wave;
+        my_tile = my_tile < n_qt64 ? my_tile : n_qt64 - 1;
+        const char* qi = (const char*)p.qimg + (((long)b * p.H + h) * n_qt64 + my_tile) * (long)S::STAGE;
+        const float* st = p.stats + (((long)b * p.H + h) * n_qt64 + my_tile) * 128;
+        const char* kv = (const char*)p.kvimg + ((long)b * p.H + h) * n_kt64 * (long)S::STAGE;
+        const uint32_t qi_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)qi), qi_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)qi >> 32));
+        const uint32_t st_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)st), st_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)st >> 32));
+        const uint32_t kv_lo = (uint32_t)(uintptr_t)kv, kv_hi = (uint32_t)((uintptr_t)kv >> 32);
+        const uint32_t n = (uint32_t)n_kt64, ring_s = __builtin_amdgcn_readfirstlane(rb);
+        const uint32_t ring = ring_s;
+        {
+            // the first 96 bytes (chunks 0..5, se3: d trans_coeff) of this wave's 64 raw q rows and the rows' (cos, sin) rows -> its side buffer,
+            // both ROW-MAJOR [row][96 B]: a DMA operation's lanes walk (row, 16-byte piece) pairs, so a row's cache line is touched once (lane
+            // l of raw operation i: row 10 i + l / 6, piece l % 6 -- lanes 60..63 already write the next operation's first pieces, the same
+            // bytes; the (cos, sin) rows of consecutive tokens are contiguous: six linear KiB).  Rows past Tq: the last row's.  The epilogue
+            // reads them from LDS, their latency lies under the walk
+            const uint32_t side = ring_s + (uint32_t)(S::OFF_SIDE + wave * S::SIDE_W);
+            const char* qgs = (const char*)p.q + ((long)b * p.q_sb + (long)h * p.q_sh) * ESZ;
+            const int rowl = lane / 6, piece = lane - 6 * rowl;
+            static_for_bwd<7>([&](auto OC) {
+                constexpr int i = decltype(OC)::value;
+                int tq = q0 + 64 * wave + 10 * i + rowl;
+                tq = tq < p.Tq ? tq : p.Tq - 1;
+                dma_lanes_x4<0>(side + (uint32_t)(i * 960), (uint32_t)((long)tq * p.q_st * ESZ) + (uint32_t)piece * 16u, qgs);
+            });
+            if (p.cs_q) {
+                const float* csb = p.cs_q + (long)b * p.Tq * 2 * p.nso2;
+                const long last = (long)p.Tq * 96 - 16;                       // (96 bytes per token: nso2 = 12)
+                static_for_bwd<6>([&](auto PC) {
+                    constexpr int pc = decltype(PC)::value;
+                    long off = (long)(q0 + 64 * wave) * 96 + pc * 1024 + lane * 16;
+                    off = off < last ? off : last;
+                    dma_lanes_x4<0>(side + (uint32_t)(S::SIDE_RAW + pc * 1024), (uint32_t)off, csb);
+                });
+            }
+        }
+        asm volatile(GTA_BWD64_DQ : : GTA_BWD64_DQ_OPERANDS : GTA_BWD64_DQ_CLOBBERS);
+    }
+    // the accumulators: dQ'^T[rb][d] = a[16 (3 rb + d) ..]
+    f32x16_t dq[2][DB];
+#define GTA_ACC16(DST, BASE) asm volatile( \
+        "v_accvgpr_read_b32 %0, a[" #BASE "+0]\n\tv_accvgpr_read_b32 %1, a[" #BASE "+1]\n\tv_accvgpr_read_b32 %2, a[" #BASE "+2]\n\tv_accvgpr_read_b32 %3, a[" #BASE "+3]\n\t" \
+        "v_accvgpr_read_b32 %4, a[" #BASE "+4]\n\tv_accvgpr_read_b32 %5, a[" #BASE "+5]\n\tv_accvgpr_read_b32 %6, a[" #BASE "+6]\n\tv_accvgpr_read_b32 %7, a[" #BASE "+7]\n\t" \
+        "v_accvgpr_read_b32 %8, a[" #BASE "+8]\n\tv_accvgpr_read_b32 %9, a[" #BASE "+9]\n\tv_accvgpr_read_b32 %10, a[" #BASE "+10]\n\tv_accvgpr_read_b32 %11, a[" #BASE "+11]\n\t" \
+        "v_accvgpr_read_b32 %12, a[" #BASE "+12]\n\tv_accvgpr_read_b32 %13, a[" #BASE "+13]\n\tv_accvgpr_read_b32 %14, a[" #BASE "+14]\n\tv_accvgpr_read_b32 %15, a[" #BASE "+15]" \
+        : "=v"(DST[0]), "=v"(DST[1]), "=v"(DST[2]), "=v"(DST[3]), "=v"(DST[4]), "=v"(DST[5]), "=v"(DST[6]), "=v"(DST[7]), \
+          "=v"(DST[8]), "=v"(DST[9]), "=v"(DST[10]), "=v"(DST[11]), "=v"(DST[12]), "=v"(DST[13]), "=v"(DST[14]), "=v"(DST[15]))
+    {
+        float t[16];
+#define GTA_ACC(RB, D, BASE) GTA_ACC16(t, BASE); _Pragma("unroll") for (int i = 0; i < 16; ++i) dq[RB][D][i] = t[i];
+        GTA_ACC(0, 0, 0) GTA_ACC(0, 1, 16) GTA_ACC(0, 2, 32) GTA_ACC(1, 0, 48) GTA_ACC(1, 1, 64) GTA_ACC(1, 2, 80)
+#undef GTA_ACC
+#undef GTA_ACC16
+    }
+
+    // ---- epilogue: dq = A_q^T (c1 dQ') ; d trans_coeff through A_q.  As gta_bwd_dkv64_kernel's: lane (row l31, half lh) of a 32-row block holds
+    // channels 32 d + 8 g + 4 lh + i of ITS row, one v_permlane32_swap per value hands the low lane half the even chunk of a pair, the high half the odd one ----
+    const float c1 = p.scale / (p.tau ? *p.tau : 1.0f);
+    char* dqg = (char*)p.dq + ((long)b * p.dq_sb + (long)h * p.dq_sh) * ESZ;
+    float dcpart = 0.f;
+    __syncthreads();
+    const char* side = smem + S::OFF_SIDE + wave * S::SIDE_W;
+#pragma unroll
+    for (int rbk = 0; rbk < 2; ++rbk) {
+        const int rl = 32 * rbk + l31;                   // the lane's row of this pass, within the wave
+        const int t = q0 + 64 * wave + rl;
+        const bool valid = t < p.Tq;
+        const float* rc = rec + (view_of(valid ? t : p.Tq - 1, p.Pq, p.invPq) - n_first) * BREC;
+        static_for_bwd<2 * DB>([&](auto SC) {
+            constexpr int sl = decltype(SC)::value, d = sl >> 1, gp = sl & 1;
+            constexpr uint32_t DE = gta_layout_desc(GTA_LAYOUT_MS, 2 * sl), DO = gta_layout_desc(GTA_LAYOUT_MS, 2 * sl + 1);
+            const f32x16_t& acc = dq[rbk][d];
+            float x[1][8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float fa = acc[8 * gp + i] * c1, fb = acc[8 * gp + 4 + i] * c1;
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(fa), __float_as_uint(fb), false, false);   // fa[32..63] <-> fb[0..31]
+                x[0][i] = __uint_as_float(sw[0]);
+                x[0][4 + i] = __uint_as_float(sw[1]);
+            }
+            const int c = 2 * sl + lh;
+            if constexpr (sl < 3) {                      // se3 | se3: d trans_coeff = dq'_3 (t_E . q_{0:3}) per 4-vector, then A_q^T
+                float q8[8];
+                unpack8(*reinterpret_cast<const u32x4_t*>(side + rl * 96 + c * 16), q8);
+                const float t0 = rc[BREC_T], t1 = rc[BREC_T + 1], t2 = rc[BREC_T + 2];
+                if (valid) {
+                    dcpart += x[0][3] * (t0 * q8[0] + t1 * q8[1] + t2 * q8[2]);
+                    dcpart += x[0][7] * (t0 * q8[4] + t1 * q8[5] + t2 * q8[6]);
+                }
+                chunk_apply<true, 1>(DE, rc + BREC_MT, rc + BREC_D1T, rc + BREC_D2T, nullptr, x);
+            } else if constexpr (sl == 3) {
+                chunk_apply<true, 1>(DE, rc + BREC_MT, rc + BREC_D1T, rc + BREC_D2T, nullptr, x);
+            } else {
+                f32x2_t cs[4];
+                const int pc = 2 * (c - 9);
+                const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(side + S::SIDE_RAW + rl * 96 + (pc < 0 ? 0 : pc) * 16);
+                const f32x4_t c1v = *reinterpret_cast<const f32x4_t*>(side + S::SIDE_RAW + rl * 96 + (pc < 0 ? 1 : pc + 1) * 16);
+                cs[0] = f32x2_t{c0.x, c0.y}; cs[1] = f32x2_t{c0.z, c0.w}; cs[2] = f32x2_t{c1v.x, c1v.y}; cs[3] = f32x2_t{c1v.z, c1v.w};
+                if constexpr (sl == 4) {
+                    if (lh == 0) chunk_apply<true, 1>(DE, rc + BREC_MT, rc + BREC_D1T, rc + BREC_D2T, cs, x);
+                    else chunk_apply<true, 1>(DO, rc + BREC_MT, rc + BREC_D1T, rc + BREC_D2T, cs, x);
+                } else {
+                    chunk_apply<true, 1>(DE, rc + BREC_MT, rc + BREC_D1T, rc + BREC_D2T, cs, x);
+                }
+            }
+            if (valid) g_store_chunk<ESZ>(dqg + (long)t * p.dq_st * ESZ, c, x[0]);
+        });
+    }
+    __syncthreads();
+    const float dc_wg = wg_sum256(dcpart, reinterpret_cast<float*>(smem + S::OFF_SCR), tid);
+    if (tid == 0) {                                      // the partials' slots are per 128 rows (gta_abi.cpp): this workgroup owns two of them
+        const int n_q128 = (p.Tq + 127) / 128;
+        p.dc_partial[p.dc_off_dq + bh * n_q128 + 2 * qt] = dc_wg;
+        if (2 * qt + 1 < n_q128) p.dc_partial[p.dc_off_dq + bh * n_q128 + 2 * qt + 1] = 0.f;
     }
 }
 
@@ -1129,15 +1311,30 @@ int run_bwd(const GtaBwdParams& p, hipStream_t stream) {
     hipLaunchKernelGGL((gta_bwd_prep_kernel<DHP, ESZ>), dim3((unsigned)prep_grid), dim3(256), lds_prep, stream, p);
     const int n_dq = p.B * p.H * ((p.Tq + 127) / 128);
     const int n_dkv = p.B * p.H * ((p.Tk + 127) / 128);
-    hipLaunchKernelGGL((gta_bwd_dq_kernel<DHP, ESZ>), dim3(n_dq), dim3(256), DqSmem<DHP>::total(p.vrep_q ? p.Nq : 0), stream, p);
+    bool ms_layout = false;
+    if constexpr (DHP == 96 && ESZ == 2) {
+        ms_layout = p.dh == 96 && p.nso2 == 12;          // (the generated kernels' epilogues are written for the MSN chunk layout)
+        for (int c = 0; c < 12; ++c) ms_layout = ms_layout && p.ctab[c] == gta_layout_desc(GTA_LAYOUT_MS, c);
+    }
+    bool dq64 = false;
+    if constexpr (DHP == 96 && ESZ == 2) {
+        // 64 rows per wave / 256 per workgroup (the generated stream) where that fills the chip at one workgroup per CU
+        const long n_dq64 = (long)p.B * p.H * ((p.Tq + 255) / 256);
+        dq64 = ms_layout && p.Tk % BN == 0 && p.dt_partial == nullptr && Dq64Smem::total(p.vrep_q ? p.Nq : 0) <= 160 * 1024 &&
+               (long)p.Tq * p.q_st * ESZ < (1L << 31) && (n_dq64 >= 2 * 256 || (p.flags & GTA_FLAG_BWD_KEYS64)) && !(p.flags & GTA_FLAG_BWD_KEYS32);
+        if (dq64) {
+            if (int rc = gta_lds_optin<&gta_bwd_dq64_kernel<ESZ>>(Dq64Smem::total(GTA_MAX_VIEWS))) return rc;
+            hipLaunchKernelGGL((gta_bwd_dq64_kernel<ESZ>), dim3((unsigned)n_dq64), dim3(256), Dq64Smem::total(p.vrep_q ? p.Nq : 0), stream, p);
+        }
+    }
+    if (!dq64)
+        hipLaunchKernelGGL((gta_bwd_dq_kernel<DHP, ESZ>), dim3(n_dq), dim3(256), DqSmem<DHP>::total(p.vrep_q ? p.Nq : 0), stream, p);
     bool dkv64 = false;
     if constexpr (DHP == 96 && ESZ == 2) {
         // 64 keys per wave / 256 per workgroup (the generated stream) where that fills the chip at one workgroup per CU; otherwise the
         // 128-key kernel's finer grain
         const long n_dkv64 = (long)p.B * p.H * ((p.Tk + 255) / 256);
-        bool ms = p.dh == 96 && p.nso2 == 12 && Dkv64Smem::total(p.vrep_k ? p.Nk : 0) <= 160 * 1024 && (long)p.Tk * p.k_st * ESZ < (1L << 31) &&
-                  (long)p.Tk * p.v_st * ESZ < (1L << 31);          // (the kernel's epilogue is written for the MSN chunk layout)
-        for (int c = 0; c < 12; ++c) ms = ms && p.ctab[c] == gta_layout_desc(GTA_LAYOUT_MS, c);
+        const bool ms = ms_layout && Dkv64Smem::total(p.vrep_k ? p.Nk : 0) <= 160 * 1024;
         dkv64 = ms && (n_dkv64 >= 2 * 256 || (p.flags & GTA_FLAG_BWD_KEYS64)) && !(p.flags & GTA_FLAG_BWD_KEYS32);
 #ifdef GTA_ATTN64_DIAG
         if (const char* e = getenv("GTA_BWD_DKV64")) dkv64 = atoi(e) != 0;

@@ -162,9 +162,10 @@ def test_backward_is_bit_reproducible(shape, dtype):
 
 @pytest.mark.parametrize("shape", ["MS-enc", "MS-dec", "ragged-ms"])
 def test_dkv64_stream_matches_keys32_kernel_bit_for_bit(shape):
-    """gta_bwd_dkv64_kernel (64 keys per wave, the tile loop ONE generated instruction stream: gen_bwd64.py) against gta_bwd_dkv_kernel
-    (32 keys per wave, compiled): per (key, query) the same arithmetic and per accumulator the same order of query tiles, so dk and dv agree
-    bit for bit (dq comes from the same kernel in both runs; d trans_coeff sums the same per-key terms in another grouping)."""
+    """gta_bwd_dkv64_kernel / gta_bwd_dq64_kernel (64 keys / 64 query rows per wave, the walks ONE generated instruction stream each:
+    gen_bwd64.py) against gta_bwd_dkv_kernel / gta_bwd_dq_kernel (32 per wave, compiled): per (key, query) the same arithmetic and per
+    accumulator the same order of tiles, so dq, dk and dv agree bit for bit (d trans_coeff sums the same per-token terms in another
+    grouping).  The ragged shape's key side is not whole tiles: its dq comes from the compiled kernel in both runs."""
     shapes = dict(SHAPES)
     shapes["ragged-ms"] = (2, 3, 3, 100, 3, 150, {"se3": 48, "so3": 24, "so2": 24}, 6, 2)      # Tq = 300 (5 query tiles, the last ragged), Tk = 450 (2 key blocks, ragged)
     B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3 = shapes[shape]

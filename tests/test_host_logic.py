@@ -330,6 +330,45 @@ def test_dkv64_stream_generator_simulates_and_is_current():
         assert open(out).read() == open(os.path.join(d, "gta_bwd64_dkv.inc")).read(), "gta_bwd64_dkv.inc is stale: make -C gta_amd/csrc regen"
 
 
+def test_dq64_stream_generator_simulates_and_is_current():
+    """the same for the dQ walk of gta_bwd_dq64_kernel (gen_bwd64.py: GenDQ -- 64 query rows per wave, the Q'' / dO~ fragments stationary, the
+    K' / V' tiles streamed): executed for 1, 2, 5 and 6 key tiles against a numpy model of dQ'^T, wait states on the executed order, the
+    assembler, the committed gta_bwd64_dq.inc."""
+    import os
+    import tempfile
+    g, d = _load_csrc_module("gen_bwd64")
+    st = g.check_dq()
+    assert st["mfma"] == 360 and st["instructions"] < 2100, st          # tile 0: 48; four stage copies of 72; the tail: 24
+    prog = g.GenDQ().program()
+    if os.path.exists("/opt/rocm/lib/llvm/bin/clang"):
+        assert g.assemble_check(prog, g.Q_VOPS, g.Q_SOPS)
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "dq.inc")
+        g.emit(out, prog, "GTA_BWD64_DQ", g.Q_VOPS, g.Q_SOPS)
+        assert open(out).read() == open(os.path.join(d, "gta_bwd64_dq.inc")).read(), "gta_bwd64_dq.inc is stale: make -C gta_amd/csrc regen"
+
+
+@pytest.mark.parametrize("fault", ["half_offset", "pair_operand", "seed", "early_wait"])
+def test_dq64_stream_simulation_catches_faults(fault):
+    """a key half's fragments read from the other half, a dQ MFMA fed with the pair's other transposed operand, the -D seed in place of
+    -lse2, a DMA wait that lets a tile's pieces be late"""
+    import os
+    g, d = _load_csrc_module("gen_bwd64")
+    src = open(os.path.join(d, "gen_bwd64.py")).read()
+    old, new = {
+        "half_offset": ("a.ds_read(128, slot[0:4], reg, base + hh * HALF + imm)", "a.ds_read(128, slot[0:4], reg, base + (1 - hh) * HALF + imm)"),
+        "pair_operand": ("a.mfma(DQ[rb][d], slot[4 * i:4 * i + 4], se[\"e\"][rb][4 * t:4 * t + 4], DQ[rb][d])",
+                         "a.mfma(DQ[rb][d], slot[4 * (1 - i):4 * (1 - i) + 4], se[\"e\"][rb][4 * t:4 * t + 4], DQ[rb][d])"),
+        "seed": ("QINIT_L[rb] if ks == 0 else se[\"s\"][rb])", "QINIT_D[rb] if ks == 0 else se[\"s\"][rb])"),
+        "early_wait": ("        a.waitcnt(vm=6)\n        a.barrier()", "        a.waitcnt(vm=8)\n        a.barrier()"),
+    }[fault]
+    assert old in src, fault
+    ns = {"__name__": "gen_bwd64_fault"}
+    exec(compile(src.replace(old, new, 1), "gen_bwd64_fault.py", "exec"), ns)
+    with pytest.raises(g.CheckError):
+        ns["check_dq"](cases=((5, 3),))
+
+
 @pytest.mark.parametrize("fault", ["fragment_offset", "tr_offset", "early_wait", "operand_swap", "pack_order", "init_rows", "stage_reuse"])
 def test_dkv64_stream_simulation_catches_faults(fault):
     """the simulation objects to what it is there for: a wrong fragment or transpose-read offset, a DMA wait that lets a tile's pieces be
@@ -368,7 +407,7 @@ def test_dkv64_kernel_leaves_the_register_files_to_the_stream():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     report, problems = mod.audit_dkv64()
-    assert report and report[0]["loop_statements"] == 1, report
+    assert len(report) == 2 and all(r["loop_statements"] == 1 for r in report), report       # gta_bwd_dkv64_kernel, gta_bwd_dq64_kernel
     assert not problems, problems
 
 

@@ -105,7 +105,7 @@ def audit_dkv64():
     holds 192 accumulator values beside its own)."""
     text = _asm("gta_bwd.hip", ("-fno-slp-vectorize",))
     report, problems = [], []
-    for m in re.finditer(r"^(_ZN\w*gta_bwd_dkv64_kernel\w+):", text, re.M):
+    for m in re.finditer(r"^(_ZN\w*gta_bwd_(?:dkv|dq)64_kernel\w+):", text, re.M):
         name = m.group(1)
         body = text[m.start():text.index(".Lfunc_end", m.start())]
         meta = text[text.index(".amdhsa_kernel " + name):][:4000]
@@ -128,13 +128,13 @@ def audit_dkv64():
         report.append({"kernel": name, "vgpr": vgpr, "accum_offset": accum, "compiler_agpr_uses": compiler_acc, "scratch": scratch,
                        "loop_statements": long_stmts})
         if compiler_acc:
-            problems.append(f"gta_bwd_dkv64_kernel: hipcc touches accumulator registers itself ({compiler_acc} operands)")
+            problems.append(f"{name}: hipcc touches accumulator registers itself ({compiler_acc} operands)")
         if long_stmts != 1:
-            problems.append(f"gta_bwd_dkv64_kernel: {long_stmts} generated statements (expected one)")
+            problems.append(f"{name}: {long_stmts} generated statements (expected one)")
         if vgpr != 512 or accum != 256:
-            problems.append(f"gta_bwd_dkv64_kernel: register file split {accum} / {vgpr} (expected 256 / 512)")
+            problems.append(f"{name}: register file split {accum} / {vgpr} (expected 256 / 512)")
         if scratch > 8:
-            problems.append(f"gta_bwd_dkv64_kernel: {scratch} scratch accesses")
+            problems.append(f"{name}: {scratch} scratch accesses")
     return report, problems
 
 
