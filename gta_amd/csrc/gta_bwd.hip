@@ -1336,9 +1336,6 @@ int run_bwd(const GtaBwdParams& p, hipStream_t stream) {
         const long n_dkv64 = (long)p.B * p.H * ((p.Tk + 255) / 256);
         const bool ms = ms_layout && Dkv64Smem::total(p.vrep_k ? p.Nk : 0) <= 160 * 1024;
         dkv64 = ms && (n_dkv64 >= 2 * 256 || (p.flags & GTA_FLAG_BWD_KEYS64)) && !(p.flags & GTA_FLAG_BWD_KEYS32);
-#ifdef GTA_ATTN64_DIAG
-        if (const char* e = getenv("GTA_BWD_DKV64")) dkv64 = atoi(e) != 0;
-#endif
         if (dkv64) {
             if (int rc = gta_lds_optin<&gta_bwd_dkv64_kernel<ESZ>>(Dkv64Smem::total(GTA_MAX_VIEWS))) return rc;
             hipLaunchKernelGGL((gta_bwd_dkv64_kernel<ESZ>), dim3((unsigned)n_dkv64), dim3(256), Dkv64Smem::total(p.vrep_k ? p.Nk : 0), stream, p);
