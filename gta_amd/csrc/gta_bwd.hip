@@ -1318,10 +1318,11 @@ int run_bwd(const GtaBwdParams& p, hipStream_t stream) {
     }
     bool dq64 = false;
     if constexpr (DHP == 96 && ESZ == 2) {
-        // 64 rows per wave / 256 per workgroup (the generated stream) where that fills the chip at one workgroup per CU
+        // 64 rows per wave / 256 per workgroup (the generated stream) from half a chip of workgroups on (measured at B = 4 .. 32 per GPU at the MSN shape:
+        // ahead at every size; below that the 128-row kernel's finer grain spreads the work over more CUs)
         const long n_dq64 = (long)p.B * p.H * ((p.Tq + 255) / 256);
         dq64 = ms_layout && p.Tk % BN == 0 && p.dt_partial == nullptr && Dq64Smem::total(p.vrep_q ? p.Nq : 0) <= 160 * 1024 &&
-               (long)p.Tq * p.q_st * ESZ < (1L << 31) && (n_dq64 >= 2 * 256 || (p.flags & GTA_FLAG_BWD_KEYS64)) && !(p.flags & GTA_FLAG_BWD_KEYS32);
+               (long)p.Tq * p.q_st * ESZ < (1L << 31) && (n_dq64 >= 128 || (p.flags & GTA_FLAG_BWD_KEYS64)) && !(p.flags & GTA_FLAG_BWD_KEYS32);
         if (dq64) {
             if (int rc = gta_lds_optin<&gta_bwd_dq64_kernel<ESZ>>(Dq64Smem::total(GTA_MAX_VIEWS))) return rc;
             hipLaunchKernelGGL((gta_bwd_dq64_kernel<ESZ>), dim3((unsigned)n_dq64), dim3(256), Dq64Smem::total(p.vrep_q ? p.Nq : 0), stream, p);
@@ -1331,11 +1332,10 @@ int run_bwd(const GtaBwdParams& p, hipStream_t stream) {
         hipLaunchKernelGGL((gta_bwd_dq_kernel<DHP, ESZ>), dim3(n_dq), dim3(256), DqSmem<DHP>::total(p.vrep_q ? p.Nq : 0), stream, p);
     bool dkv64 = false;
     if constexpr (DHP == 96 && ESZ == 2) {
-        // 64 keys per wave / 256 per workgroup (the generated stream) where that fills the chip at one workgroup per CU; otherwise the
-        // 128-key kernel's finer grain
+        // 64 keys per wave / 256 per workgroup (the generated stream) from half a chip of workgroups on; otherwise the 128-key kernel's finer grain
         const long n_dkv64 = (long)p.B * p.H * ((p.Tk + 255) / 256);
         const bool ms = ms_layout && Dkv64Smem::total(p.vrep_k ? p.Nk : 0) <= 160 * 1024;
-        dkv64 = ms && (n_dkv64 >= 2 * 256 || (p.flags & GTA_FLAG_BWD_KEYS64)) && !(p.flags & GTA_FLAG_BWD_KEYS32);
+        dkv64 = ms && (n_dkv64 >= 128 || (p.flags & GTA_FLAG_BWD_KEYS64)) && !(p.flags & GTA_FLAG_BWD_KEYS32);
         if (dkv64) {
             if (int rc = gta_lds_optin<&gta_bwd_dkv64_kernel<ESZ>>(Dkv64Smem::total(GTA_MAX_VIEWS))) return rc;
             hipLaunchKernelGGL((gta_bwd_dkv64_kernel<ESZ>), dim3((unsigned)n_dkv64), dim3(256), Dkv64Smem::total(p.vrep_k ? p.Nk : 0), stream, p);
