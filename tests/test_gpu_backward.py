@@ -191,3 +191,36 @@ def test_dkv64_stream_matches_keys32_kernel_bit_for_bit(shape):
     assert torch.equal(a[2], b[2]), (a[2] - b[2]).abs().max()
     assert torch.equal(a[1], b[1]), (a[1] - b[1]).abs().max()
     assert abs(a[3] - b[3]) <= 1e-4 * max(1.0, abs(a[3])), (a[3], b[3])
+
+
+@pytest.mark.parametrize("shape", ["MS-enc", "MS-dec"])
+def test_generated_backward_kernels_vs_oracle_autograd(shape):
+    """the generated dQ and dK/dV kernels (forced: the shapes are below their launch-size threshold) against autograd through the oracle, with
+    the bounds of test_gradients_vs_oracle_autograd"""
+    from oracle import gta_oracle as O
+    B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3 = SHAPES[shape]
+    q, k, v, ex, ak, cross = C.synth_inputs(B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, torch.bfloat16, seed=7)
+    q, k, v = q.bfloat16().float(), k.bfloat16().float(), v.bfloat16().float()
+    w = torch.randn(q.shape, generator=torch.Generator().manual_seed(11))
+    qo, ko, vo = (t.clone().requires_grad_() for t in (q, k, v))
+    tco = torch.tensor([0.37], requires_grad=True)
+    reps = O.encoder_reps(ak, ex)
+    if cross:
+        reps = O.decoder_reps(ak, ex, reps)
+    out_o, _ = O.gta_attention(qo, ko, vo, f_dims, reps, tco)
+    (out_o * w).sum().backward()
+    exd = {kk: vv.cuda() for kk, vv in ex.items()}
+    gta_amd.pre_compute_reps_encoder(ak, exd)
+    if cross:
+        gta_amd.pre_compute_reps_decoder(ak, exd)
+    packed = gta_amd.pack_reps(exd, f_dims)
+    qd, kd, vd = (t.bfloat16().cuda().requires_grad_() for t in (q, k, v))
+    tcd = torch.tensor([0.37], device="cuda", requires_grad=True)
+    out = gta_amd.gta_attention(qd, kd, vd, f_dims, packed, so3_degree=exd.get("gta_so3_degree", 0), trans_coeff=tcd, kv_mode="prepass_bwd_keys64")
+    (out.float() * w.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    _check(out.float().cpu(), out_o.detach(), "out", 2.5e-2, 1.2e-2)
+    for name, a, b in (("dq", qd, qo), ("dk", kd, ko), ("dv", vd, vo)):
+        _check(a.grad.float().cpu(), b.grad, name)
+    ref, got = float(tco.grad.item()), float(tcd.grad.item())
+    assert abs(got - ref) <= 3e-2 * max(1.0, abs(ref)), (got, ref)
