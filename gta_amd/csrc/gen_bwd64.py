@@ -104,8 +104,9 @@ class Group:
 
 
 class Gen:
-    def __init__(self, sched=True):
+    def __init__(self, sched=True, by_cost=True):
         self.sched = sched
+        self.by_cost = by_cost
 
     # ---- addresses ----
     @staticmethod
@@ -233,47 +234,69 @@ class Gen:
             c(a)
 
     # ---- weaving: MFMA groups with the loads PF groups ahead and a share of the VALU list in their gaps ----
+    COST = {"trans": 16, "valu": 5, "ds": 10, "dma": 12, "salu": 2, "nop": 4, "wait": 0, "dsw": 10}      # (8 .. 24 / 6 .. 16 for the first and third: no difference on the GPU)
+
     def weave(self, a, groups, valu, first_slot, extra=None, preloaded=0):
-        """groups: the MFMA groups in order; valu: [(first group, last group, [closures])]: each list is dealt evenly over the gaps of its
-        group range; extra: {group index: [closures]} issued with that group's loads.  Loads of groups [0, preloaded) are already out.
-        Returns the slot index after the last group."""
+        """groups: the MFMA groups in order; valu: [(first group, last group, [closures])]: each list is dealt over the gaps of its group range
+        BY ISSUE COST (a matrix instruction leaves ~28 cycles of issue behind it: a v_exp_f32 takes 16 of them, a plain VALU instruction 5, an LDS
+        read ~10), counting what the gaps already hold; extra: {group index: [closures]} issued with that group's loads.  Loads of groups
+        [0, preloaded) are already out.  Returns the slot index after the last group."""
         extra = extra or {}
         n = len(groups)
-        per_gap = {}
-        for g0, g1, lst in valu:
-            gaps = [(g, m) for g in range(g0, g1 + 1) for m in range(4)]
-            for i, c in enumerate(lst):
-                per_gap.setdefault(gaps[i * len(gaps) // len(lst)], []).append(c)
+        cost = lambda x: self.COST.get(x.kind, 4)
         for g in range(min(PF, n)):
             if g >= preloaded:
                 groups[g].loads(a, SLOT[(first_slot + g) % 4])
+        # what every gap holds anyway: the loads of the group PF ahead (and the extras), over the gaps behind the group's MFMAs 1..3
+        mf, gap = [], {}
         for g, grp in enumerate(groups):
-            slot = SLOT[(first_slot + g) % 4]
             body = Asm()
-            grp.mfmas(body, slot)
+            grp.mfmas(body, SLOT[(first_slot + g) % 4])
+            mf.append(list(body.out))
             ld = Asm()
             if g + PF < n:
                 groups[g + PF].loads(ld, SLOT[(first_slot + g + PF) % 4])
             for c in extra.get(g, []):
                 c(ld)
             lds = list(ld.out)
-            for m, ins in enumerate(body.out):
-                a.raw(ins)
-                if not self.sched:
-                    continue
+            for m in range(4):
+                gap[(g, m)] = []
                 if lds and m >= 1:                                     # (a slot is re-loaded once the group PF + 1 back has issued its MFMAs)
                     k = (len(lds) + (3 - m)) // (4 - m)
-                    for x in lds[:k]:
-                        a.raw(x)
+                    gap[(g, m)] += lds[:k]
                     del lds[:k]
-                for c in per_gap.get((g, m), []):
-                    c(a)
-            if not self.sched:
-                for x in lds:
-                    a.raw(x)
+        for g0, g1, lst in valu:
+            tmp = Asm()
+            for c in lst:
+                c(tmp)
+            ops = list(tmp.out)
+            gaps = [(g, m) for g in range(g0, g1 + 1) for m in range(4)]
+            if not self.sched or not self.by_cost:
+                for i, x in enumerate(ops):
+                    gap[gaps[i * len(gaps) // len(ops)]].append(x)
+                continue
+            fixed = [sum(cost(x) for x in gap[k]) for k in gaps]
+            target = (sum(fixed) + sum(cost(x) for x in ops)) / len(gaps)
+            gi, cum = 0, fixed[0]
+            for x in ops:
+                c = cost(x)
+                while gi < len(gaps) - 1 and cum + c / 2 > target * (gi + 1):
+                    gi += 1
+                    cum += fixed[gi]
+                gap[gaps[gi]].append(x)
+                cum += c
+        for g in range(n):
+            if self.sched:
+                for m, ins in enumerate(mf[g]):
+                    a.raw(ins)
+                    for x in gap[(g, m)]:
+                        a.raw(x)
+            else:
+                for ins in mf[g]:
+                    a.raw(ins)
                 for m in range(4):
-                    for c in per_gap.get((g, m), []):
-                        c(a)
+                    for x in gap[(g, m)]:
+                        a.raw(x)
         return (first_slot + n) % 4
 
     # ---- the statement ----
