@@ -224,3 +224,25 @@ def test_generated_backward_kernels_vs_oracle_autograd(shape):
         _check(a.grad.float().cpu(), b.grad, name)
     ref, got = float(tco.grad.item()), float(tcd.grad.item())
     assert abs(got - ref) <= 3e-2 * max(1.0, abs(ref)), (got, ref)
+
+
+@pytest.mark.parametrize("shape", ["MS-enc", "MS-dec"])
+def test_generated_backward_is_bit_reproducible(shape):
+    """two runs of the generated dQ / dK/dV kernels on the same inputs agree bit for bit (no atomics; d trans_coeff is a fixed-order sum)"""
+    B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3 = SHAPES[shape]
+    q, k, v, ex, ak, cross = C.synth_inputs(B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, torch.bfloat16, seed=23)
+    w = torch.randn(q.shape, generator=torch.Generator().manual_seed(29)).cuda()
+    exd = {kk: vv.cuda() for kk, vv in ex.items()}
+    gta_amd.pre_compute_reps_encoder(ak, exd)
+    if cross:
+        gta_amd.pre_compute_reps_decoder(ak, exd)
+    packed = gta_amd.pack_reps(exd, f_dims)
+    res = {}
+    for run in range(2):
+        qd, kd, vd = (t.bfloat16().cuda().requires_grad_() for t in (q, k, v))
+        tcd = torch.tensor([0.37], device="cuda", requires_grad=True)
+        out = gta_amd.gta_attention(qd, kd, vd, f_dims, packed, so3_degree=exd.get("gta_so3_degree", 0), trans_coeff=tcd, kv_mode="prepass_bwd_keys64")
+        (out.float() * w).sum().backward()
+        torch.cuda.synchronize()
+        res[run] = (qd.grad.float().cpu(), kd.grad.float().cpu(), vd.grad.float().cpu(), float(tcd.grad.item()))
+    assert all(torch.equal(res[0][i], res[1][i]) for i in range(3)) and res[0][3] == res[1][3]
