@@ -209,7 +209,11 @@ __global__ __launch_bounds__(256) void gta_kv_prep_kernel(const GtaFwdParams p) 
                 }
             };
             if (c < ch_real && valid) {
+#ifdef GTA_PREP_ABL          // timing-only ablation (tools/r04_ablate_prep.sh): no transform
+                const uint32_t desc = 0u;
+#else
                 const uint32_t desc = xf ? p.ctab[c] : 0u;
+#endif
                 const uint32_t lo = cd_lo(desc), hi = cd_hi(desc);
                 if (desc == 0) {
                     run([](float (*)[8]) {});
@@ -274,7 +278,9 @@ __global__ __launch_bounds__(256) void gta_kv_prep_kernel(const GtaFwdParams p) 
         if (lane == 0) p.kn[((long)b * p.H + h) * n_tiles + j] = sqrtf(tot) * 1.0001f;
     }
     if constexpr (!JOINT) {
+#if !defined(GTA_PREP_ABL) || GTA_PREP_ABL < 2      // (level 2: the V rows go out as they came in)
         if (xv) pass(std::false_type{}, std::true_type{}, std::false_type{}); else pass(std::false_type{}, std::false_type{}, std::false_type{});
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // (the K' stores may still be in flight)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
