@@ -925,21 +925,20 @@ struct Dkv64Smem {
     static constexpr int OFF_SCR = OFF_SIDE + 4 * SIDE_W;
     static constexpr int OFF_REC = OFF_SCR + 32;
     static_assert(OFF_STATS == GTA_BWD64_OFF_STATS && GTA_BWD64_HI_BASE == 2 * STAGE, "gen_bwd64.py's LDS map");
-    static int total(int nviews) { return OFF_REC + nviews * BREC * 4; }
+    static constexpr int total(int nviews) { return OFF_REC + nviews * BREC * 4; }
 };
 
+// (body: workgroup L of nwg of this kernel's grid -- its own launch, or its share of the joint launch gta_bwd_dqkv64_kernel below)
 template <int ESZ>
-__global__ __launch_bounds__(256, 1) void gta_bwd_dkv64_kernel(const GtaBwdParams p) {
+GTA_DEV void bwd_dkv64_body(const GtaBwdParams& p, char* smem, const int L, const int nwg) {
     using S = Dkv64Smem;
     constexpr int CHP = 12, DB = 3, KB = 2, BK = 256;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
 
     int w;
     {
-        const int nwg = gridDim.x, L = blockIdx.x;
         const int xcd = L & 7, idx = L >> 3, q8 = nwg >> 3, r8 = nwg & 7;
         w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     }
@@ -1117,21 +1116,19 @@ struct Dq64Smem {
     static constexpr int OFF_SCR = OFF_SIDE + 4 * SIDE_W;
     static constexpr int OFF_REC = OFF_SCR + 32;
     static_assert(GTA_BWD64_HI_BASE == 2 * STAGE, "gen_bwd64.py's LDS map");
-    static int total(int nviews) { return OFF_REC + nviews * BREC * 4; }
+    static constexpr int total(int nviews) { return OFF_REC + nviews * BREC * 4; }
 };
 
 template <int ESZ>
-__global__ __launch_bounds__(256, 1) void gta_bwd_dq64_kernel(const GtaBwdParams p) {
+GTA_DEV void bwd_dq64_body(const GtaBwdParams& p, char* smem, const int L, const int nwg) {
     using S = Dq64Smem;
     constexpr int CHP = 12, DB = 3, BM = 256;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
 
     int w;
     {
-        const int nwg = gridDim.x, L = blockIdx.x;
         const int xcd = L & 7, idx = L >> 3, q8 = nwg >> 3, r8 = nwg & 7;
         w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     }
@@ -1282,6 +1279,28 @@ __global__ __launch_bounds__(256, 1) void gta_bwd_dq64_kernel(const GtaBwdParams
     }
 }
 
+template <int ESZ>
+__global__ __launch_bounds__(256, 1) void gta_bwd_dkv64_kernel(const GtaBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bwd_dkv64_body<ESZ>(p, smem, blockIdx.x, gridDim.x);
+}
+template <int ESZ>
+__global__ __launch_bounds__(256, 1) void gta_bwd_dq64_kernel(const GtaBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bwd_dq64_body<ESZ>(p, smem, blockIdx.x, gridDim.x);
+}
+// Both generated kernels in ONE launch: workgroups [0, n_dq) walk dQ blocks, the rest dK/dV blocks.  The two depend on the q-side pre-pass only, not on
+// each other; as two launches the second waited for the first's last workgroups (their ends spread over ~10 us) and paid its own ramp; here the
+// dK/dV workgroups take the CUs as the dQ workgroups leave them.  (n_dq a multiple of 8: workgroup L of either part runs on XCD L % 8, which
+// both bodies' work maps rely on.)
+template <int ESZ>
+__global__ __launch_bounds__(256, 1) void gta_bwd_dqkv64_kernel(const GtaBwdParams p, const int n_dq) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int L = blockIdx.x;
+    if (L < n_dq) bwd_dq64_body<ESZ>(p, smem, L, n_dq);
+    else bwd_dkv64_body<ESZ>(p, smem, L - n_dq, (int)gridDim.x - n_dq);
+}
+
 // deterministic two-level sum: 1024 threads each take a fixed strided subset, then a fixed tree
 __global__ __launch_bounds__(1024) void gta_reduce_kernel(const float* __restrict__ part, int n, float* __restrict__ out,
                                                           const float* __restrict__ neg_div) {
@@ -1316,31 +1335,35 @@ int run_bwd(const GtaBwdParams& p, hipStream_t stream) {
         ms_layout = p.dh == 96 && p.nso2 == 12;          // (the generated kernels' epilogues are written for the MSN chunk layout)
         for (int c = 0; c < 12; ++c) ms_layout = ms_layout && p.ctab[c] == gta_layout_desc(GTA_LAYOUT_MS, c);
     }
-    bool dq64 = false;
+    bool dq64 = false, dkv64 = false;
     if constexpr (DHP == 96 && ESZ == 2) {
-        // 64 rows per wave / 256 per workgroup (the generated stream) from half a chip of workgroups on (measured at B = 4 .. 32 per GPU at the MSN shape:
-        // ahead at every size; below that the 128-row kernel's finer grain spreads the work over more CUs)
+        // 64 rows / keys per wave, 256 per workgroup (the generated streams) from half a chip of workgroups on (measured at B = 4 .. 32 per GPU at the MSN
+        // shape: ahead at every size; below that the 128-row kernels' finer grain spreads the work over more CUs)
         const long n_dq64 = (long)p.B * p.H * ((p.Tq + 255) / 256);
-        dq64 = ms_layout && p.Tk % BN == 0 && p.dt_partial == nullptr && Dq64Smem::total(p.vrep_q ? p.Nq : 0) <= 160 * 1024 &&
-               (long)p.Tq * p.q_st * ESZ < (1L << 31) && (n_dq64 >= 128 || (p.flags & GTA_FLAG_BWD_KEYS64)) && !(p.flags & GTA_FLAG_BWD_KEYS32);
-        if (dq64) {
-            if (int rc = gta_lds_optin<&gta_bwd_dq64_kernel<ESZ>>(Dq64Smem::total(GTA_MAX_VIEWS))) return rc;
-            hipLaunchKernelGGL((gta_bwd_dq64_kernel<ESZ>), dim3((unsigned)n_dq64), dim3(256), Dq64Smem::total(p.vrep_q ? p.Nq : 0), stream, p);
-        }
-    }
-    if (!dq64)
-        hipLaunchKernelGGL((gta_bwd_dq_kernel<DHP, ESZ>), dim3(n_dq), dim3(256), DqSmem<DHP>::total(p.vrep_q ? p.Nq : 0), stream, p);
-    bool dkv64 = false;
-    if constexpr (DHP == 96 && ESZ == 2) {
-        // 64 keys per wave / 256 per workgroup (the generated stream) from half a chip of workgroups on; otherwise the 128-key kernel's finer grain
         const long n_dkv64 = (long)p.B * p.H * ((p.Tk + 255) / 256);
-        const bool ms = ms_layout && Dkv64Smem::total(p.vrep_k ? p.Nk : 0) <= 160 * 1024;
-        dkv64 = ms && (n_dkv64 >= 128 || (p.flags & GTA_FLAG_BWD_KEYS64)) && !(p.flags & GTA_FLAG_BWD_KEYS32);
-        if (dkv64) {
-            if (int rc = gta_lds_optin<&gta_bwd_dkv64_kernel<ESZ>>(Dkv64Smem::total(GTA_MAX_VIEWS))) return rc;
-            hipLaunchKernelGGL((gta_bwd_dkv64_kernel<ESZ>), dim3((unsigned)n_dkv64), dim3(256), Dkv64Smem::total(p.vrep_k ? p.Nk : 0), stream, p);
+        const int lds_dq = Dq64Smem::total(p.vrep_q ? p.Nq : 0), lds_dkv = Dkv64Smem::total(p.vrep_k ? p.Nk : 0);
+        dq64 = ms_layout && p.Tk % BN == 0 && p.dt_partial == nullptr && lds_dq <= 160 * 1024 &&
+               (long)p.Tq * p.q_st * ESZ < (1L << 31) && (n_dq64 >= 128 || (p.flags & GTA_FLAG_BWD_KEYS64)) && !(p.flags & GTA_FLAG_BWD_KEYS32);
+        dkv64 = ms_layout && lds_dkv <= 160 * 1024 && (n_dkv64 >= 128 || (p.flags & GTA_FLAG_BWD_KEYS64)) && !(p.flags & GTA_FLAG_BWD_KEYS32);
+        constexpr int LDS_MAX = Dq64Smem::total(GTA_MAX_VIEWS) > Dkv64Smem::total(GTA_MAX_VIEWS) ? Dq64Smem::total(GTA_MAX_VIEWS) : Dkv64Smem::total(GTA_MAX_VIEWS);
+        if (dq64 && dkv64 && n_dq64 % 8 == 0 && n_dq64 + n_dkv64 < 0x7fffffffL && !(p.flags & GTA_FLAG_BWD_SPLIT)) {                 // one launch for both (see the kernel)
+            if (int rc = gta_lds_optin<&gta_bwd_dqkv64_kernel<ESZ>>(LDS_MAX)) return rc;
+            hipLaunchKernelGGL((gta_bwd_dqkv64_kernel<ESZ>), dim3((unsigned)(n_dq64 + n_dkv64)), dim3(256), lds_dq > lds_dkv ? lds_dq : lds_dkv, stream,
+                               p, (int)n_dq64);
+        } else {
+            if (dq64) {
+                if (int rc = gta_lds_optin<&gta_bwd_dq64_kernel<ESZ>>(Dq64Smem::total(GTA_MAX_VIEWS))) return rc;
+                hipLaunchKernelGGL((gta_bwd_dq64_kernel<ESZ>), dim3((unsigned)n_dq64), dim3(256), lds_dq, stream, p);
+            }
+            if (dkv64) {
+                if (!dq64) hipLaunchKernelGGL((gta_bwd_dq_kernel<DHP, ESZ>), dim3(n_dq), dim3(256), DqSmem<DHP>::total(p.vrep_q ? p.Nq : 0), stream, p);
+                if (int rc = gta_lds_optin<&gta_bwd_dkv64_kernel<ESZ>>(Dkv64Smem::total(GTA_MAX_VIEWS))) return rc;
+                hipLaunchKernelGGL((gta_bwd_dkv64_kernel<ESZ>), dim3((unsigned)n_dkv64), dim3(256), lds_dkv, stream, p);
+            }
         }
     }
+    if (!dq64 && !dkv64)
+        hipLaunchKernelGGL((gta_bwd_dq_kernel<DHP, ESZ>), dim3(n_dq), dim3(256), DqSmem<DHP>::total(p.vrep_q ? p.Nq : 0), stream, p);
     if (!dkv64)
         hipLaunchKernelGGL((gta_bwd_dkv_kernel<DHP, ESZ>), dim3(n_dkv), dim3(256), DkvSmem<DHP>::total(p.vrep_k ? p.Nk : 0), stream, p);
     if (p.dtrans_coeff)

@@ -31,6 +31,7 @@ FLAG_ROWS32 = 1 << 11
 FLAG_ITEM_CXX = 1 << 12
 FLAG_BWD_KEYS32 = 1 << 13
 FLAG_BWD_KEYS64 = 1 << 14
+FLAG_BWD_SPLIT = 1 << 15
 VREP_STRIDE = 72
 VREP_INV, VREP_REP, VREP_D1, VREP_D2 = 0, 16, 32, 41
 MAX_VIEWS = 16

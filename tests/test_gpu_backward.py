@@ -165,7 +165,7 @@ def test_dkv64_stream_matches_keys32_kernel_bit_for_bit(shape):
     """gta_bwd_dkv64_kernel / gta_bwd_dq64_kernel (64 keys / 64 query rows per wave, the walks ONE generated instruction stream each:
     gen_bwd64.py) against gta_bwd_dkv_kernel / gta_bwd_dq_kernel (32 per wave, compiled): per (key, query) the same arithmetic and per
     accumulator the same order of tiles, so dq, dk and dv agree bit for bit (d trans_coeff sums the same per-token terms in another
-    grouping).  The ragged shape's key side is not whole tiles: its dq comes from the compiled kernel in both runs."""
+    grouping).  The ragged shape's key side is not whole tiles: its dq comes from the compiled kernel in every run."""
     shapes = dict(SHAPES)
     shapes["ragged-ms"] = (2, 3, 3, 100, 3, 150, {"se3": 48, "so3": 24, "so2": 24}, 6, 2)      # Tq = 300 (5 query tiles, the last ragged), Tk = 450 (2 key blocks, ragged)
     B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3 = shapes[shape]
@@ -178,7 +178,7 @@ def test_dkv64_stream_matches_keys32_kernel_bit_for_bit(shape):
         gta_amd.pre_compute_reps_decoder(ak, exd)
     packed = gta_amd.pack_reps(exd, f_dims)
     res = {}
-    for mode in ("prepass_bwd_keys32", "prepass_bwd_keys64"):
+    for mode in ("prepass_bwd_keys32", "prepass_bwd_keys64", "prepass_bwd_split"):
         qd, kd, vd = (t.bfloat16().cuda().requires_grad_() for t in (q, k, v))
         tcd = torch.tensor([0.37], device="cuda", requires_grad=True)
         out = gta_amd.gta_attention(qd, kd, vd, f_dims, packed, so3_degree=exd.get("gta_so3_degree", 0), trans_coeff=tcd, kv_mode=mode)
@@ -191,6 +191,10 @@ def test_dkv64_stream_matches_keys32_kernel_bit_for_bit(shape):
     assert torch.equal(a[2], b[2]), (a[2] - b[2]).abs().max()
     assert torch.equal(a[1], b[1]), (a[1] - b[1]).abs().max()
     assert abs(a[3] - b[3]) <= 1e-4 * max(1.0, abs(a[3])), (a[3], b[3])
+    # the two generated kernels as ONE launch (gta_bwd_dqkv64_kernel: the default where both run and the dQ blocks are a multiple of 8 -- MS-enc,
+    # MS-dec here) and as two (GTA_FLAG_BWD_SPLIT): the same workgroups doing the same work
+    c = res["prepass_bwd_split"]
+    assert all(torch.equal(b[i], c[i]) for i in range(3)) and b[3] == c[3]
 
 
 @pytest.mark.parametrize("shape", ["MS-enc", "MS-dec"])

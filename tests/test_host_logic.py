@@ -407,7 +407,8 @@ def test_dkv64_kernel_leaves_the_register_files_to_the_stream():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     report, problems = mod.audit_dkv64()
-    assert len(report) == 2 and all(r["loop_statements"] == 1 for r in report), report       # gta_bwd_dkv64_kernel, gta_bwd_dq64_kernel
+    # gta_bwd_dkv64_kernel, gta_bwd_dq64_kernel: one generated statement each; gta_bwd_dqkv64_kernel (both bodies in one launch): two
+    assert sorted(r["loop_statements"] for r in report) == [1, 1, 2], report
     assert not problems, problems
 
 
