@@ -1289,16 +1289,16 @@ __global__ __launch_bounds__(256, 1) void gta_bwd_dq64_kernel(const GtaBwdParams
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bwd_dq64_body<ESZ>(p, smem, blockIdx.x, gridDim.x);
 }
-// Both generated kernels in ONE launch: workgroups [0, n_dq) walk dQ blocks, the rest dK/dV blocks.  The two depend on the q-side pre-pass only, not on
-// each other; as two launches the second waited for the first's last workgroups (their ends spread over ~10 us) and paid its own ramp; here the
-// dK/dV workgroups take the CUs as the dQ workgroups leave them.  (n_dq a multiple of 8: workgroup L of either part runs on XCD L % 8, which
-// both bodies' work maps rely on.)
+// Both generated kernels in ONE launch: workgroups [0, n_dkv) walk dK/dV blocks, the rest dQ blocks (the longer blocks first: the launch ends on the
+// shorter ones).  The two depend on the q-side pre-pass only, not on each other; as two launches the second waited for the first's last workgroups
+// (their ends spread over ~10 us) and paid its own ramp; here the second kind takes the CUs as the first leaves them.  (n_dkv a multiple of 8:
+// workgroup L of either part runs on XCD L % 8, which both bodies' work maps rely on.)
 template <int ESZ>
 __global__ __launch_bounds__(256, 1) void gta_bwd_dqkv64_kernel(const GtaBwdParams p, const int n_dq) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int L = blockIdx.x;
-    if (L < n_dq) bwd_dq64_body<ESZ>(p, smem, L, n_dq);
-    else bwd_dkv64_body<ESZ>(p, smem, L - n_dq, (int)gridDim.x - n_dq);
+    const int L = blockIdx.x, n_dkv = (int)gridDim.x - n_dq;
+    if (L < n_dkv) bwd_dkv64_body<ESZ>(p, smem, L, n_dkv);
+    else bwd_dq64_body<ESZ>(p, smem, L - n_dkv, n_dq);
 }
 
 // deterministic two-level sum: 1024 threads each take a fixed strided subset, then a fixed tree
@@ -1346,7 +1346,7 @@ int run_bwd(const GtaBwdParams& p, hipStream_t stream) {
                (long)p.Tq * p.q_st * ESZ < (1L << 31) && (n_dq64 >= 128 || (p.flags & GTA_FLAG_BWD_KEYS64)) && !(p.flags & GTA_FLAG_BWD_KEYS32);
         dkv64 = ms_layout && lds_dkv <= 160 * 1024 && (n_dkv64 >= 128 || (p.flags & GTA_FLAG_BWD_KEYS64)) && !(p.flags & GTA_FLAG_BWD_KEYS32);
         constexpr int LDS_MAX = Dq64Smem::total(GTA_MAX_VIEWS) > Dkv64Smem::total(GTA_MAX_VIEWS) ? Dq64Smem::total(GTA_MAX_VIEWS) : Dkv64Smem::total(GTA_MAX_VIEWS);
-        if (dq64 && dkv64 && n_dq64 % 8 == 0 && n_dq64 + n_dkv64 < 0x7fffffffL && !(p.flags & GTA_FLAG_BWD_SPLIT)) {                 // one launch for both (see the kernel)
+        if (dq64 && dkv64 && n_dkv64 % 8 == 0 && n_dq64 + n_dkv64 < 0x7fffffffL && !(p.flags & GTA_FLAG_BWD_SPLIT)) {                 // one launch for both (see the kernel)
             if (int rc = gta_lds_optin<&gta_bwd_dqkv64_kernel<ESZ>>(LDS_MAX)) return rc;
             hipLaunchKernelGGL((gta_bwd_dqkv64_kernel<ESZ>), dim3((unsigned)(n_dq64 + n_dkv64)), dim3(256), lds_dq > lds_dkv ? lds_dq : lds_dkv, stream,
                                p, (int)n_dq64);
