@@ -53,9 +53,10 @@ def attn_bwd(cfg, q, k, v, out, dout, lse, tc, ta, vrep_q, vrep_k, cs_q, cs_k, k
     Tk = k.shape[2]
     # gradients in the projections' memory order (packed like the forward's q, k, v where those were packed)
     dq, dk, dv = _grad_buffers(q, k, v)
-    dtc = torch.zeros(1, device=q.device, dtype=torch.float32) if f_dims.get("se3", 0) > 0 else None
+    # (both scalars are WRITTEN by the library -- the fixed-order reduction stores its sum -- so no zero-fill launch)
+    dtc = torch.empty(1, device=q.device, dtype=torch.float32) if f_dims.get("se3", 0) > 0 else None
     desc = native.make_desc(q, k, v, out, f_dims, so3_degree, Nq, Nk, scale, flags)
     ws = torch.empty(native.attn_bwd_workspace_bytes(desc), device=q.device, dtype=torch.uint8)
-    dta = torch.zeros(1, device=q.device, dtype=torch.float32) if (want_dtau and ta is not None) else None
+    dta = torch.empty(1, device=q.device, dtype=torch.float32) if (want_dtau and ta is not None) else None
     native.attn_bwd(desc, q, k, v, out, dout, lse, vrep_q, vrep_k, cs_q, cs_k, tc, ta, kv_images, dq, dk, dv, dtc, ws, dta)
     return dq, dk, dv, dtc, dta

@@ -160,7 +160,7 @@ int64_t gta_attn_fwd_workspace_bytes(const GtaAttnDesc* desc);
  *   plan     : Q''/dO~ pre-pass -> dQ kernel -> dK/dV kernel, each recomputing S and dP from the images (14 GEMM-units).
  *              Deterministic (no atomics: fixed-order reductions).
  *   outputs: dq, dk, dv with element strides dqkv_stride[9] = dq(b,h,t), dk(b,h,t), dv(b,h,t);
- *            dtrans_coeff [1] fp32 (d loss / d trans_coeff, layers.py:191) or NULL;
+ *            dtrans_coeff [1] fp32 (d loss / d trans_coeff, layers.py:191; written, not accumulated) or NULL;
  *            dtau [1] fp32 (d loss / d tau of TemperatureAdjsutableSoftmax, layers.py:135-143,195-200) or
  *            NULL.  The logits are z = scale q'.k' / tau, so dL/dtau = -(1/tau) sum_ij dz_ij z_ij
  *            = -(1/tau) sum_i <q'_i, dq'_i> = -(1/tau) sum_i <q_i, dq_i>  (rho_q is linear): it falls out of
