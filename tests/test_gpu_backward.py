@@ -250,3 +250,37 @@ def test_generated_backward_is_bit_reproducible(shape):
         torch.cuda.synchronize()
         res[run] = (qd.grad.float().cpu(), kd.grad.float().cpu(), vd.grad.float().cpu(), float(tcd.grad.item()))
     assert all(torch.equal(res[0][i], res[1][i]) for i in range(3)) and res[0][3] == res[1][3]
+
+
+def test_backward_properties_at_the_bench_size():
+    """Size-independent properties of the operator's backward at the BASELINE size the bench times (MSN encoder, B = 32 per GPU, bf16: the default
+    kernel selection there is the joint launch of the two generated streams), where autograd through the oracle would take minutes:
+    (1) every step of the backward is linear in dout and a factor 2 is exact in bf16 and fp32, so the gradients of 2 w are EXACTLY twice those of w;
+    (2) replacing every extrinsic E_n by E_n g (a change of the global frame) leaves dq, dk, dv unchanged to bf16 accuracy."""
+    from oracle import gta_oracle as O
+    _, H, Nq, Pq, Nk, Pk, f_dims, so2, so3 = SHAPES["MS-enc"]
+    B = 32
+    q, k, v, ex, ak, cross = C.synth_inputs(B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, torch.bfloat16, seed=3)
+    w = torch.randn(q.shape, generator=torch.Generator().manual_seed(4)).bfloat16().cuda()
+    g = O.random_extrinsics(1, 2, torch.Generator().manual_seed(9))[:, 1:2]
+
+    def grads(ex_in, wscale):
+        exd = {kk: vv.cuda() for kk, vv in ex_in.items()}
+        gta_amd.pre_compute_reps_encoder(ak, exd)
+        packed = gta_amd.pack_reps(exd, f_dims)
+        qd, kd, vd = (t.bfloat16().cuda().requires_grad_() for t in (q, k, v))
+        tcd = torch.tensor([0.37], device="cuda", requires_grad=True)
+        out = gta_amd.gta_attention(qd, kd, vd, f_dims, packed, so3_degree=exd.get("gta_so3_degree", 0), trans_coeff=tcd)
+        out.backward(w * wscale)
+        torch.cuda.synchronize()
+        return qd.grad, kd.grad, vd.grad, float(tcd.grad.item())
+
+    a = grads(ex, 1.0)
+    b = grads(ex, 2.0)
+    for x, y in zip(a[:3], b[:3]):
+        assert torch.isfinite(x.float()).all() and x.float().abs().max() > 0
+        assert torch.equal(y.float(), 2.0 * x.float())
+    assert abs(b[3] - 2.0 * a[3]) <= 1e-5 * max(1.0, abs(a[3]))
+    c = grads(dict(ex, input_transforms=ex["input_transforms"] @ g), 1.0)
+    for x, y, name in zip(a[:3], c[:3], ("dq", "dk", "dv")):
+        _check(y.float().cpu(), x.float().cpu(), name)
