@@ -114,6 +114,26 @@ def test_global_frame_invariance_full_size():
     _check(b, a)
 
 
+def test_forward_properties_at_the_bench_size():
+    """Two more size-independent properties on the device path at the size the bench times (MSN encoder, B = 32 per GPU, bf16: the item-stream
+    kernel): (1) the output is linear in V and a factor 2 is exact in bf16 and fp32 -- rho_k v, P V', the normalisation and rho_q^-1 all scale --
+    so out(q, k, 2 v) is EXACTLY 2 out(q, k, v); (2) attention sums over the keys: permuting the tokens inside every view (rows of q, k, v and
+    their coordinates alike; the views' poses stay) permutes the output rows and changes nothing else but the order of the sums."""
+    B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3 = SHAPES["MS-enc"]
+    B = 32
+    q, k, v, ex, ak, cross = C.synth_inputs(B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, torch.bfloat16, seed=6)
+    q, k, v = q.bfloat16().float(), k.bfloat16().float(), v.bfloat16().float()
+    a = C.hip_forward(q, k, v, ex, ak, cross, 0.3, torch.bfloat16, kv_mode="prepass").float().cpu()
+    b = C.hip_forward(q, k, 2.0 * v, ex, ak, cross, 0.3, torch.bfloat16, kv_mode="prepass").float().cpu()
+    assert torch.isfinite(a).all() and a.abs().max() > 0
+    assert torch.equal(b, 2.0 * a)
+    perm = torch.randperm(Pq, generator=torch.Generator().manual_seed(8))
+    idx = (torch.arange(Nq)[:, None] * Pq + perm[None, :]).reshape(-1)           # view-major token order (gta.py:160-162)
+    ex2 = dict(ex, input_coord=ex["input_coord"][:, :, perm])
+    c = C.hip_forward(q[:, :, idx], k[:, :, idx], v[:, :, idx], ex2, ak, cross, 0.3, torch.bfloat16, kv_mode="prepass").float().cpu()
+    _check(c, a[:, :, idx])
+
+
 @pytest.mark.parametrize("kv_mode", ["prepass", "prepass_pg"])
 @pytest.mark.parametrize("pattern", ["hot_logits", "late_spike", "early_spike"])
 def test_lazy_softmax_full_path(pattern, kv_mode):
