@@ -284,3 +284,36 @@ def test_backward_properties_at_the_bench_size():
     c = grads(dict(ex, input_transforms=ex["input_transforms"] @ g), 1.0)
     for x, y, name in zip(a[:3], c[:3], ("dq", "dk", "dv")):
         _check(y.float().cpu(), x.float().cpu(), name)
+
+
+@pytest.mark.parametrize("shape", ["MS-enc", "MS-dec", "CL-enc", "CL-dec"])
+def test_bench_size_sampled_scenes_gradients_vs_oracle(shape):
+    """The backward at the batch the bench times (B = 32 per GPU, bf16: the kernels that launch selects -- at the MSN shapes the joint launch of
+    the generated streams): the whole batch on the device, two of its scenes through autograd over the oracle (a scene's dq, dk, dv depend on
+    that scene alone; d trans_coeff sums over the batch and is covered by the small-batch tests)."""
+    from oracle import gta_oracle as O
+    _, H, Nq, Pq, Nk, Pk, f_dims, so2, so3 = SHAPES[shape]
+    B = 32
+    q, k, v, ex, ak, cross = C.synth_inputs(B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, torch.bfloat16, seed=13)
+    q, k, v = q.bfloat16().float(), k.bfloat16().float(), v.bfloat16().float()
+    w = torch.randn(q.shape, generator=torch.Generator().manual_seed(14)).bfloat16().float()
+    exd = {kk: vv.cuda() for kk, vv in ex.items()}
+    gta_amd.pre_compute_reps_encoder(ak, exd)
+    if cross:
+        gta_amd.pre_compute_reps_decoder(ak, exd)
+    packed = gta_amd.pack_reps(exd, f_dims)
+    qd, kd, vd = (t.bfloat16().cuda().requires_grad_() for t in (q, k, v))
+    tcd = torch.tensor([0.37], device="cuda", requires_grad=True)
+    out = gta_amd.gta_attention(qd, kd, vd, f_dims, packed, so3_degree=exd.get("gta_so3_degree", 0), trans_coeff=tcd)
+    out.backward(w.bfloat16().cuda())
+    torch.cuda.synchronize()
+    idx = torch.tensor([5, 27])
+    qo, ko, vo = (t[idx].clone().requires_grad_() for t in (q, k, v))
+    exs = {kk: vv[idx] for kk, vv in ex.items()}
+    reps = O.encoder_reps(ak, exs)
+    if cross:
+        reps = O.decoder_reps(ak, exs, reps)
+    out_o, _ = O.gta_attention(qo, ko, vo, f_dims, reps, torch.tensor([0.37]))
+    (out_o * w[idx]).sum().backward()
+    for name, a, b in (("dq", qd, qo), ("dk", kd, ko), ("dv", vd, vo)):
+        _check(a.grad[idx.cuda()].float().cpu(), b.grad, name)

@@ -114,6 +114,21 @@ def test_global_frame_invariance_full_size():
     _check(b, a)
 
 
+@pytest.mark.parametrize("shape", ["MS-enc", "MS-dec", "CL-enc", "CL-dec", "DT"])
+def test_bench_size_sampled_scenes_vs_oracle(shape):
+    """Every BASELINE workload at the batch the bench times (B = 32 per GPU, bf16; the kernels and grids that launch selects: item stream,
+    64-row kernel, 32-row kernel in whole rounds) -- the full batch on the device, four of its scenes through the oracle (the check
+    bench.py prints with its line, here as a test)."""
+    _, H, Nq, Pq, Nk, Pk, f_dims, so2, so3 = SHAPES[shape]
+    B = 32
+    q, k, v, ex, ak, cross = C.synth_inputs(B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, torch.bfloat16, seed=2)
+    q, k, v = q.bfloat16().float(), k.bfloat16().float(), v.bfloat16().float()
+    got = C.hip_forward(q, k, v, ex, ak, cross, 0.01, torch.bfloat16, kv_mode="prepass").float().cpu()
+    idx = torch.tensor([0, 10, 21, 31])
+    ref = C.oracle_forward(q[idx], k[idx], v[idx], {kk: vv[idx] for kk, vv in ex.items()}, ak, cross, 0.01)
+    _check(got[idx], ref)
+
+
 def test_forward_properties_at_the_bench_size():
     """Two more size-independent properties on the device path at the size the bench times (MSN encoder, B = 32 per GPU, bf16: the item-stream
     kernel): (1) the output is linear in V and a factor 2 is exact in bf16 and fp32 -- rho_k v, P V', the normalisation and rho_q^-1 all scale --
