@@ -1,7 +1,10 @@
 // gta_apply.hip -- generic rho application for ANY f_dims layout (ablation paths of the reference):
 // t2 slab (gta.py:221-238,272-274), euclid similarity (gta.py:146-156,251-253; layers.py:213-224),
-// so3 of degree 1, unaligned slabs.  One thread per (batch, head, token) row, block by block straight
-// from/to global memory -- correctness path, HBM-bound at best; the shipped configs never come here.
+// so3 of degree 1, unaligned slabs -- and the fp32 rho of the fp32-faithful mode (gta.py: precise=True with gradients).  One thread per
+// (batch, head, token) row, block by block.  r04: the rows pass through LDS -- a wave copies its 64 rows in (one coalesced access per row:
+// the lanes take the row's channels), every lane then works on ITS row in LDS (rows 4 (dh + 1) bytes apart: an odd word stride, no bank
+// conflicts) and the wave copies the results out the same way; straight from global memory every lane's element access touched another
+// row -- 64 lines per instruction (the direct form is kept for head dimensions whose rows do not fit: dh > 300).
 //   mode 0: q side      q' = blockdiag((E_q.m)^T | D(R_q) | R(th_q) | (T_q^-1)^T) q      (euclid: affine inv(E_q).m)
 //   mode 1: k side      k' = blockdiag(inv(E_k).m | D(R_k) | R(th_k) | T_k) k  (also v)  (euclid: affine inv(E_k).m)
 //   mode 2: output      o  = blockdiag(E_q.m | D(R_q)^T | R(th_q)^T | T_q^-1) o~        (euclid: affine E_q.m)
@@ -28,23 +31,64 @@ template <int ESZ> GTA_DEV void st(char* p, int i, float v) {
     if (ESZ == 4) { reinterpret_cast<float*>(p)[i] = v; return; }
     reinterpret_cast<uint16_t*>(p)[i] = (uint16_t)(pack_bf16x2(v, 0.f) & 0xffffu);
 }
+// a row as the bodies below see it: element ch in, element ch out -- in global memory (direct form) or as fp32 in the wave's LDS stage
+template <int ESZ> struct GIn  { const char* p; GTA_DEV float operator()(int ch) const { return ld<ESZ>(p, ch); } };
+template <int ESZ> struct GOut { char* p;       GTA_DEV void operator()(int ch, float v) const { st<ESZ>(p, ch, v); } };
+struct LIn  { const float* p; GTA_DEV float operator()(int ch) const { return p[ch]; } };
+struct LOut { float* p;       GTA_DEV void operator()(int ch, float v) const { p[ch] = v; } };
 
-template <int ESZ>
-__global__ void gta_apply_kernel(const ApplyParams p) {
-    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)p.B * p.H * p.T;
-    if (row >= total) return;
-    const int t = (int)(row % p.T);
-    const int h = (int)((row / p.T) % p.H);
-    const int b = (int)(row / ((long)p.T * p.H));
-    const char* x = (const char*)p.x + ((long)b * p.x_sb + (long)h * p.x_sh + (long)t * p.x_st) * ESZ;
-    char* y = (char*)p.y + ((long)b * p.y_sb + (long)h * p.y_sh + (long)t * p.y_st) * ESZ;
+GTA_DEV void row_decode(long row, int T, int H, int& b, int& h, int& t) {
+    t = (int)(row % T);
+    h = (int)((row / T) % H);
+    b = (int)(row / ((long)T * H));
+}
+// 64 rows of dh elements between global memory (base + (b sb + h sh + t st) elements, rows [row0, row0 + 64) of the launch) and a wave's stage
+// [64][dh + 1] floats: one access per row and 64 channels.  Lane l knows the offset of row row0 + l (my_off, bytes; < 0 past the end); the
+// wave reads them back lane by lane (uniform values), EIGHT rows' loads in flight before their LDS writes (a load -> write chain per row
+// cost one memory latency per row: 64 of them in a row were most of these kernels' time)
+template <int ESZ, bool IN>
+GTA_DEV void stage_rows(float* stage, const void* base, const long my_off, const int dh, const int lane) {
+    for (int ch = lane; ch < dh; ch += 64) {
+#pragma unroll 1
+        for (int r0 = 0; r0 < 64; r0 += 8) {
+            long off[8];
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)(uint64_t)my_off, r0 + u);
+                const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)((uint64_t)my_off >> 32), r0 + u);
+                off[u] = (long)(((uint64_t)hi << 32) | lo);
+            }
+            if (IN) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = off[u] >= 0 ? ld<ESZ>((const char*)base + off[u], ch) : 0.f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) stage[(r0 + u) * (dh + 1) + ch] = v[u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = stage[(r0 + u) * (dh + 1) + ch];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (off[u] >= 0) st<ESZ>((char*)base + off[u], ch, v[u]);
+            }
+        }
+    }
+}
+GTA_DEV long row_offset(long row, long total, int T, int H, long sb, long sh, long st_, int esz) {
+    if (row >= total) return -1;
+    int b, h, t;
+    row_decode(row, T, H, b, h, t);
+    return ((long)b * sb + (long)h * sh + (long)t * st_) * esz;
+}
+
+template <class In, class Out>
+GTA_DEV void apply_row(const ApplyParams& p, const int b, const int h, const int t, const In X, const Out Y) {
     const float tc = p.trans_coeff ? *p.trans_coeff : 1.0f;
     const int n = t / p.P;
     const float* vr = p.vrep ? p.vrep + ((long)b * p.N + n) * GTA_VREP_STRIDE : nullptr;
     float sq = 0.f;
     int ch = 0;
-    for (int i = 0; i < p.d_triv; ++i, ++ch) { const float v = ld<ESZ>(x, ch); st<ESZ>(y, ch, v); sq += v * v; }
+    for (int i = 0; i < p.d_triv; ++i, ++ch) { const float v = X(ch); Y(ch, v); sq += v * v; }
     if (p.d_se3 > 0) {
         // matrix used: mode 0 non-euclid: (E.m)^T ; mode 0 euclid: inv(E).m ; mode 1: inv(E).m ; mode 2: E.m
         float M[16];
@@ -58,18 +102,18 @@ __global__ void gta_apply_kernel(const ApplyParams p) {
             }
         if (p.euclid) {
             for (int blk = 0; blk < p.d_se3 / 3; ++blk, ch += 3) {
-                const float a = ld<ESZ>(x, ch), bb = ld<ESZ>(x, ch + 1), c = ld<ESZ>(x, ch + 2);
+                const float a = X(ch), bb = X(ch + 1), c = X(ch + 2);
                 for (int r = 0; r < 3; ++r) {
                     const float v = M[r * 4] * a + M[r * 4 + 1] * bb + M[r * 4 + 2] * c + M[r * 4 + 3];   // homogenisation
-                    st<ESZ>(y, ch + r, v); sq += v * v;
+                    Y(ch + r, v); sq += v * v;
                 }
             }
         } else {
             for (int blk = 0; blk < p.d_se3 / 4; ++blk, ch += 4) {
-                const float a = ld<ESZ>(x, ch), bb = ld<ESZ>(x, ch + 1), c = ld<ESZ>(x, ch + 2), d = ld<ESZ>(x, ch + 3);
+                const float a = X(ch), bb = X(ch + 1), c = X(ch + 2), d = X(ch + 3);
                 for (int r = 0; r < 4; ++r) {
                     const float v = M[r * 4] * a + M[r * 4 + 1] * bb + M[r * 4 + 2] * c + M[r * 4 + 3] * d;
-                    st<ESZ>(y, ch + r, v); sq += v * v;
+                    Y(ch + r, v); sq += v * v;
                 }
             }
         }
@@ -81,11 +125,11 @@ __global__ void gta_apply_kernel(const ApplyParams p) {
                 const int dim = 2 * l + 1;
                 const float* D = vr + (l == 1 ? GTA_VREP_D1 : GTA_VREP_D2);
                 float in[5];
-                for (int i = 0; i < dim; ++i) in[i] = ld<ESZ>(x, ch + i);
+                for (int i = 0; i < dim; ++i) in[i] = X(ch + i);
                 for (int r = 0; r < dim; ++r) {
                     float v = 0.f;
                     for (int c = 0; c < dim; ++c) v += (p.mode == 2 ? D[c * dim + r] : D[r * dim + c]) * in[c];
-                    st<ESZ>(y, ch + r, v); sq += v * v;
+                    Y(ch + r, v); sq += v * v;
                 }
                 ch += dim;
             }
@@ -96,23 +140,50 @@ __global__ void gta_apply_kernel(const ApplyParams p) {
         const float* cs = p.cs + ((long)b * p.T + t) * 2 * nblk;
         for (int blk = 0; blk < nblk; ++blk, ch += 2) {
             const float c = cs[2 * blk], s = (p.mode == 2 ? -1.f : 1.f) * cs[2 * blk + 1];
-            const float a = ld<ESZ>(x, ch), bb = ld<ESZ>(x, ch + 1);
+            const float a = X(ch), bb = X(ch + 1);
             const float v0 = c * a - s * bb, v1 = s * a + c * bb;
-            st<ESZ>(y, ch, v0); st<ESZ>(y, ch + 1, v1); sq += v0 * v0 + v1 * v1;
+            Y(ch, v0); Y(ch + 1, v1); sq += v0 * v0 + v1 * v1;
         }
     }
     if (p.d_t2 > 0) {
         const float cx = p.coord[((long)b * p.T + t) * 2], cy = p.coord[((long)b * p.T + t) * 2 + 1];
         for (int blk = 0; blk < p.d_t2 / 3; ++blk, ch += 3) {
-            const float a = ld<ESZ>(x, ch), bb = ld<ESZ>(x, ch + 1), c = ld<ESZ>(x, ch + 2);
+            const float a = X(ch), bb = X(ch + 1), c = X(ch + 2);
             float v0, v1, v2;
             if (p.mode == 0)      { v0 = a - cx * c; v1 = bb - cy * c; v2 = c; }                   // (T^-1)^T
             else if (p.mode == 1) { v0 = a; v1 = bb; v2 = cx * a + cy * bb + c; }                  // T
             else                  { v0 = a; v1 = bb; v2 = c - cx * a - cy * bb; }                  // T^-1
-            st<ESZ>(y, ch, v0); st<ESZ>(y, ch + 1, v1); st<ESZ>(y, ch + 2, v2); sq += v0 * v0 + v1 * v1 + v2 * v2;
+            Y(ch, v0); Y(ch + 1, v1); Y(ch + 2, v2); sq += v0 * v0 + v1 * v1 + v2 * v2;
         }
     }
     if (p.key_bias) p.key_bias[((long)b * p.H + h) * p.bias_pitch + t] = -0.5f * p.bias_scale * sq;
+}
+
+template <int ESZ, bool STAGED>
+__global__ void gta_apply_kernel(const ApplyParams p) {
+    const long total = (long)p.B * p.H * p.T;
+    int b, h, t;
+    if constexpr (!STAGED) {
+        const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (row >= total) return;
+        row_decode(row, p.T, p.H, b, h, t);
+        const char* x = (const char*)p.x + ((long)b * p.x_sb + (long)h * p.x_sh + (long)t * p.x_st) * ESZ;
+        char* y = (char*)p.y + ((long)b * p.y_sb + (long)h * p.y_sh + (long)t * p.y_st) * ESZ;
+        apply_row(p, b, h, t, GIn<ESZ>{x}, GOut<ESZ>{y});
+    } else {                                             // one wave per workgroup, 64 rows through its stage (in place)
+        extern __shared__ float stage[];
+        const int dh = p.d_triv + p.d_se3 + p.d_so3 + p.d_so2 + p.d_t2, lane = threadIdx.x;
+        const long row0 = (long)blockIdx.x * 64;
+        stage_rows<ESZ, true>(stage, p.x, row_offset(row0 + lane, total, p.T, p.H, p.x_sb, p.x_sh, p.x_st, ESZ), dh, lane);
+        __syncthreads();
+        if (row0 + lane < total) {
+            row_decode(row0 + lane, p.T, p.H, b, h, t);
+            float* r = stage + lane * (dh + 1);
+            apply_row(p, b, h, t, LIn{r}, LOut{r});
+        }
+        __syncthreads();
+        stage_rows<ESZ, false>(stage, p.y, row_offset(row0 + lane, total, p.T, p.H, p.y_sb, p.y_sh, p.y_st, ESZ), dh, lane);
+    }
 }
 
 // Adjoint of the above: dx = M^T dy for the block-diagonal M of `mode`, plus (optionally) this row's contribution
@@ -127,25 +198,16 @@ struct ApplyBwdParams {
     float* dtc_rows;               // [B,H,T] or null
 };
 
-template <int ESZ>
-__global__ void gta_apply_bwd_kernel(const ApplyBwdParams q) {
+template <class In, class InG, class Out>
+GTA_DEV float apply_bwd_row(const ApplyBwdParams& q, const int b, const int h, const int t, const In X, const InG DY, const Out DX) {
     const ApplyParams& p = q.f;
-    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)p.B * p.H * p.T;
-    if (row >= total) return;
-    const int t = (int)(row % p.T);
-    const int h = (int)((row / p.T) % p.H);
-    const int b = (int)(row / ((long)p.T * p.H));
-    const char* x = (const char*)p.x + ((long)b * p.x_sb + (long)h * p.x_sh + (long)t * p.x_st) * ESZ;
-    const char* dy = (const char*)q.dy + ((long)b * q.dy_sb + (long)h * q.dy_sh + (long)t * q.dy_st) * ESZ;
-    char* dx = (char*)q.dx + ((long)b * q.dx_sb + (long)h * q.dx_sh + (long)t * q.dx_st) * ESZ;
     const float tc = p.trans_coeff ? *p.trans_coeff : 1.0f;
     const int n = t / p.P;
     const float* vr = p.vrep ? p.vrep + ((long)b * p.N + n) * GTA_VREP_STRIDE : nullptr;
     const float kb = q.dbias ? -p.bias_scale * q.dbias[((long)b * p.H + h) * p.bias_pitch + t] : 0.f;   // d/dy of the bias = kb * y
     float dc = 0.f;
     int ch = 0;
-    for (int i = 0; i < p.d_triv; ++i, ++ch) st<ESZ>(dx, ch, ld<ESZ>(dy, ch) + kb * ld<ESZ>(x, ch));
+    for (int i = 0; i < p.d_triv; ++i, ++ch) DX(ch, DY(ch) + kb * X(ch));
     if (p.d_se3 > 0) {
         float M[16];                                     // the forward's matrix, row-major (y = M x)
         const bool use_inv_slot = (p.mode == 2) || (p.mode == 0 && !p.euclid);
@@ -158,24 +220,24 @@ __global__ void gta_apply_bwd_kernel(const ApplyBwdParams q) {
             }
         if (p.euclid) {
             for (int blk = 0; blk < p.d_se3 / 3; ++blk, ch += 3) {
-                const float a = ld<ESZ>(x, ch), bb = ld<ESZ>(x, ch + 1), c = ld<ESZ>(x, ch + 2);
+                const float a = X(ch), bb = X(ch + 1), c = X(ch + 2);
                 float g[3];
                 for (int r = 0; r < 3; ++r) {
                     const float y = M[r * 4] * a + M[r * 4 + 1] * bb + M[r * 4 + 2] * c + M[r * 4 + 3];
-                    g[r] = ld<ESZ>(dy, ch + r) + kb * y;
+                    g[r] = DY(ch + r) + kb * y;
                     dc += g[r] * src[r * 4 + 3];                            // y_r = ... + c * t_r
                 }
-                for (int col = 0; col < 3; ++col) st<ESZ>(dx, ch + col, M[col] * g[0] + M[4 + col] * g[1] + M[8 + col] * g[2]);
+                for (int col = 0; col < 3; ++col) DX(ch + col, M[col] * g[0] + M[4 + col] * g[1] + M[8 + col] * g[2]);
             }
         } else {
             for (int blk = 0; blk < p.d_se3 / 4; ++blk, ch += 4) {
                 float xi[4], g[4];
-                for (int i = 0; i < 4; ++i) { xi[i] = ld<ESZ>(x, ch + i); g[i] = ld<ESZ>(dy, ch + i); }
+                for (int i = 0; i < 4; ++i) { xi[i] = X(ch + i); g[i] = DY(ch + i); }
                 if (kb != 0.f)
                     for (int r = 0; r < 4; ++r)
                         g[r] += kb * (M[r * 4] * xi[0] + M[r * 4 + 1] * xi[1] + M[r * 4 + 2] * xi[2] + M[r * 4 + 3] * xi[3]);
                 for (int col = 0; col < 4; ++col)
-                    st<ESZ>(dx, ch + col, M[col] * g[0] + M[4 + col] * g[1] + M[8 + col] * g[2] + M[12 + col] * g[3]);
+                    DX(ch + col, M[col] * g[0] + M[4 + col] * g[1] + M[8 + col] * g[2] + M[12 + col] * g[3]);
                 if (p.mode == 0) dc += g[3] * (src[3] * xi[0] + src[7] * xi[1] + src[11] * xi[2]);       // y_3 = sum_c E[c][3] c x_c + x_3
                 else             dc += (g[0] * src[3] + g[1] * src[7] + g[2] * src[11]) * xi[3];           // y_r = ... + M[r][3] c x_3
             }
@@ -188,11 +250,11 @@ __global__ void gta_apply_bwd_kernel(const ApplyBwdParams q) {
                 const int dim = 2 * l + 1;
                 const float* D = vr + (l == 1 ? GTA_VREP_D1 : GTA_VREP_D2);
                 float in[5];
-                for (int i = 0; i < dim; ++i) in[i] = ld<ESZ>(dy, ch + i);
+                for (int i = 0; i < dim; ++i) in[i] = DY(ch + i);
                 for (int r = 0; r < dim; ++r) {
-                    float v = kb * ld<ESZ>(x, ch + r);                     // D orthogonal: D^T (kb D x) = kb x
+                    float v = kb * X(ch + r);                     // D orthogonal: D^T (kb D x) = kb x
                     for (int c = 0; c < dim; ++c) v += (p.mode == 2 ? D[r * dim + c] : D[c * dim + r]) * in[c];
-                    st<ESZ>(dx, ch + r, v);
+                    DX(ch + r, v);
                 }
                 ch += dim;
             }
@@ -203,16 +265,16 @@ __global__ void gta_apply_bwd_kernel(const ApplyBwdParams q) {
         const float* cs = p.cs + ((long)b * p.T + t) * 2 * nblk;
         for (int blk = 0; blk < nblk; ++blk, ch += 2) {
             const float c = cs[2 * blk], s = (p.mode == 2 ? -1.f : 1.f) * cs[2 * blk + 1];
-            const float a = ld<ESZ>(dy, ch), bb = ld<ESZ>(dy, ch + 1);
-            st<ESZ>(dx, ch, c * a + s * bb + kb * ld<ESZ>(x, ch)); st<ESZ>(dx, ch + 1, -s * a + c * bb + kb * ld<ESZ>(x, ch + 1));
+            const float a = DY(ch), bb = DY(ch + 1);
+            DX(ch, c * a + s * bb + kb * X(ch)); DX(ch + 1, -s * a + c * bb + kb * X(ch + 1));
         }
     }
     if (p.d_t2 > 0) {
         const float cx = p.coord[((long)b * p.T + t) * 2], cy = p.coord[((long)b * p.T + t) * 2 + 1];
         for (int blk = 0; blk < p.d_t2 / 3; ++blk, ch += 3) {
-            float a = ld<ESZ>(dy, ch), bb = ld<ESZ>(dy, ch + 1), c = ld<ESZ>(dy, ch + 2);
+            float a = DY(ch), bb = DY(ch + 1), c = DY(ch + 2);
             if (kb != 0.f) {                                               // y = T x recomputed for the bias term
-                const float xa = ld<ESZ>(x, ch), xb = ld<ESZ>(x, ch + 1), xc = ld<ESZ>(x, ch + 2);
+                const float xa = X(ch), xb = X(ch + 1), xc = X(ch + 2);
                 float y0, y1, y2;
                 if (p.mode == 0)      { y0 = xa - cx * xc; y1 = xb - cy * xc; y2 = xc; }
                 else if (p.mode == 1) { y0 = xa; y1 = xb; y2 = cx * xa + cy * xb + xc; }
@@ -223,12 +285,46 @@ __global__ void gta_apply_bwd_kernel(const ApplyBwdParams q) {
             if (p.mode == 0)      { v0 = a; v1 = bb; v2 = c - cx * a - cy * bb; }
             else if (p.mode == 1) { v0 = a + cx * c; v1 = bb + cy * c; v2 = c; }
             else                  { v0 = a - cx * c; v1 = bb - cy * c; v2 = c; }
-            st<ESZ>(dx, ch, v0); st<ESZ>(dx, ch + 1, v1); st<ESZ>(dx, ch + 2, v2);
+            DX(ch, v0); DX(ch + 1, v1); DX(ch + 2, v2);
         }
     }
-    if (q.dtc_rows) q.dtc_rows[row] = dc;
+    return dc;
 }
 
+template <int ESZ, bool STAGED>
+__global__ void gta_apply_bwd_kernel(const ApplyBwdParams q) {
+    const ApplyParams& p = q.f;
+    const long total = (long)p.B * p.H * p.T;
+    int b, h, t;
+    if constexpr (!STAGED) {
+        const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (row >= total) return;
+        row_decode(row, p.T, p.H, b, h, t);
+        const char* x = (const char*)p.x + ((long)b * p.x_sb + (long)h * p.x_sh + (long)t * p.x_st) * ESZ;
+        const char* dy = (const char*)q.dy + ((long)b * q.dy_sb + (long)h * q.dy_sh + (long)t * q.dy_st) * ESZ;
+        char* dx = (char*)q.dx + ((long)b * q.dx_sb + (long)h * q.dx_sh + (long)t * q.dx_st) * ESZ;
+        const float dc = apply_bwd_row(q, b, h, t, GIn<ESZ>{x}, GIn<ESZ>{dy}, GOut<ESZ>{dx});
+        if (q.dtc_rows) q.dtc_rows[row] = dc;
+    } else {                                             // one wave per workgroup: x in one stage, dy -> dx in place in a second
+        extern __shared__ float stage[];
+        const int dh = p.d_triv + p.d_se3 + p.d_so3 + p.d_so2 + p.d_t2, lane = threadIdx.x;
+        float* sx = stage;
+        float* sg = stage + 64 * (dh + 1);
+        const long row0 = (long)blockIdx.x * 64;
+        stage_rows<ESZ, true>(sx, p.x, row_offset(row0 + lane, total, p.T, p.H, p.x_sb, p.x_sh, p.x_st, ESZ), dh, lane);
+        stage_rows<ESZ, true>(sg, q.dy, row_offset(row0 + lane, total, p.T, p.H, q.dy_sb, q.dy_sh, q.dy_st, ESZ), dh, lane);
+        __syncthreads();
+        if (row0 + lane < total) {
+            row_decode(row0 + lane, p.T, p.H, b, h, t);
+            const float dc = apply_bwd_row(q, b, h, t, LIn{sx + lane * (dh + 1)}, LIn{sg + lane * (dh + 1)}, LOut{sg + lane * (dh + 1)});
+            if (q.dtc_rows) q.dtc_rows[row0 + lane] = dc;
+        }
+        __syncthreads();
+        stage_rows<ESZ, false>(sg, q.dx, row_offset(row0 + lane, total, p.T, p.H, q.dx_sb, q.dx_sh, q.dx_st, ESZ), dh, lane);
+    }
+}
+
+constexpr int APPLY_LDS_MAX = 160 * 1024;
 }  // namespace
 
 extern "C" int gta_rep_apply(const GtaAttnDesc* d, int32_t mode, const void* x, const int64_t* x_stride,
@@ -257,10 +353,22 @@ extern "C" int gta_rep_apply(const GtaAttnDesc* d, int32_t mode, const void* x, 
     p.d_triv = d->d_triv; p.d_se3 = d->d_se3; p.d_so3 = d->d_so3; p.d_so2 = d->d_so2; p.d_t2 = d->d_t2; p.L = d->so3_degree;
     p.mode = mode; p.euclid = euclid ? 1 : 0; p.esz = d->dtype == GTA_DTYPE_BF16 ? 2 : 4;
     const long total = (long)p.B * p.H * p.T;
+    const int lds = 64 * (d->dh + 1) * 4;                // the staged form: one wave per workgroup, its 64 rows in LDS
+    if (lds <= APPLY_LDS_MAX && (total + 63) / 64 < 0x7fffffffL) {
+        const unsigned nb = (unsigned)((total + 63) / 64);
+        if (p.esz == 2) {
+            if (int rc = gta_lds_optin<&gta_apply_kernel<2, true>>(APPLY_LDS_MAX)) return rc;
+            hipLaunchKernelGGL((gta_apply_kernel<2, true>), dim3(nb), dim3(64), lds, (hipStream_t)stream, p);
+        } else {
+            if (int rc = gta_lds_optin<&gta_apply_kernel<4, true>>(APPLY_LDS_MAX)) return rc;
+            hipLaunchKernelGGL((gta_apply_kernel<4, true>), dim3(nb), dim3(64), lds, (hipStream_t)stream, p);
+        }
+        return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH;
+    }
     const int th = 256;
     const unsigned nb = (unsigned)((total + th - 1) / th);
-    if (p.esz == 2) hipLaunchKernelGGL(gta_apply_kernel<2>, dim3(nb), dim3(th), 0, (hipStream_t)stream, p);
-    else            hipLaunchKernelGGL(gta_apply_kernel<4>, dim3(nb), dim3(th), 0, (hipStream_t)stream, p);
+    if (p.esz == 2) hipLaunchKernelGGL((gta_apply_kernel<2, false>), dim3(nb), dim3(th), 0, (hipStream_t)stream, p);
+    else            hipLaunchKernelGGL((gta_apply_kernel<4, false>), dim3(nb), dim3(th), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH;
 }
 
@@ -295,9 +403,21 @@ extern "C" int gta_rep_apply_bwd(const GtaAttnDesc* d, int32_t mode, const void*
     q.dx_sb = dx_stride[0]; q.dx_sh = dx_stride[1]; q.dx_st = dx_stride[2];
     q.dbias = dkey_bias; q.dtc_rows = dtc_rows;
     const long total = (long)p.B * p.H * p.T;
+    const int lds = 2 * 64 * (d->dh + 1) * 4;            // the staged form: x and dy -> dx of the wave's 64 rows in LDS
+    if (lds <= APPLY_LDS_MAX && (total + 63) / 64 < 0x7fffffffL) {
+        const unsigned nb = (unsigned)((total + 63) / 64);
+        if (p.esz == 2) {
+            if (int rc = gta_lds_optin<&gta_apply_bwd_kernel<2, true>>(APPLY_LDS_MAX)) return rc;
+            hipLaunchKernelGGL((gta_apply_bwd_kernel<2, true>), dim3(nb), dim3(64), lds, (hipStream_t)stream, q);
+        } else {
+            if (int rc = gta_lds_optin<&gta_apply_bwd_kernel<4, true>>(APPLY_LDS_MAX)) return rc;
+            hipLaunchKernelGGL((gta_apply_bwd_kernel<4, true>), dim3(nb), dim3(64), lds, (hipStream_t)stream, q);
+        }
+        return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH;
+    }
     const int th = 256;
     const unsigned nb = (unsigned)((total + th - 1) / th);
-    if (p.esz == 2) hipLaunchKernelGGL(gta_apply_bwd_kernel<2>, dim3(nb), dim3(th), 0, (hipStream_t)stream, q);
-    else            hipLaunchKernelGGL(gta_apply_bwd_kernel<4>, dim3(nb), dim3(th), 0, (hipStream_t)stream, q);
+    if (p.esz == 2) hipLaunchKernelGGL((gta_apply_bwd_kernel<2, false>), dim3(nb), dim3(th), 0, (hipStream_t)stream, q);
+    else            hipLaunchKernelGGL((gta_apply_bwd_kernel<4, false>), dim3(nb), dim3(th), 0, (hipStream_t)stream, q);
     return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH;
 }
