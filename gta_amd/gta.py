@@ -307,7 +307,9 @@ class _GenericAttn(torch.autograd.Function):
         Nq, Nk = _views(f_dims, packed, q, k)
         flags = (native.FLAG_V_TRANSFORM if v_transform else 0) | (native.FLAG_EUCLID if euclid else 0)
         dhp = (dh + 7) // 8 * 8                                    # the attention kernel works on 8-channel chunks
-        mk = lambda T: torch.zeros(B, T, H, dhp, device=q.device, dtype=dt).permute(0, 2, 1, 3)
+        # (every kernel below writes all dh channels of every row: only PADDING channels need the zero fill -- 6 us + a launch boundary per buffer)
+        alloc = torch.zeros if dhp != dh else torch.empty
+        mk = lambda T: alloc(B, T, H, dhp, device=q.device, dtype=dt).permute(0, 2, 1, 3)
         qp, kp, vp, op = mk(Tq), mk(Tk), mk(Tk), mk(Tq)
         out = torch.empty(B, Tq, H, dh, device=q.device, dtype=dt).permute(0, 2, 1, 3)
         desc = native.make_desc(q, k, v, out, f_dims, so3_degree, Nq, Nk, scale, flags)
@@ -351,13 +353,23 @@ class _GenericAttn(torch.autograd.Function):
         Nq, Nk = _views(f_dims, packed, q, k)
         desc = native.make_desc(q, k, v, q, f_dims, so3_degree, Nq, Nk, scale, ctx.flags)
         vq, vk = packed.get("vrep_q"), packed.get("vrep_k")
-        mk = lambda T, d=dhp: torch.zeros(B, T, H, d, device=q.device, dtype=dt).permute(0, 2, 1, 3)
-        rows = lambda T: torch.zeros(B, H, T, device=q.device, dtype=torch.float32)
+        # buffers the kernels write in full are not zero-filled (padding channels -- d > dh -- are); the per-row d trans_coeff terms of the four adjoints
+        # share ONE buffer, summed once in fp64 (four separate reductions were 110 us of the fp32-faithful backward at the CLEVR shape)
+        mk = lambda T, d=dhp: (torch.zeros if d != dh else torch.empty)(B, T, H, d, device=q.device, dtype=dt).permute(0, 2, 1, 3)
         need_tc = f_dims.get("se3", 0) > 0 and ctx.tc_meta is not None
+        n_rq, n_rk = B * H * Tq, B * H * Tk
+        n_rows = (n_rq + n_rk + (n_rk + n_rq if v_transform else 0)) if need_tc else 0
+        row_buf = torch.empty(n_rows, device=q.device, dtype=torch.float32) if need_tc else None
+        row_at = [0]
+
+        def rows(T):
+            a = row_at[0]
+            row_at[0] = a + B * H * T
+            return row_buf[a:row_at[0]].view(B, H, T)
         dout = dout.to(dt)
         # o = rho2(o~)  ->  do~ = rho2^T do
         dop = mk(Tq)
-        r_o = rows(Tq) if need_tc else None
+        r_o = rows(Tq) if (need_tc and v_transform) else None
         if v_transform:
             native.rep_apply_bwd(desc, 2, op[..., :dh], dout, vq, packed.get("cs_q"), packed.get("coord_q"), tc,
                                  dop[..., :dh], r_o)
@@ -399,7 +411,8 @@ class _GenericAttn(torch.autograd.Function):
             dbias = torch.zeros(B, H, pitch, device=q.device, dtype=torch.float32)
             dbias[..., :Tk] = dkp[..., dh].float()
         dq, dk, dv = mk(Tq, dh), mk(Tk, dh), mk(Tk, dh)
-        r_q, r_k, r_v = (rows(Tq), rows(Tk), rows(Tk)) if need_tc else (None, None, None)
+        r_q, r_k = (rows(Tq), rows(Tk)) if need_tc else (None, None)
+        r_v = rows(Tk) if (need_tc and v_transform) else None
         native.rep_apply_bwd(desc, 0, q, dqp[..., :dh], vq, packed.get("cs_q"), packed.get("coord_q"), tc, dq, r_q)
         native.rep_apply_bwd(desc, 1, k, dkp[..., :dh], vk, packed.get("cs_k"), packed.get("coord_k"), tc, dk, r_k,
                              dkey_bias=dbias, bias_scale=1.0)
@@ -410,12 +423,8 @@ class _GenericAttn(torch.autograd.Function):
             r_v = None
         dtc = None
         if need_tc:
-            tot = r_q.sum(dtype=torch.float64) + r_k.sum(dtype=torch.float64)
-            if r_v is not None:
-                tot = tot + r_v.sum(dtype=torch.float64)
-            if r_o is not None and v_transform:
-                tot = tot + r_o.sum(dtype=torch.float64)
-            dtc = tot.to(ctx.tc_meta[1]).reshape(ctx.tc_meta[0])
+            assert row_at[0] == n_rows
+            dtc = row_buf.sum(dtype=torch.float64).to(ctx.tc_meta[1]).reshape(ctx.tc_meta[0])
         return dq, dk, dv, dtc, dta, None, None
 
 
