@@ -36,18 +36,32 @@ GTA_DEV f32x16_t mfma32(float a, float b, f32x16_t c) { return __builtin_amdgcn_
 // rows of 32 x DHP fp32 tiles in LDS are DHP + 4 floats apart: the 16 lanes of a ds_read_b128 group then cover all 64 banks
 template <int DHP> struct P32 { static constexpr int HC = DHP / 2, ROW = DHP + 4, NB = DHP / 32; };
 
-// stage rows [t0, t0 + 32) of a [T][dh] fp32 matrix (row stride st) as a 32 x DHP tile (rows past T repeat the last one, channels
-// past dh are zero); 256 threads
+// rows [t0, t0 + 32) of a [T][dh] fp32 matrix (row stride st) as a 32 x DHP tile in LDS (rows past T repeat the last one, channels past dh
+// are zero), 256 threads, in two halves: the loads into registers (tile_fetch: issued BEFORE the previous tile's arithmetic, so their latency
+// lies under it -- the first form loaded and wrote a tile between two barriers and ran at 52 % of the fp32 matrix rate) and the LDS writes
+// (tile_put, between the barriers)
+template <int DHP> struct TileRegs { f32x4_t x[(32 * (DHP / 4) + 255) / 256]; };
 template <int DHP>
-GTA_DEV void stage_tile(float* dst, const float* src, long st, int t0, int T, int dh, int tid) {
-    constexpr int Q4 = DHP / 4;
-    for (int i = tid; i < 32 * Q4; i += 256) {
+GTA_DEV void tile_fetch(TileRegs<DHP>& R, const float* src, long st, int t0, int T, int dh, int tid) {
+    constexpr int Q4 = DHP / 4, N = (32 * Q4 + 255) / 256;
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const int i = tid + 256 * n;
         const int r = i / Q4, c4 = i - r * Q4;
         int t = t0 + r;
         t = t < T ? t : T - 1;
-        f32x4_t x = {0.f, 0.f, 0.f, 0.f};
-        if (4 * c4 < dh) x = *reinterpret_cast<const f32x4_t*>(src + (long)t * st + 4 * c4);
-        *reinterpret_cast<f32x4_t*>(dst + r * P32<DHP>::ROW + 4 * c4) = x;
+        R.x[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (i < 32 * Q4 && 4 * c4 < dh) R.x[n] = *reinterpret_cast<const f32x4_t*>(src + (long)t * st + 4 * c4);
+    }
+}
+template <int DHP>
+GTA_DEV void tile_put(float* dst, const TileRegs<DHP>& R, int tid) {
+    constexpr int Q4 = DHP / 4, N = (32 * Q4 + 255) / 256;
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const int i = tid + 256 * n;
+        const int r = i / Q4, c4 = i - r * Q4;
+        if (i < 32 * Q4) *reinterpret_cast<f32x4_t*>(dst + r * P32<DHP>::ROW + 4 * c4) = R.x[n];
     }
 }
 
@@ -124,11 +138,18 @@ __global__ __launch_bounds__(256) void plain32_dq_kernel(const Plain32Params p) 
     for (int d = 0; d < NB; ++d)
 #pragma unroll
         for (int i = 0; i < 16; ++i) dq[d][i] = 0.f;
+    TileRegs<DHP> rk, rv;
+    tile_fetch<DHP>(rk, kb, p.k_st, 0, p.Tk, p.dh, tid);
+    tile_fetch<DHP>(rv, vb, p.v_st, 0, p.Tk, p.dh, tid);
     for (int k0 = 0; k0 < p.Tk; k0 += 32) {
+        __syncthreads();                                         // (the previous tile's arithmetic is through with the LDS tiles)
+        tile_put<DHP>(ks, rk, tid);
+        tile_put<DHP>(vs, rv, tid);
         __syncthreads();
-        stage_tile<DHP>(ks, kb, p.k_st, k0, p.Tk, p.dh, tid);
-        stage_tile<DHP>(vs, vb, p.v_st, k0, p.Tk, p.dh, tid);
-        __syncthreads();
+        if (k0 + 32 < p.Tk) {                                    // the next tile's rows: in flight under this tile's arithmetic
+            tile_fetch<DHP>(rk, kb, p.k_st, k0 + 32, p.Tk, p.dh, tid);
+            tile_fetch<DHP>(rv, vb, p.v_st, k0 + 32, p.Tk, p.dh, tid);
+        }
         f32x16_t s, dp;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
@@ -179,15 +200,24 @@ __global__ __launch_bounds__(256) void plain32_dkv_kernel(const Plain32Params p)
     for (int d = 0; d < NB; ++d)
 #pragma unroll
         for (int i = 0; i < 16; ++i) { dk[d][i] = 0.f; dv[d][i] = 0.f; }
-    for (int q0 = 0; q0 < p.Tq; q0 += 32) {
-        __syncthreads();
-        stage_tile<DHP>(qs, qb, p.q_st, q0, p.Tq, p.dh, tid);
-        stage_tile<DHP>(ds_, db, p.do_st, q0, p.Tq, p.dh, tid);
+    TileRegs<DHP> rq, rd;
+    float rs = 0.f;
+    auto fetch = [&](int q0) {
+        tile_fetch<DHP>(rq, qb, p.q_st, q0, p.Tq, p.dh, tid);
+        tile_fetch<DHP>(rd, db, p.do_st, q0, p.Tq, p.dh, tid);
         if (tid < 64) {
             const int t = q0 + (tid & 31), tc = t < p.Tq ? t : p.Tq - 1;
-            st[tid] = tid < 32 ? lb[tc] * P32_LOG2E : Db[tc];
+            rs = tid < 32 ? lb[tc] * P32_LOG2E : Db[tc];
         }
+    };
+    fetch(0);
+    for (int q0 = 0; q0 < p.Tq; q0 += 32) {
+        __syncthreads();                                         // (the previous tile's arithmetic is through with the LDS tiles)
+        tile_put<DHP>(qs, rq, tid);
+        tile_put<DHP>(ds_, rd, tid);
+        if (tid < 64) st[tid] = rs;
         __syncthreads();
+        if (q0 + 32 < p.Tq) fetch(q0 + 32);                      // the next tile's rows: in flight under this tile's arithmetic
         f32x16_t s, dp;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
