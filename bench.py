@@ -317,7 +317,7 @@ def main():
                     help="also time one whole pre-LN layer around the operator (SURVEY 8 f1: the fused block of libgta_block.so "
                          "against the module-by-module path), forward and forward+backward; reported as `block_layer`, not "
                          "part of `value`; 0 = skip")
-    ap.add_argument("--kv-mode", dest="kv_mode", default="prepass", choices=["prepass", "fused", "prepass_rows32", "prepass_item_cxx", "prepass_bwd_keys32", "prepass_bwd_keys64", "prepass_bwd_split"],
+    ap.add_argument("--kv-mode", dest="kv_mode", default="prepass", choices=["prepass", "fused", "prepass_rows32", "prepass_item_cxx", "prepass_bwd_keys32", "prepass_bwd_keys64", "prepass_bwd_split", "prepass_bwd_keys64_split"],
                     help="execution plan of gta_attn_fwd (see include/gta_hip.h); prepass_rows32 = GTA_FLAG_ROWS32: the 32-rows-per-wave "
                          "attention kernel where the 64-rows one would run; prepass_item_cxx = GTA_FLAG_ITEM_CXX: the 64-rows kernel with its "
                          "compiler-scheduled item prologue / epilogue where the generated item stream would run (A/B)")

@@ -348,7 +348,7 @@ struct DqSmem {
     static constexpr int OFF_RING = 0;
     static constexpr int OFF_SCR = RING;                   // 8 floats of reduction scratch
     static constexpr int OFF_REC = RING + 32;
-    static int total(int nviews) { return OFF_REC + nviews * BREC * 4; }
+    static constexpr int total(int nviews) { return OFF_REC + nviews * BREC * 4; }
 };
 
 template <int BYTES>
@@ -374,20 +374,18 @@ GTA_DEV void dma_stats(float* dst, const float* src, int wave, int lane) {
 }
 
 template <int DHP, int ESZ>
-// (dh = 128: the 96-KiB ring admits one workgroup per CU anyway -- no reason to hold the kernel to 256 registers)
-__global__ __launch_bounds__(256, (DHP > 96 ? 1 : 2)) void gta_bwd_dq_kernel(const GtaBwdParams p) {
+// (body: workgroup L of nwg of this kernel's grid -- its own launch, or its share of the joint launch gta_bwd_dqkv_kernel)
+GTA_DEV void bwd_dq_body(const GtaBwdParams& p, char* smem, const int L, const int nwg) {
     using S = DqSmem<DHP>;
     constexpr int CHP = S::CHP, KS = DHP / 16, DB = DHP / 32, BM = 128;
     constexpr int DMA_PER_WAVE = S::STAGE / 1024 / 4;
     constexpr int ITEMS = 2 * CHP / 4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
 
     int w;
     {
-        const int nwg = gridDim.x, L = blockIdx.x;
         const int xcd = L & 7, idx = L >> 3, q8 = nwg >> 3, r8 = nwg & 7;
         w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     }
@@ -639,24 +637,21 @@ struct DkvSmem {
     static constexpr int OROW = DHP + 4;
     static constexpr int OST = 128 * OROW * 4;             // staging of dK' (then dV'): 128 keys
     static_assert(OST <= RING, "staging must fit the ring");
-    static int total(int nviews) { return OFF_REC + nviews * BREC * 4; }
+    static constexpr int total(int nviews) { return OFF_REC + nviews * BREC * 4; }
 };
 
 template <int DHP, int ESZ>
-// (dh = 128: one workgroup per CU -- with two, the 256-register budget left 117 dwords of scratch in the tile loop)
-__global__ __launch_bounds__(256, (DHP > 96 ? 1 : 2)) void gta_bwd_dkv_kernel(const GtaBwdParams p) {
+GTA_DEV void bwd_dkv_body(const GtaBwdParams& p, char* smem, const int L, const int nwg) {
     using S = DkvSmem<DHP>;
     constexpr int CHP = S::CHP, KS = DHP / 16, DB = DHP / 32, BK = 128;
     constexpr int DMA_PER_WAVE = S::STAGE / 1024 / 4;
     constexpr int ITEMS = 2 * CHP / 4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
 
     int w;
     {
-        const int nwg = gridDim.x, L = blockIdx.x;
         const int xcd = L & 7, idx = L >> 3, q8 = nwg >> 3, r8 = nwg & 7;
         w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     }
@@ -901,6 +896,27 @@ __global__ __launch_bounds__(256, (DHP > 96 ? 1 : 2)) void gta_bwd_dkv_kernel(co
     }
     const float dc_wg = wg_sum256(dcpart, reinterpret_cast<float*>(smem + S::OFF_SCR), tid);
     if (tid == 0) p.dc_partial[p.dc_off_dkv + w] = dc_wg;
+}
+
+// the two compiled kernels, and both in ONE launch (as gta_bwd_dqkv64_kernel for the generated pair, below: they depend on the q-side pre-pass
+// only; the dK/dV blocks -- the longer ones -- first).  dh = 128: one workgroup per CU (the 96-KiB ring admits one anyway; with two, the
+// 256-register budget left 117 dwords of scratch in the dK/dV tile loop)
+template <int DHP, int ESZ>
+__global__ __launch_bounds__(256, (DHP > 96 ? 1 : 2)) void gta_bwd_dq_kernel(const GtaBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bwd_dq_body<DHP, ESZ>(p, smem, blockIdx.x, gridDim.x);
+}
+template <int DHP, int ESZ>
+__global__ __launch_bounds__(256, (DHP > 96 ? 1 : 2)) void gta_bwd_dkv_kernel(const GtaBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bwd_dkv_body<DHP, ESZ>(p, smem, blockIdx.x, gridDim.x);
+}
+template <int DHP, int ESZ>
+__global__ __launch_bounds__(256, (DHP > 96 ? 1 : 2)) void gta_bwd_dqkv_kernel(const GtaBwdParams p, const int n_dq) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int L = blockIdx.x, n_dkv = (int)gridDim.x - n_dq;
+    if (L < n_dkv) bwd_dkv_body<DHP, ESZ>(p, smem, L, n_dkv);
+    else bwd_dq_body<DHP, ESZ>(p, smem, L - n_dkv, n_dq);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1362,10 +1378,17 @@ int run_bwd(const GtaBwdParams& p, hipStream_t stream) {
             }
         }
     }
-    if (!dq64 && !dkv64)
-        hipLaunchKernelGGL((gta_bwd_dq_kernel<DHP, ESZ>), dim3(n_dq), dim3(256), DqSmem<DHP>::total(p.vrep_q ? p.Nq : 0), stream, p);
-    if (!dkv64)
-        hipLaunchKernelGGL((gta_bwd_dkv_kernel<DHP, ESZ>), dim3(n_dkv), dim3(256), DkvSmem<DHP>::total(p.vrep_k ? p.Nk : 0), stream, p);
+    if (!dq64 && !dkv64 && n_dkv % 8 == 0 && (long)n_dq + n_dkv < 0x7fffffffL && !(p.flags & GTA_FLAG_BWD_SPLIT)) {      // the compiled pair in one launch
+        const int lds_dq = DqSmem<DHP>::total(p.vrep_q ? p.Nq : 0), lds_dkv = DkvSmem<DHP>::total(p.vrep_k ? p.Nk : 0);
+        constexpr int LDS_MAX = DqSmem<DHP>::total(GTA_MAX_VIEWS) > DkvSmem<DHP>::total(GTA_MAX_VIEWS) ? DqSmem<DHP>::total(GTA_MAX_VIEWS) : DkvSmem<DHP>::total(GTA_MAX_VIEWS);
+        if (int rc = gta_lds_optin<&gta_bwd_dqkv_kernel<DHP, ESZ>>(LDS_MAX)) return rc;
+        hipLaunchKernelGGL((gta_bwd_dqkv_kernel<DHP, ESZ>), dim3((unsigned)(n_dq + n_dkv)), dim3(256), lds_dq > lds_dkv ? lds_dq : lds_dkv, stream, p, n_dq);
+    } else {
+        if (!dq64 && !dkv64)
+            hipLaunchKernelGGL((gta_bwd_dq_kernel<DHP, ESZ>), dim3(n_dq), dim3(256), DqSmem<DHP>::total(p.vrep_q ? p.Nq : 0), stream, p);
+        if (!dkv64)
+            hipLaunchKernelGGL((gta_bwd_dkv_kernel<DHP, ESZ>), dim3(n_dkv), dim3(256), DkvSmem<DHP>::total(p.vrep_k ? p.Nk : 0), stream, p);
+    }
     if (p.dtrans_coeff)
         hipLaunchKernelGGL(gta_reduce_kernel, dim3(1), dim3(1024), 0, stream, p.dc_partial, p.dc_total, p.dtrans_coeff,
                            (const float*)nullptr);

@@ -474,10 +474,13 @@ def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: 
     if kv_mode == "prepass_item_cxx":  # tuning knob: the 64-rows kernel with its compiler-scheduled item prologue / epilogue (not the item stream)
         flags |= native.FLAG_ITEM_CXX
         kv_mode = "prepass"
-    if kv_mode in ("prepass_bwd_keys32", "prepass_bwd_keys64", "prepass_bwd_split"):
-        # tuning knobs of the backward: the 32-keys-per-wave dK/dV kernel / the generated 64-keys streams whatever the size / those streams (forced as
-        # by keys64) as two launches instead of the joint one
-        flags |= native.FLAG_BWD_KEYS32 if kv_mode.endswith("32") else native.FLAG_BWD_KEYS64
+    if kv_mode in ("prepass_bwd_keys32", "prepass_bwd_keys64", "prepass_bwd_split", "prepass_bwd_keys64_split"):
+        # tuning knobs of the backward: the 32-keys-per-wave dK/dV kernel / the generated 64-keys streams whatever the size / the dQ and dK/dV kernels
+        # (whichever pair the size selects; keys64_split: the generated pair) as two launches instead of the joint one
+        if "keys32" in kv_mode:
+            flags |= native.FLAG_BWD_KEYS32
+        if "keys64" in kv_mode:
+            flags |= native.FLAG_BWD_KEYS64
         if kv_mode.endswith("split"):
             flags |= native.FLAG_BWD_SPLIT
         kv_mode = "prepass"

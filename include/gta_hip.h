@@ -50,8 +50,8 @@ extern "C" {
 #define GTA_FLAG_BWD_KEYS32    (1u << 13) /* tuning / diagnostics (gta_attn_bwd): keep the 32-keys-per-wave dK/dV kernel where the generated    */
                                           /* 64-per-wave streams (gen_bwd64.py: bf16, dh = 96, MSN layout, >= 128 blocks of 256 keys / rows) would run        */
 #define GTA_FLAG_BWD_KEYS64    (1u << 14) /* tuning / diagnostics (gta_attn_bwd): run that stream at bf16, dh = 96 whatever the number of blocks    */
-#define GTA_FLAG_BWD_SPLIT     (1u << 15) /* tuning / diagnostics (gta_attn_bwd): the generated dQ and dK/dV kernels as two launches (per-kernel times under a   */
-                                          /* profiler) where one joint launch would run; same results bit for bit                                               */
+#define GTA_FLAG_BWD_SPLIT     (1u << 15) /* tuning / diagnostics (gta_attn_bwd): the dQ and dK/dV kernels as two launches (per-kernel times under a profiler)     */
+                                          /* where one joint launch would run; same results bit for bit                                                         */
 #define GTA_FLAG_NO_DMA        (1u << 8) /* debug: stage K/V tiles through VGPRs, not LDS-DMA  */
 
 /* error codes */

@@ -178,7 +178,7 @@ def test_dkv64_stream_matches_keys32_kernel_bit_for_bit(shape):
         gta_amd.pre_compute_reps_decoder(ak, exd)
     packed = gta_amd.pack_reps(exd, f_dims)
     res = {}
-    for mode in ("prepass_bwd_keys32", "prepass_bwd_keys64", "prepass_bwd_split"):
+    for mode in ("prepass_bwd_keys32", "prepass_bwd_keys64", "prepass_bwd_keys64_split"):
         qd, kd, vd = (t.bfloat16().cuda().requires_grad_() for t in (q, k, v))
         tcd = torch.tensor([0.37], device="cuda", requires_grad=True)
         out = gta_amd.gta_attention(qd, kd, vd, f_dims, packed, so3_degree=exd.get("gta_so3_degree", 0), trans_coeff=tcd, kv_mode=mode)
@@ -193,7 +193,7 @@ def test_dkv64_stream_matches_keys32_kernel_bit_for_bit(shape):
     assert abs(a[3] - b[3]) <= 1e-4 * max(1.0, abs(a[3])), (a[3], b[3])
     # the two generated kernels as ONE launch (gta_bwd_dqkv64_kernel: the default where both run and the dQ blocks are a multiple of 8 -- MS-enc,
     # MS-dec here) and as two (GTA_FLAG_BWD_SPLIT): the same workgroups doing the same work
-    c = res["prepass_bwd_split"]
+    c = res["prepass_bwd_keys64_split"]
     assert all(torch.equal(b[i], c[i]) for i in range(3)) and b[3] == c[3]
 
 
@@ -317,3 +317,28 @@ def test_bench_size_sampled_scenes_gradients_vs_oracle(shape):
     (out_o * w[idx]).sum().backward()
     for name, a, b in (("dq", qd, qo), ("dk", kd, ko), ("dv", vd, vo)):
         _check(a.grad[idx.cuda()].float().cpu(), b.grad, name)
+
+
+@pytest.mark.parametrize("shape", ["C1", "MS-enc", "MS-dec"])
+def test_compiled_backward_joint_launch_matches_two_launches(shape):
+    """the compiled dQ and dK/dV kernels as ONE launch (gta_bwd_dqkv_kernel: the default where neither generated stream runs and the dK/dV blocks
+    are a multiple of 8 -- these shapes) against two launches (GTA_FLAG_BWD_SPLIT): the same workgroups doing the same work, bit for bit"""
+    B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3 = SHAPES[shape]
+    assert (B * H * ((Nk * Pk + 127) // 128)) % 8 == 0
+    q, k, v, ex, ak, cross = C.synth_inputs(B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, torch.bfloat16, seed=31)
+    w = torch.randn(q.shape, generator=torch.Generator().manual_seed(32)).cuda()
+    exd = {kk: vv.cuda() for kk, vv in ex.items()}
+    gta_amd.pre_compute_reps_encoder(ak, exd)
+    if cross:
+        gta_amd.pre_compute_reps_decoder(ak, exd)
+    packed = gta_amd.pack_reps(exd, f_dims)
+    res = {}
+    for mode in ("prepass", "prepass_bwd_split"):
+        qd, kd, vd = (t.bfloat16().cuda().requires_grad_() for t in (q, k, v))
+        tcd = torch.tensor([0.37], device="cuda", requires_grad=True)
+        out = gta_amd.gta_attention(qd, kd, vd, f_dims, packed, so3_degree=exd.get("gta_so3_degree", 0), trans_coeff=tcd, kv_mode=mode)
+        (out.float() * w).sum().backward()
+        torch.cuda.synchronize()
+        res[mode] = (qd.grad.float().cpu(), kd.grad.float().cpu(), vd.grad.float().cpu(), float(tcd.grad.item()))
+    a, b = res["prepass"], res["prepass_bwd_split"]
+    assert a[1].abs().max() > 0 and all(torch.equal(a[i], b[i]) for i in range(3)) and a[3] == b[3]
