@@ -44,31 +44,32 @@ GTA_DEV void row_decode(long row, int T, int H, int& b, int& h, int& t) {
 }
 // 64 rows of dh elements between global memory (base + (b sb + h sh + t st) elements, rows [row0, row0 + 64) of the launch) and a wave's stage
 // [64][dh + 1] floats: one access per row and 64 channels.  Lane l knows the offset of row row0 + l (my_off, bytes; < 0 past the end); the
-// wave reads them back lane by lane (uniform values), EIGHT rows' loads in flight before their LDS writes (a load -> write chain per row
+// wave reads them back lane by lane (uniform values), SIXTEEN rows' loads in flight before their LDS writes (a load -> write chain per row
 // cost one memory latency per row: 64 of them in a row were most of these kernels' time)
 template <int ESZ, bool IN>
 GTA_DEV void stage_rows(float* stage, const void* base, const long my_off, const int dh, const int lane) {
+    constexpr int NB = 16;                               // rows in flight per batch
     for (int ch = lane; ch < dh; ch += 64) {
 #pragma unroll 1
-        for (int r0 = 0; r0 < 64; r0 += 8) {
-            long off[8];
-            float v[8];
+        for (int r0 = 0; r0 < 64; r0 += NB) {
+            long off[NB];
+            float v[NB];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < NB; ++u) {
                 const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)(uint64_t)my_off, r0 + u);
                 const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)((uint64_t)my_off >> 32), r0 + u);
                 off[u] = (long)(((uint64_t)hi << 32) | lo);
             }
             if (IN) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = off[u] >= 0 ? ld<ESZ>((const char*)base + off[u], ch) : 0.f;
+                for (int u = 0; u < NB; ++u) v[u] = off[u] >= 0 ? ld<ESZ>((const char*)base + off[u], ch) : 0.f;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) stage[(r0 + u) * (dh + 1) + ch] = v[u];
+                for (int u = 0; u < NB; ++u) stage[(r0 + u) * (dh + 1) + ch] = v[u];
             } else {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = stage[(r0 + u) * (dh + 1) + ch];
+                for (int u = 0; u < NB; ++u) v[u] = stage[(r0 + u) * (dh + 1) + ch];
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
+                for (int u = 0; u < NB; ++u)
                     if (off[u] >= 0) st<ESZ>((char*)base + off[u], ch, v[u]);
             }
         }
