@@ -126,6 +126,140 @@ def kernel_clock(prof):
     return span_us * mhz, mhz
 
 
+class PlannedStep:
+    """One workload's step through the planned C-ABI path: rep build(s) + ONE gta_attn_fwd (K/V pre-pass + attention kernel), inputs resident
+    in HBM; `step(i)` of a sampled index i also attaches dispatch events and per-item stamps to the attention kernel's own launch."""
+
+    def __init__(self, workload, B, dtype_name, device, L, seed, steps, kernel_samples, flags=0, time_kernel=True):
+        import gta_amd
+        from gta_amd import plan, synth
+        H, Nq, Pq, Nk, Pk, f_dims, so2, so3, _ = WORKLOADS[workload]
+        self.L, self.B, self.H, self.f_dims = L, B, H, f_dims
+        self.dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
+        qm, km, vm, ex, ak, cross = synth.attention_inputs(B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, seed=seed)
+        self.masters, self.ak, self.cross = (qm, km, vm, ex), ak, cross
+        # Q/K/V as the module's packed projection leaves them: [B, T, H, dh] in memory, viewed [B, H, T, dh]
+        self.q, self.k, self.v = (synth.as_projection(t, self.dtype, device) for t in (qm, km, vm))
+        self.exd = {kk: vv.to(device).contiguous() for kk, vv in ex.items()}
+        self.tc = torch.tensor([0.01], device=device) if f_dims.get("se3", 0) > 0 else None
+        self.Tq, self.Tk, self.dh = Nq * Pq, Nk * Pk, sum(f_dims.values())
+        need_view = f_dims.get("se3", 0) > 0 or f_dims.get("so3", 0) > 0
+        self.so3_deg = so3 if f_dims.get("so3", 0) > 0 else 0
+        # ---- the planned step: rep build(s) + one gta_attn_fwd ----
+        self.reps_k = plan.RepPlan(B, Nk, Pk, self.so3_deg, so2, device=device) if (need_view and f_dims.get("so2", 0) > 0) else None
+        self.reps_q = plan.RepPlan(B, Nq, Pq, self.so3_deg, so2, device=device) if (self.reps_k is not None and cross) else None
+        self.fwd = plan.ForwardPlan(self.q, self.k, self.v, f_dims, so3_degree=self.so3_deg, Nq=Nq if need_view else 1,
+                                    Nk=Nk if need_view else 1, flags=flags)
+        n_it, rows_it = ctypes.c_int32(0), ctypes.c_int32(0)
+        self.kname = (L.gta_debug_attention_kernel(ctypes.byref(self.fwd.desc), ctypes.byref(n_it), ctypes.byref(rows_it)) or b"").decode()
+        self.rows_it = rows_it.value
+        self.time_kernel = time_kernel
+        n_samp = steps if kernel_samples <= 0 else min(kernel_samples, steps)
+        stride = max(1, steps // n_samp)
+        self.sampled = {i: len(range(stride // 2, i, stride)) for i in range(stride // 2, steps, stride)} if time_kernel else {}   # step -> event slot
+        self.ev = [(L.gta_debug_event_create(), L.gta_debug_event_create()) for _ in self.sampled]
+        self.n_samples = len(self.ev)
+        # the sampled launches also leave per-item start / end stamps (shader cycles + 100-MHz clock): kernel cycles and granted clock
+        self.profs = [torch.zeros(max(n_it.value, 1), 8, dtype=torch.int64, device=device) for _ in self.sampled]
+        self._gta = gta_amd
+
+    def build_reps(self):
+        exd, cross = self.exd, self.cross
+        if self.reps_k is not None:
+            vk, ck = self.reps_k(exd["input_transforms"], exd["input_coord"])
+            vq, cq = self.reps_q(exd["target_transforms"], exd["target_coord"]) if cross else (vk, ck)
+            return vq, vk, cq, ck
+        # layouts without a per-view part (or without so2): the general builders of gta_amd.reps
+        e2 = dict(exd)
+        self._gta.pre_compute_reps_encoder(self.ak, e2)
+        if cross:
+            self._gta.pre_compute_reps_decoder(self.ak, e2)
+        pk = self._gta.pack_reps(e2, self.f_dims)
+        return pk.get("vrep_q"), pk.get("vrep_k"), pk.get("cs_q"), pk.get("cs_k")
+
+    def step(self, i=None):
+        L = self.L
+        vq, vk, cq, ck = self.build_reps()                 # reps are rebuilt every step (timed)
+        if i in self.sampled:
+            e = self.ev[self.sampled[i]]
+            L.gta_debug_time_next_attention_kernel(ctypes.c_void_p(e[0]), ctypes.c_void_p(e[1]))
+            pb = self.profs[self.sampled[i]]
+            L.gta_debug_profile_next_attention_kernel(ctypes.c_void_p(pb.data_ptr()), pb.shape[0])      # (one-shot: this launch only)
+        return self.fwd(self.q, self.k, self.v, vq, vk, cq, ck, self.tc)
+
+    def kernel_times(self):
+        """(mean attention-kernel ms by the events of its own dispatch, mean shader cycles per launch, granted clock in MHz) over the sampled steps"""
+        if not self.ev:
+            return None, None, None
+        L = self.L
+        ks = [L.gta_debug_event_elapsed_ms(ctypes.c_void_p(a), ctypes.c_void_p(b)) for a, b in self.ev]
+        kern_ms = sum(ks) / len(ks)                         # attention kernel only (events of its own dispatch)
+        cyc = [kernel_clock(p_) for p_ in self.profs]
+        cyc = [c for c in cyc if c[0]]
+        kern_cycles = sum(c[0] for c in cyc) / len(cyc) if cyc else None
+        sclk_mhz = sum(c[1] for c in cyc) / len(cyc) if cyc else None
+        return kern_ms, kern_cycles, sclk_mhz
+
+    def release_events(self):
+        for a, b in self.ev:
+            self.L.gta_debug_event_destroy(ctypes.c_void_p(a)); self.L.gta_debug_event_destroy(ctypes.c_void_p(b))
+        self.ev = []
+
+    def flops(self):
+        return 4.0 * self.B * self.H * self.Tq * self.Tk * self.dh      # QK^T + PV, 2 flop/MAC (SURVEY 8d)
+
+
+def workload_leg(name, dtype_name, device, L, seed, steps=30, warmup=5, kernel_samples=6, bwd_steps=3):
+    """One of the OTHER BASELINE workloads, measured exactly as the headline (same planned step, same dispatch events and stamps), in well
+    under a second of GPU time -> the entry of the line's `workloads` object.  Never part of `value`."""
+    import gta_amd
+    B = WORKLOADS[name][8]
+    ps = PlannedStep(name, B, dtype_name, device, L, seed=seed, steps=steps, kernel_samples=kernel_samples)
+    for _ in range(warmup):
+        ps.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ps.step(i)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    kern_ms, cyc, mhz = ps.kernel_times()
+    ps.release_events()
+    fl = ps.flops()
+    out = {"value": B * ps.Tq / (ms * 1e-3) / 1e6, "unit": "Mtokens/s", "ms_per_step": ms, "steps": steps, "warmup": warmup, "batch": B,
+           "kernel": ps.kname, "kernel_ms": kern_ms, "frac": (fl / (kern_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if kern_ms else None,
+           "step_frac": fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "kernel_cycles": cyc, "sclk_mhz": mhz,
+           "mfma_busy": (fl / MFMA_FLOP_PER_CYCLE / cyc) if cyc else None, "algorithmic_flops": fl,
+           "shape": {"H": ps.H, "Tq": ps.Tq, "Tk": ps.Tk, "dh": ps.dh}}
+    # the full-batch output against the oracle on one scene (the GPU tests hold the full parity matrix of this workload)
+    out["parity"] = parity_check(ps.fwd.out, ps.masters, ps.ak, ps.cross, [B - 1])
+    if bwd_steps > 0:
+        qg, kg, vg = (t.detach().clone().requires_grad_() for t in (ps.q, ps.k, ps.v))
+        tcg = ps.tc.detach().clone().requires_grad_() if ps.tc is not None else None
+        e2 = dict(ps.exd)
+        gta_amd.pre_compute_reps_encoder(ps.ak, e2)
+        if ps.cross:
+            gta_amd.pre_compute_reps_decoder(ps.ak, e2)
+        packed = gta_amd.pack_reps(e2, ps.f_dims)
+        w = torch.randn_like(ps.q)
+
+        def train_step():
+            o = gta_amd.gta_attention(qg, kg, vg, ps.f_dims, packed, so3_degree=e2.get("gta_so3_degree", 0), trans_coeff=tcg)
+            o.backward(w)
+            qg.grad = kg.grad = vg.grad = None
+        for _ in range(2):
+            train_step()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(bwd_steps):
+            train_step()
+        e1.record()
+        torch.cuda.synchronize()
+        out["fwd_bwd_ms"] = e0.elapsed_time(e1) / bwd_steps
+    return out
+
+
 def model_train_leg(args, dist, world, rank, local_rank, device, model, loss_of):
     """K optimizer steps of ``model`` (sub-modules ``encoder`` / ``decoder``) under the reference's data-parallel structure
     (train.py:182-188: each in its OWN DistributedDataParallel -> two bucketed gradient all-reduce streams per step, RCCL over xGMI on
@@ -317,6 +451,11 @@ def main():
                     help="also time one whole pre-LN layer around the operator (SURVEY 8 f1: the fused block of libgta_block.so "
                          "against the module-by-module path), forward and forward+backward; reported as `block_layer`, not "
                          "part of `value`; 0 = skip")
+    ap.add_argument("--workloads", default="auto",
+                    help="comma-separated list of OTHER BASELINE workloads to measure after the headline's timed region (30 steps each, same "
+                         "planned step, dispatch events and per-item stamps; under a second of GPU time each) -> the `workloads` object of the "
+                         "JSON line; never part of `value`.  auto = ms-dec,cl-enc,cl-dec,dit when the headline workload is ms-enc on bf16 and "
+                         "this is rank 0, none otherwise; none = skip")
     ap.add_argument("--kv-mode", dest="kv_mode", default="prepass", choices=["prepass", "fused", "prepass_rows32", "prepass_item_cxx", "prepass_bwd_keys32", "prepass_bwd_keys64", "prepass_bwd_split", "prepass_bwd_keys64_split"],
                     help="execution plan of gta_attn_fwd (see include/gta_hip.h); prepass_rows32 = GTA_FLAG_ROWS32: the 32-rows-per-wave "
                          "attention kernel where the 64-rows one would run; prepass_item_cxx = GTA_FLAG_ITEM_CXX: the 64-rows kernel with its "
@@ -354,60 +493,20 @@ def main():
 
     H, Nq, Pq, Nk, Pk, f_dims, so2, so3, Bdef = WORKLOADS[args.workload]
     B = args.batch or Bdef
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    qm, km, vm, ex, ak, cross = synth.attention_inputs(B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, seed=1234 + rank)
-    # Q/K/V as the module's packed projection leaves them: [B, T, H, dh] in memory, viewed [B, H, T, dh]
-    q, k, v = (synth.as_projection(t, dtype, device) for t in (qm, km, vm))
-    exd = {kk: vv.to(device).contiguous() for kk, vv in ex.items()}
-    tc = torch.tensor([0.01], device=device) if f_dims.get("se3", 0) > 0 else None
-    Tq, Tk, dh = Nq * Pq, Nk * Pk, sum(f_dims.values())
-    need_view = f_dims.get("se3", 0) > 0 or f_dims.get("so3", 0) > 0
-    so3_deg = so3 if f_dims.get("so3", 0) > 0 else 0
     if args.precise:
         if args.dtype != "f32":
             raise SystemExit("--precise is the fp32-faithful mode: use --dtype f32")
         args.kv_mode = "fused"                             # (the timed forward of the mode is the single-kernel plan; its fwd_bwd leg runs
                                                            #  rho in fp32 + the exact-fp32 backward of gta_plain32.hip)
     fused = args.kv_mode == "fused"
-
-    # ---- the planned step: rep build(s) + one gta_attn_fwd ----
-    reps_k = plan.RepPlan(B, Nk, Pk, so3_deg, so2, device=device) if (need_view and f_dims.get("so2", 0) > 0) else None
-    reps_q = plan.RepPlan(B, Nq, Pq, so3_deg, so2, device=device) if (reps_k is not None and cross) else None
-    fwd = plan.ForwardPlan(q, k, v, f_dims, so3_degree=so3_deg, Nq=Nq if need_view else 1, Nk=Nk if need_view else 1,
-                           flags=(native.FLAG_FUSED_KV | (native.FLAG_FP32_PRODUCTS if args.precise else 0)) if fused
-                           else native.FLAG_ROWS32 if args.kv_mode == "prepass_rows32"
-                           else native.FLAG_ITEM_CXX if args.kv_mode == "prepass_item_cxx" else 0)
-    n_it, rows_it = ctypes.c_int32(0), ctypes.c_int32(0)
-    kname = (L.gta_debug_attention_kernel(ctypes.byref(fwd.desc), ctypes.byref(n_it), ctypes.byref(rows_it)) or b"").decode()
-    n_samp = args.steps if args.kernel_samples <= 0 else min(args.kernel_samples, args.steps)
-    stride = max(1, args.steps // n_samp)
-    sampled = {i: len(range(stride // 2, i, stride)) for i in range(stride // 2, args.steps, stride)}   # step -> event slot
-    ev = [(L.gta_debug_event_create(), L.gta_debug_event_create()) for _ in sampled]
-    # the sampled launches also leave per-item start / end stamps (shader cycles + 100-MHz clock): kernel cycles and granted clock
-    profs = [torch.zeros(max(n_it.value, 1), 8, dtype=torch.int64, device=device) for _ in sampled]
-
-    def build_reps():
-        if reps_k is not None:
-            vk, ck = reps_k(exd["input_transforms"], exd["input_coord"])
-            vq, cq = reps_q(exd["target_transforms"], exd["target_coord"]) if cross else (vk, ck)
-            return vq, vk, cq, ck
-        # layouts without a per-view part (or without so2): the general builders of gta_amd.reps
-        e2 = dict(exd)
-        gta_amd.pre_compute_reps_encoder(ak, e2)
-        if cross:
-            gta_amd.pre_compute_reps_decoder(ak, e2)
-        pk = gta_amd.pack_reps(e2, f_dims)
-        return pk.get("vrep_q"), pk.get("vrep_k"), pk.get("cs_q"), pk.get("cs_k")
-
-    def step(i=None):
-        vq, vk, cq, ck = build_reps()                      # reps are rebuilt every step (timed)
-        if i in sampled and not fused:
-            e = ev[sampled[i]]
-            L.gta_debug_time_next_attention_kernel(ctypes.c_void_p(e[0]), ctypes.c_void_p(e[1]))
-            pb = profs[sampled[i]]
-            L.gta_debug_profile_next_attention_kernel(ctypes.c_void_p(pb.data_ptr()), pb.shape[0])      # (one-shot: this launch only)
-            return fwd(q, k, v, vq, vk, cq, ck, tc)
-        return fwd(q, k, v, vq, vk, cq, ck, tc)
+    ps = PlannedStep(args.workload, B, args.dtype, device, L, seed=1234 + rank, steps=args.steps, kernel_samples=args.kernel_samples,
+                     flags=(native.FLAG_FUSED_KV | (native.FLAG_FP32_PRODUCTS if args.precise else 0)) if fused
+                     else native.FLAG_ROWS32 if args.kv_mode == "prepass_rows32"
+                     else native.FLAG_ITEM_CXX if args.kv_mode == "prepass_item_cxx" else 0, time_kernel=not fused)
+    step, fwd, q, k, v, exd, tc, ak, cross, kname, rows_it = ps.step, ps.fwd, ps.q, ps.k, ps.v, ps.exd, ps.tc, ps.ak, ps.cross, ps.kname, ps.rows_it
+    qm, km, vm, ex = ps.masters
+    Tq, Tk, dh = ps.Tq, ps.Tk, ps.dh
+    dtype = ps.dtype
 
     for _ in range(args.warmup):
         step()
@@ -434,18 +533,9 @@ def main():
         dist.all_gather(g, torch.tensor([mine / args.steps * 1e3], device=device, dtype=torch.float64))
         per_rank = [float(u.item()) for u in g]
 
-    kern_cycles = sclk_mhz = None
-    if fused:
-        kern_ms = None
-    else:
-        ks = [L.gta_debug_event_elapsed_ms(ctypes.c_void_p(a), ctypes.c_void_p(b)) for a, b in ev]
-        kern_ms = sum(ks) / len(ks)                         # attention kernel only (events of its own dispatch)
-        cyc = [kernel_clock(p_) for p_ in profs]
-        cyc = [c for c in cyc if c[0]]
-        kern_cycles = sum(c[0] for c in cyc) / len(cyc) if cyc else None
-        sclk_mhz = sum(c[1] for c in cyc) / len(cyc) if cyc else None
-    for a, b in ev:
-        L.gta_debug_event_destroy(ctypes.c_void_p(a)); L.gta_debug_event_destroy(ctypes.c_void_p(b))
+    kern_ms, kern_cycles, sclk_mhz = ps.kernel_times()
+    n_kernel_samples = ps.n_samples
+    ps.release_events()
     # every rank's granted shader clock and attention-kernel time (eight GPUs under load are not granted one clock)
     per_rank_sclk, per_rank_kern = [sclk_mhz], [kern_ms]
     if dist is not None:
@@ -495,6 +585,20 @@ def main():
             block_layer = block_layer_leg(B, args.block_steps, device)
         except Exception as e:  # noqa: BLE001
             extra_errors["block_layer"] = f"{type(e).__name__}: {str(e)[:300]}"
+    workloads = None
+    wl_names = ([w for w in ("ms-dec", "cl-enc", "cl-dec", "dit") if w != args.workload]
+                if (args.workloads == "auto" and args.workload == "ms-enc" and args.dtype == "bf16" and not fused and args.kv_mode == "prepass")
+                else [] if args.workloads in ("auto", "none", "") else [w for w in args.workloads.split(",") if w])
+    if wl_names and rank == 0:
+        # the other BASELINE workloads (configs 2, 3's decoder, 5) on the same box, right behind the headline: what only the builder's
+        # `workloads.jsonl` held before.  The headline's tensors are released first (ms-dec alone holds 0.6 GB).
+        workloads = {}
+        for w in wl_names:
+            try:
+                workloads[w] = workload_leg(w, args.dtype, device, L, seed=1234 + rank)
+            except Exception as e:  # noqa: BLE001   (an extra leg: reported, the headline line is still printed)
+                workloads[w] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+            torch.cuda.empty_cache()
     srt_train = None
     if args.model_train_steps > 0:
         # whole-model optimizer step (conv stem, 5 + 2 Transformer blocks on the HIP attention path,
@@ -538,10 +642,10 @@ def main():
             "dist": __import__("gta_amd.ddp", fromlist=["backend_info"]).backend_info(),
         }
         if achieved is not None:
-            line["roofline"] = {"bound": "mfma", "kernel": kname, "rows_per_item": rows_it.value, "achieved": achieved,
+            line["roofline"] = {"bound": "mfma", "kernel": kname, "rows_per_item": rows_it, "achieved": achieved,
                                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
                                 "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                                "kernel_ms": kern_ms, "kernel_samples": len(ev), "algorithmic_flops": flops, "algorithmic_bytes": alg_bytes,
+                                "kernel_ms": kern_ms, "kernel_samples": n_kernel_samples, "algorithmic_flops": flops, "algorithmic_bytes": alg_bytes,
                                 "hbm_frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                 "step_frac": flops / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                                 # box-independent view of the same launches (per-item s_memtime / s_memrealtime stamps): a move in
@@ -561,6 +665,8 @@ def main():
                                        "not part of `value`"}
         if block_layer is not None:
             line["block_layer"] = block_layer
+        if workloads is not None:
+            line["workloads"] = workloads
         if srt_train is not None:
             line["srt_train"] = srt_train
         if not args.no_cpu_baseline and n == 1:

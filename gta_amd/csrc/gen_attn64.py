@@ -1263,7 +1263,7 @@ def emit(progs, path):
                 f.write(f'    "{ins.text}\\n\\t" \\\n')
             f.write('    ""\n')
         regs = [f"v{i}" for i in range(32, 256)] + [f"a{i}" for i in range(AB, 256)] + [f"s{i}" for i in range(84, 97)]
-        f.write("#define GTA_ATTN64_CLOBBERS \\\n    " + ", ".join(f'"{r}"' for r in regs) + ', "vcc", "scc", "memory"\n')
+        f.write("#define GTA_ATTN64_CLOBBERS \\\n    " + ", ".join(f'"{r}"' for r in regs) + ', "m0", "vcc", "scc", "memory"\n')
 
 
 def check_all(gen, prog, verbose=False):

@@ -850,7 +850,7 @@ def emit(path, prog, macro="GTA_BWD64_DKV", vops=VOPS, sops=SOPS):
                 f.write(f'    "{ins.text}\\n\\t" \\\n')
         f.write('    ""\n')
         regs_ = [f"v{i}" for i in CLOBBER_V] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in CLOBBER_S]
-        f.write(f"#define {macro}_CLOBBERS \\\n    " + ", ".join(f'"{r}"' for r in regs_) + ', "vcc", "scc", "memory"\n')
+        f.write(f"#define {macro}_CLOBBERS \\\n    " + ", ".join(f'"{r}"' for r in regs_) + ', "m0", "vcc", "scc", "memory"\n')
         f.write(f"#define {macro}_OPERANDS \\\n    " + ", ".join(f'[{n}] "v"({n})' for n in vops) + ", \\\n    " + ", ".join(f'[{n}] "s"({n})' for n in sops) + "\n")
 
 

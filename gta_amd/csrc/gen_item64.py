@@ -1052,7 +1052,7 @@ def check(verbose=False, waves=(0, 1, 2, 3), **kw):
 # ------------------------------------------------------------------------------------------------------------------
 def clobbers():
     regs_ = [f"v{i}" for i in range(8, 256)] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in CLOBBER_S]
-    return ", ".join(f'"{r}"' for r in regs_) + ', "vcc", "scc", "memory"'
+    return ", ".join(f'"{r}"' for r in regs_) + ', "m0", "vcc", "scc", "memory"'
 
 
 def emit(path, prog, prog_p4=None, prog_ph=None):

@@ -49,7 +49,11 @@ GTA_DEV void row_decode(long row, int T, int H, int& b, int& h, int& t) {
 template <int ESZ, bool IN>
 GTA_DEV void stage_rows(float* stage, const void* base, const long my_off, const int dh, const int lane) {
     constexpr int NB = 16;                               // rows in flight per batch
-    for (int ch = lane; ch < dh; ch += 64) {
+    // (uniform trip count: the readlanes below run under the full EXEC mask of the wave -- a `ch = lane; ch < dh` loop would run its last
+    //  round, at dh % 64 != 0, with the source lanes of some rows masked off and rely on their registers' stale contents)
+    for (int c0 = 0; c0 < dh; c0 += 64) {
+        const int ch = c0 + lane;
+        const bool chok = ch < dh;
 #pragma unroll 1
         for (int r0 = 0; r0 < 64; r0 += NB) {
             long off[NB];
@@ -62,15 +66,16 @@ GTA_DEV void stage_rows(float* stage, const void* base, const long my_off, const
             }
             if (IN) {
 #pragma unroll
-                for (int u = 0; u < NB; ++u) v[u] = off[u] >= 0 ? ld<ESZ>((const char*)base + off[u], ch) : 0.f;
-#pragma unroll
-                for (int u = 0; u < NB; ++u) stage[(r0 + u) * (dh + 1) + ch] = v[u];
-            } else {
-#pragma unroll
-                for (int u = 0; u < NB; ++u) v[u] = stage[(r0 + u) * (dh + 1) + ch];
+                for (int u = 0; u < NB; ++u) v[u] = (chok && off[u] >= 0) ? ld<ESZ>((const char*)base + off[u], ch) : 0.f;
 #pragma unroll
                 for (int u = 0; u < NB; ++u)
-                    if (off[u] >= 0) st<ESZ>((char*)base + off[u], ch, v[u]);
+                    if (chok) stage[(r0 + u) * (dh + 1) + ch] = v[u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < NB; ++u) v[u] = chok ? stage[(r0 + u) * (dh + 1) + ch] : 0.f;
+#pragma unroll
+                for (int u = 0; u < NB; ++u)
+                    if (chok && off[u] >= 0) st<ESZ>((char*)base + off[u], ch, v[u]);
             }
         }
     }

@@ -27,6 +27,9 @@
 #include "gta_common.h"
 #include "gta_fwd_params.h"
 #include "gta_bwd_params.h"
+// The generated statements write M0 (LDS-DMA bases) and name it in their clobber lists; M0 is a reserved register for LLVM, which
+// warns about that by default (the clobber is what keeps a hoisted M0 initialisation of compiler-emitted code from living across them).
+#pragma clang diagnostic ignored "-Winline-asm"
 #include "../../include/gta_hip.h"
 
 namespace {

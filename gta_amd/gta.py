@@ -246,9 +246,12 @@ class _GtaAttn(torch.autograd.Function):
             else:
                 need = native.attn_fwd_workspace_bytes(desc)
                 if kv_cache is not None:
-                    # the workspace's tail (query-side operand tiles, bf16 at dh = 96) grows with the number of QUERY views: a cache
-                    # serves later query sets against the same keys, so it is sized for the most views a call can have
-                    need += max(0, native.MAX_VIEWS - Nq) * B * 24 * 1024
+                    # the workspace's tail (query-side operand tiles) grows with the number of QUERY views: a cache serves later query
+                    # sets against the same keys, so it is sized by asking the library for the most views a call can have (the size
+                    # rule -- which instances carry a tail, how large a tile is -- stays the library's)
+                    widest = type(desc).from_buffer_copy(desc)
+                    widest.Nq = widest.Tq = native.MAX_VIEWS
+                    need = max(need, native.attn_fwd_workspace_bytes(widest))
                 ws = torch.empty(need, device=q.device, dtype=torch.uint8)
                 if kv_cache is not None:
                     kv_cache["images"] = ws

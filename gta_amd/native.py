@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GTA_HIP_LIB: developer override (instrumented -DGTA_ABLATE builds of the same library)
 LIB_PATH = os.environ.get("GTA_HIP_LIB") or os.path.join(_HERE, "csrc", "libgta_hip.so")
 
-GTA_ABI_VERSION = 1
+GTA_ABI_VERSION = 2
 DTYPE_F32, DTYPE_BF16 = 0, 1
 FLAG_V_TRANSFORM = 1 << 0
 FLAG_EUCLID = 1 << 1

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GTA_ABI_VERSION 1
+#define GTA_ABI_VERSION 2   /* r05: flag bit 12 is GTA_FLAG_ITEM_CXX, 8/16-byte alignment rules of the rep builders, dtype-dependent workspace size */
 
 /* element types of q/k/v/out (all four share one type per call) */
 #define GTA_DTYPE_F32  0

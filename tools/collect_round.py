@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Copy the judged summaries of tools/profile_r04.sh (gpurun_out/prof_r04, scratch) into profiles/r04 (tracked) and derive
+"""Copy the judged summaries of tools/profile_round.sh (gpurun_out/prof_<round>, scratch) into profiles/<round> (tracked; ROUND env, default r05) and derive
 pmc_traffic.json -- what bench.py quotes as roofline.traffic / mfma_busy_sq for the kernel it was measured on."""
 import json
 import os
@@ -7,8 +7,9 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "prof_r04")
-DST = os.path.join(ROOT, "profiles", "r04")
+ROUND = os.environ.get("ROUND", "r05")
+SRC = os.path.join(ROOT, "gpurun_out", "prof_" + ROUND)
+DST = os.path.join(ROOT, "profiles", ROUND)
 os.makedirs(DST, exist_ok=True)
 for a, b in (("summary_kernel_stats.csv", "kernel_stats.csv"), ("summary_kernels.json", "kernels.json"), ("step_gaps.txt", "step_gaps.txt"),
              ("bench_line.json", "bench_line.json")):      # (workloads.jsonl is copied by hand: its lines may come from different calls)
@@ -24,7 +25,7 @@ out = {"workload": "ms-enc", "batch": 32, "dtype": "bf16", "kernel": "gta_attn64
        "mfma_busy_sq": d["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * simd_cycles), "kernel_cycles_sq": simd_cycles,
        "valu_per_mfma": d["SQ_INSTS_VALU"] / d["SQ_INSTS_MFMA"], "lds_bank_conflict_cycles": d.get("SQ_LDS_BANK_CONFLICT"),
        "avg_us_under_rocprof": d["avg_us"],
-       "source": "tools/profile_r04.sh: separate rocprofv3 --pmc passes over bench.py (FETCH_SIZE doubled: gfx950 tallies 128-B requests at 64 B, "
+       "source": "tools/profile_round.sh: separate rocprofv3 --pmc passes over bench.py (FETCH_SIZE doubled: gfx950 tallies 128-B requests at 64 B, "
                  "MI355X_MICROARCH.md HBM section; WRITE_SIZE as reported; SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x SQ_BUSY_CYCLES / 32))"}
 json.dump(out, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -1,6 +1,7 @@
-# One bench.py line per BASELINE workload (SURVEY 8d shapes) -> gpurun_out/prof_r04/workloads.jsonl (copied to profiles/r04 by collect_r04.py)
+# One bench.py line per BASELINE workload (SURVEY 8d shapes) -> gpurun_out/prof_$ROUND/workloads.jsonl (copied to profiles/$ROUND by collect_round.py)
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/prof_r04
+ROUND=${ROUND:-r05}
+OUT=$R/gpurun_out/prof_$ROUND
 mkdir -p $OUT
 : > $OUT/workloads.jsonl
 for w in ms-enc ms-dec cl-enc cl-dec dit; do
