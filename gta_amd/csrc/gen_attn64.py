@@ -736,6 +736,9 @@ class Gen:
                 # it, so that the kernel's l(lane) + l(lane ^ 32) stays what it is for the VALU sums
                 out.append(Ins(f"v_accvgpr_read_b32 {T[0]}, {Lacc(rb, 0)}", "valu", [Lacc(rb, 0)], [T[0]]))
                 out.append(Ins(f"v_mul_f32 %[lr{rb}], 0.5, {T[0]}", "valu", [T[0]], []))
+                # (r05: the running max goes out with the row sum here as well -- this branch used to `continue` past the move below, the
+                #  statement's m output stayed unwritten and the dh = 64 instances' LSE lacked m: outputs right, every gradient wrong)
+                out.append(Ins(f"v_mov_b32 %[mr{rb}], {MRUN[rb]}", "valu", [MRUN[rb]], []))
                 continue
             out.append(Ins(f"v_add_f32 {LA[rb][0]}, {LA[rb][0]}, {LA[rb][1]}", "valu", [LA[rb][0], LA[rb][1]], [LA[rb][0]]))
             out.append(Ins(f"v_add_f32 {LB[rb][0]}, {LB[rb][0]}, {LB[rb][1]}", "valu", [LB[rb][0], LB[rb][1]], [LB[rb][0]]))

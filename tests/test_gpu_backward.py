@@ -59,6 +59,7 @@ SHAPES = {
     "many-views": (2, 2, 12, 20, 9, 28, {"triv": 0, "se3": 48, "so3": 24, "so2": 24}, 6, 2),
     "wide": (1, 2, 2, 160, 2, 96, {"se3": 64, "so2": 64}, 16, 0),                # dh = 128
     "wide-ragged": (1, 2, 3, 50, 2, 70, {"triv": 8, "se3": 48, "so3": 24, "so2": 24}, 6, 2),   # dh = 104 -> padded 128
+    "DT": (1, 16, 1, 1024, 1, 1024, {"so2": 64}, 16, 0),                           # BASELINE config 5: pure so2, one 32 x 32 "view"
 }
 
 
@@ -286,7 +287,7 @@ def test_backward_properties_at_the_bench_size():
         _check(y.float().cpu(), x.float().cpu(), name)
 
 
-@pytest.mark.parametrize("shape", ["MS-enc", "MS-dec", "CL-enc", "CL-dec"])
+@pytest.mark.parametrize("shape", ["MS-enc", "MS-dec", "CL-enc", "CL-dec", "DT"])
 def test_bench_size_sampled_scenes_gradients_vs_oracle(shape):
     """The backward at the batch the bench times (B = 32 per GPU, bf16: the kernels that launch selects -- at the MSN shapes the joint launch of
     the generated streams): the whole batch on the device, two of its scenes through autograd over the oracle (a scene's dq, dk, dv depend on
@@ -303,7 +304,7 @@ def test_bench_size_sampled_scenes_gradients_vs_oracle(shape):
         gta_amd.pre_compute_reps_decoder(ak, exd)
     packed = gta_amd.pack_reps(exd, f_dims)
     qd, kd, vd = (t.bfloat16().cuda().requires_grad_() for t in (q, k, v))
-    tcd = torch.tensor([0.37], device="cuda", requires_grad=True)
+    tcd = torch.tensor([0.37], device="cuda", requires_grad=True) if f_dims.get("se3", 0) > 0 else None      # (DT: no se3 slab, no trans_coeff)
     out = gta_amd.gta_attention(qd, kd, vd, f_dims, packed, so3_degree=exd.get("gta_so3_degree", 0), trans_coeff=tcd)
     out.backward(w.bfloat16().cuda())
     torch.cuda.synchronize()
