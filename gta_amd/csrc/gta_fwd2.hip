@@ -97,36 +97,33 @@ GTA_DEV void dma_stage(char* ring, int st, const char* img, int wave, int lane) 
 // Full path of the lazy softmax (tile 0, masked tail, violated bound): true row max of S' (= S - m_run), move
 // m_run there, rescale l and O, re-base S' and the -m splat.  key of register r = kbase + (r&3) + 8(r>>2) (+32).
 // The masked last key tile: the rows past Tk are zero rows of the images (score 0, not -inf), so their probabilities must be struck
-// from the row sums.  rem = Tk % 64 valid keys; key of register r = 4 lh + (r & 3) + 8 (r >> 2) (+ 32 for s1).  When rem is a whole
-// number of 8-key groups (CLEVR-TR: 600 = 9 x 64 + 24) the dead registers are the same in every lane: wave-uniform branches and moves,
-// no per-register compare / select pairs.
-GTA_DEV void mask_tail(f32x16_t& s0, f32x16_t& s1, int rem, int lh) {
-    if ((rem & 7) == 0) {
-        const int g = __builtin_amdgcn_readfirstlane(rem >> 3);
+// from the row sums.  Key of register r = 4 lh + (r & 3) + 8 (r >> 2) (+ 32 for s1): when the tile's valid keys are a whole number g of
+// 8-key groups (CLEVR-TR: 600 = 9 x 64 + 24) the dead registers are the same in every lane -- wave-uniform branches and moves, no
+// per-register compare / select pairs, and no reason to leave the lazy softmax (other remainders keep the full path's per-register mask).
+GTA_DEV void mask_tail8(f32x16_t& s0, f32x16_t& s1, int g) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (q >= g) {
+    for (int q = 0; q < 4; ++q) {
+        if (q >= g) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) s0[4 * q + i] = -1e30f;
-            }
-            if (q + 4 >= g) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) s1[4 * q + i] = -1e30f;
-            }
+            for (int i = 0; i < 4; ++i) s0[4 * q + i] = -1e30f;
         }
-    } else {
+        if (q + 4 >= g) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = 4 * lh + (r & 3) + 8 * (r >> 2);
-            if (key >= rem) s0[r] = -1e30f;
-            if (key + 32 >= rem) s1[r] = -1e30f;
+            for (int i = 0; i < 4; ++i) s1[4 * q + i] = -1e30f;
         }
     }
 }
-template <int DHP>
+template <int DHP, bool MASK = true>
 GTA_DEV void softmax_rebase(f32x16_t& s0, f32x16_t& s1, float& m_run, float& l_run, f32x16_t (&oacc)[DHP / 32],
                             f32x16_t& msplat, bool first, bool tail, int kbase, int Tk) {
-    if (tail) mask_tail(s0, s1, Tk - (kbase & ~63), (kbase >> 2) & 1);
+    if (MASK && tail) {                         // (the skewed dh = 96 loop masks here, per register: a call of mask_tail costs that instance 10 spills)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kbase + (r & 3) + 8 * (r >> 2);
+            if (key >= Tk) s0[r] = -1e30f;
+            if (key + 32 >= Tk) s1[r] = -1e30f;
+        }
+    }
     float mx = s0[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s0[r]);
@@ -620,18 +617,20 @@ __global__ __launch_bounds__(256, (DHP <= 64 ? 3 : 2)) void gta_fwd2_kernel(cons
         // O rescale is needed; tile 0, the masked tail tile and a violated bound take the full path.
         bf16x8_t pf[2][2];
         {
-            // (r05) The masked tail tile is no reason for the full path by itself: its dead keys are struck (mask_tail), and the lazy
-            // softmax's bound decides as for any other tile.  At the CLEVR-TR shapes (10 key tiles, 24 keys in the last) the forced
-            // full path was ~250 VALU instructions per item and wave, a ninth of its vector work: -3 % kernel cycles (profiles/r05).
-            // Tile 0 keeps the full path (true row max): taking it lazily as well (valid: |S| <= |q'| max|k'| bounds the scores from
-            // both sides) measured another -1 % and would make this kernel round P differently from the single-kernel plan and the
-            // 64-row kernel on one-tile key sides, where they agree to the last bits today.
+            // (r05) A masked tail tile whose valid keys are whole 8-key groups is no reason for the full path: its dead keys are struck
+            // (mask_tail8) and the lazy softmax's bound decides as for any other tile.  At the CLEVR-TR shapes (10 key tiles, 24 keys in
+            // the last) the forced full path was ~250 VALU instructions per item and wave, a ninth of its vector work: -3 % kernel cycles
+            // (profiles/r05).  Tile 0 keeps the full path (true row max): taking it lazily as well (valid: |S| <= |q'| max|k'| bounds
+            // the scores from both sides) measured another -1 % and would make this kernel round P differently from the single-kernel
+            // plan and the 64-row kernel on one-tile key sides, where they agree to the last bits today.
             const float kn_j = __uint_as_float(kn_bits);
             const bool tail = has_tail && j == n_tiles - 1;
-            const bool need = (j == 0) || (qn * kn_j - m_run > BOUND_THR);
-            if (tail) mask_tail(s[0], s[1], pp->Tk & (BN - 1), lh);
+            const int rem = pp->Tk & (BN - 1);
+            const bool tail8 = tail && (rem & 7) == 0;
+            const bool need = (j == 0) || (tail && !tail8) || (qn * kn_j - m_run > BOUND_THR);
+            if (tail8) mask_tail8(s[0], s[1], __builtin_amdgcn_readfirstlane(rem >> 3));
             if (__builtin_amdgcn_ballot_w64(need) != 0)
-                softmax_rebase<DHP>(s[0], s[1], m_run, l_run, oacc, msplat, j == 0, false, j * BN + 4 * lh, pp->Tk);
+                softmax_rebase<DHP>(s[0], s[1], m_run, l_run, oacc, msplat, j == 0, tail && !tail8, j * BN + 4 * lh, pp->Tk);
             softmax_exp_pack(s[0], s[1], l_run, pf);
         }
 
