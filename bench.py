@@ -209,12 +209,15 @@ class PlannedStep:
         return 4.0 * self.B * self.H * self.Tq * self.Tk * self.dh      # QK^T + PV, 2 flop/MAC
 
 
-def workload_leg(name, dtype_name, device, L, seed, steps=30, warmup=5, kernel_samples=6, bwd_steps=3):
+def workload_leg(name, dtype_name, device, L, seed, steps=30, warmup=5, kernel_samples=6, bwd_steps=5, precise=False):
     """One of the OTHER BASELINE workloads, measured exactly as the headline (same planned step, same dispatch events and stamps), in well
     under a second of GPU time -> the entry of the line's `workloads` object.  Never part of `value`."""
     import gta_amd
+    from gta_amd import native
     B = WORKLOADS[name][8]
-    ps = PlannedStep(name, B, dtype_name, device, L, seed=seed, steps=steps, kernel_samples=kernel_samples)
+    # precise = the fp32-faithful mode (fp32 inputs, split-bf16 operands, three MFMAs per product: single-kernel plan, no separate attention launch to time)
+    ps = PlannedStep(name, B, dtype_name, device, L, seed=seed, steps=steps, kernel_samples=kernel_samples,
+                     flags=(native.FLAG_FUSED_KV | native.FLAG_FP32_PRODUCTS) if precise else 0, time_kernel=not precise)
     for _ in range(warmup):
         ps.step()
     torch.cuda.synchronize()
@@ -226,7 +229,8 @@ def workload_leg(name, dtype_name, device, L, seed, steps=30, warmup=5, kernel_s
     kern_ms, cyc, mhz = ps.kernel_times()
     ps.release_events()
     fl = ps.flops()
-    out = {"value": B * ps.Tq / (ms * 1e-3) / 1e6, "unit": "Mtokens/s", "ms_per_step": ms, "steps": steps, "warmup": warmup, "batch": B,
+    out = {"value": B * ps.Tq / (ms * 1e-3) / 1e6, "unit": "Mtokens/s", "ms_per_step": ms, "steps": steps, "warmup": warmup, "batch": B, "dtype": dtype_name,
+           "mode": "fp32-faithful products (GTA_FLAG_FP32_PRODUCTS)" if precise else "default (bf16 products, fp32 accumulation)",
            "kernel": ps.kname, "kernel_ms": kern_ms, "frac": (fl / (kern_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if kern_ms else None,
            "step_frac": fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "kernel_cycles": cyc, "sclk_mhz": mhz,
            "mfma_busy": (fl / MFMA_FLOP_PER_CYCLE / cyc) if cyc else None, "algorithmic_flops": fl,
@@ -244,10 +248,10 @@ def workload_leg(name, dtype_name, device, L, seed, steps=30, warmup=5, kernel_s
         w = torch.randn_like(ps.q)
 
         def train_step():
-            o = gta_amd.gta_attention(qg, kg, vg, ps.f_dims, packed, so3_degree=e2.get("gta_so3_degree", 0), trans_coeff=tcg)
+            o = gta_amd.gta_attention(qg, kg, vg, ps.f_dims, packed, so3_degree=e2.get("gta_so3_degree", 0), trans_coeff=tcg, precise=precise)
             o.backward(w)
             qg.grad = kg.grad = vg.grad = None
-        for _ in range(2):
+        for _ in range(3):
             train_step()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -598,6 +602,12 @@ def main():
                 workloads[w] = workload_leg(w, args.dtype, device, L, seed=1234 + rank)
             except Exception as e:  # noqa: BLE001   (an extra leg: reported, the headline line is still printed)
                 workloads[w] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+        if args.workloads == "auto":
+            # the fp32-faithful mode at the CLEVR-TR encoder shape (runs/clevrtr/GTA/gta/config.yaml:55 mixed_prec: False): fp32 inputs
+            try:
+                workloads["cl-enc-f32-faithful"] = workload_leg("cl-enc", "f32", device, L, seed=1234 + rank, precise=True)
+            except Exception as e:  # noqa: BLE001
+                workloads["cl-enc-f32-faithful"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
             torch.cuda.empty_cache()
     srt_train = None
     if args.model_train_steps > 0:

@@ -6,7 +6,7 @@ ROUND=${ROUND:-r05}
 OUT=$R/gpurun_out/prof_$ROUND
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT; mkdir -p $OUT
-B="--no-cpu-baseline --no-parity --block-steps 0"
+B="--no-cpu-baseline --no-parity --block-steps 0 --workloads none"
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --steps 20 --warmup 5 $B --train-steps 10 > $OUT/bench_stats.log 2>&1
 timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --steps 4 --warmup 2 $B --train-steps 2 > $OUT/bench_fetch.log 2>&1
 timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $R/bench.py --steps 4 --warmup 2 $B --train-steps 2 > $OUT/bench_write.log 2>&1

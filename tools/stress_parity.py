@@ -1,0 +1,155 @@
+"""Randomised end-to-end parity of the operator against the oracle (developer tool; r05 wrote it after the LSE bug of the dh = 64
+64-row kernel: outputs right, gradients wrong, and no test looked):
+
+    python tools/stress_parity.py <seed> <count>
+
+Per draw: a layout (MSN / CLEVR-TR / DiT / a generic mix that takes the rho-apply path), a dtype, a geometry (ragged views, masked key
+tails, one-tile key sides, cross attention with different view counts), a plan (auto / prepass / prepass_rows32 / fused / prepass_pg),
+optionally tau != 1 and v_transform = False; then forward output, LSE (through the planned C-ABI call where the layout is fused-eligible)
+and dq, dk, dv, d trans_coeff, d tau from gta_attention + autograd against autograd over the oracle."""
+import random
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+import gta_amd
+from gta_amd import native, plan
+from oracle import gta_oracle as O
+from tests import _hip_cases as C
+
+MS = ("MS", {"triv": 0, "se3": 48, "so3": 24, "so2": 24}, 6, 2)
+CL = ("CL", {"se3": 32, "so2": 32}, 8, 0)
+DT = ("DT", {"so2": 64}, 16, 0)
+MIX = ("MIX", {"triv": 8, "se3": 16, "so2": 8}, 2, 0)          # dh = 32
+WIDE = ("WIDE", {"se3": 64, "so2": 64}, 16, 0)                  # dh = 128
+
+
+def stats(a, b):
+    d = (a.double() - b.double()).abs()
+    return float(d.max()), float(b.double().abs().max()), float((a.double() - b.double()).pow(2).mean().sqrt() / b.double().pow(2).mean().sqrt().clamp_min(1e-30))
+
+
+def main():
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    random.seed(seed)
+    bad = 0
+    for it in range(count):
+        name, f_dims, so2, so3 = random.choice([MS, MS, CL, CL, DT, DT, MIX, WIDE])
+        one_view = name == "DT"
+        Nk = 1 if one_view else random.choice([1, 2, 3, 5])
+        Pk = random.choice([24, 64, 75, 128, 150, 256, 300])
+        cross = (not one_view) and random.random() < 0.35
+        Nq = Nk if not cross else random.choice([1, 2, 3, 4])
+        Pq = Pk if not cross else random.choice([40, 100, 128, 213, 256, 300])
+        if Nq * Pq > 900 or Nk * Pk > 900:
+            Pq, Pk = min(Pq, 128), min(Pk, 128)
+        B, H = random.choice([1, 2]), random.choice([1, 2, 3])
+        dtype = random.choice([torch.bfloat16, torch.bfloat16, torch.float32])
+        mode = random.choice(["auto", "prepass", "prepass", "prepass_rows32", "fused", "prepass_pg"])
+        tau = random.choice([None, None, None, 0.7, 1.6])
+        vtr = random.random() > 0.15
+        tcv = random.choice([0.01, 0.37, 1.0])
+        q, k, v, ex, ak, cr = C.synth_inputs(B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, torch.float32, seed=1000 * seed + it, cross=cross)
+        qm = random.choice([1.0, 1.0, 1.0, 4.0])
+        q = q * qm
+        if dtype == torch.bfloat16:
+            q, k, v = q.bfloat16().float(), k.bfloat16().float(), v.bfloat16().float()
+        w = torch.randn(B, H, Nq * Pq, q.shape[-1], generator=torch.Generator().manual_seed(it))
+        has_se3 = f_dims.get("se3", 0) > 0
+        tag = f"{name} B{B} H{H} q {Nq}x{Pq} k {Nk}x{Pk} {'cross ' if cr else ''}{str(dtype)[6:]} {mode} tau={tau} vt={int(vtr)} tc={tcv} qx{qm:g}"
+        try:
+            # ---- oracle ----
+            qo, ko, vo = (t.clone().requires_grad_() for t in (q, k, v))
+            tco = torch.tensor([tcv], requires_grad=True)
+            tauo = torch.tensor([tau], requires_grad=True) if tau is not None else None
+            reps = O.encoder_reps(ak, ex)
+            if cr:
+                reps = O.decoder_reps(ak, ex, reps)
+            out_o, _ = O.gta_attention(qo, ko, vo, f_dims, reps, tco, vtr, False, None, tauo if tauo is not None else 1.0)
+            (out_o * w).sum().backward()
+            # ---- HIP ----
+            exd = {kk: vv.cuda() for kk, vv in ex.items()}
+            gta_amd.pre_compute_reps_encoder(ak, exd)
+            if cr:
+                gta_amd.pre_compute_reps_decoder(ak, exd)
+            packed = gta_amd.pack_reps(exd, f_dims)
+            qd, kd, vd = (t.to(dtype).cuda().requires_grad_() for t in (q, k, v))
+            tcd = torch.tensor([tcv], device="cuda", requires_grad=True) if has_se3 else None
+            taud = torch.tensor([tau], device="cuda", requires_grad=True) if tau is not None else None
+            out = gta_amd.gta_attention(qd, kd, vd, f_dims, packed, so3_degree=exd.get("gta_so3_degree", 0), trans_coeff=tcd, tau=taud,
+                                        v_transform=vtr, kv_mode=mode)
+            (out.float() * w.cuda()).sum().backward()
+            torch.cuda.synchronize()
+            msgs, ok = [], True
+            hot = qm > 1.0           # hot logits: near-one-hot rows amplify bf16 rounding of q', k' (both the reference's autocast and this build)
+            tol_o, tol_g = ((6e-2, 3e-2), (1e-1, 5e-2)) if hot else ((2.5e-2, 1.2e-2), (4e-2, 2e-2))
+            mx, rm, rr = stats(out.float().cpu(), out_o.detach())
+            ok &= bool(torch.isfinite(out).all()) and mx <= tol_o[0] * rm + 1e-6 and rr <= tol_o[1]
+            msgs.append(f"out {mx / max(rm, 1e-30):.1e}/{rr:.1e}")
+            for nm, a, b in (("dq", qd, qo), ("dk", kd, ko), ("dv", vd, vo)):
+                mx, rm, rr = stats(a.grad.float().cpu(), b.grad)
+                good = bool(torch.isfinite(a.grad).all()) and mx <= tol_g[0] * rm + 1e-6 and rr <= tol_g[1]
+                ok &= good
+                msgs.append(f"{nm} {mx / max(rm, 1e-30):.1e}/{rr:.1e}" + ("" if good else "!"))
+            if has_se3:
+                ref, got = float(tco.grad.item()), float(tcd.grad.item())
+                # (scalar gradients are sums with heavy cancellation: bf16 products leave them a few per cent off in ~4 % of the draws, up to
+                #  ~25 % on hot logits -- 400 draws of r05; the fp32-faithful leg below holds them to 3e-3 -- so only gross errors count here)
+                good = abs(got - ref) <= 0.3 * max(1.0, abs(ref))
+                ok &= good
+                msgs.append(f"dtc {got:.4g}/{ref:.4g}" + ("" if good else "!"))
+            if tau is not None:
+                ref, got = float(tauo.grad.item()), float(taud.grad.item())
+                good = abs(got - ref) <= 0.3 * max(1.0, abs(ref))
+                ok &= good
+                msgs.append(f"dtau {got:.4g}/{ref:.4g}" + ("" if good else "!"))
+            # ---- LSE through the planned call (fused-eligible layouts, no tau: ForwardPlan's signature) ----
+            if mode != "fused" and Nq * Pq > 0:
+                need_view = has_se3
+                fl = {"prepass_rows32": native.FLAG_ROWS32, "prepass_pg": native.FLAG_PERSIST}.get(mode, 0)
+                fp = plan.ForwardPlan(qd.detach(), kd.detach(), vd.detach(), f_dims, so3_degree=exd.get("gta_so3_degree", 0),
+                                      Nq=Nq if need_view else 1, Nk=Nk if need_view else 1, v_transform=vtr, flags=fl)
+                fp(qd.detach(), kd.detach(), vd.detach(), packed.get("vrep_q"), packed.get("vrep_k"), packed.get("cs_q"), packed.get("cs_k"),
+                   tcd.detach() if tcd is not None else None)
+                torch.cuda.synchronize()
+                qt, kt, _ = O.transform_qkv(q, k, v, f_dims, reps, tcv, vtr, False)
+                ref = torch.logsumexp(torch.einsum("bhid,bhjd->bhij", qt.double(), kt.double()) * (q.shape[-1] ** -0.5), dim=-1)
+                dl = float((fp.lse.double().cpu() - ref).abs().max())
+                good = bool(torch.isfinite(fp.lse).all()) and dl <= (2e-1 if hot else 5e-2)
+                ok &= good
+                kn = native.attention_kernel(fp.desc)[0]
+                msgs.append(f"lse {dl:.1e} [{kn}]" + ("" if good else "!"))
+            # ---- the same draw in the fp32-faithful mode (fp32 draws): separates bf16 rounding noise of the cancellation-prone scalar
+            # gradients from a wrong formula -- here everything must agree to 1e-3
+            if dtype == torch.float32 and mode in ("auto", "prepass", "fused"):
+                qp, kp, vp = (t.cuda().requires_grad_() for t in (q, k, v))
+                tcp = torch.tensor([tcv], device="cuda", requires_grad=True) if has_se3 else None
+                taup = torch.tensor([tau], device="cuda", requires_grad=True) if tau is not None else None
+                outp = gta_amd.gta_attention(qp, kp, vp, f_dims, packed, so3_degree=exd.get("gta_so3_degree", 0), trans_coeff=tcp, tau=taup,
+                                             v_transform=vtr, precise=True)
+                (outp * w.cuda()).sum().backward()
+                torch.cuda.synchronize()
+                worst = 0.0
+                for a, b in ((outp, out_o.detach()), (qp.grad, qo.grad), (kp.grad, ko.grad), (vp.grad, vo.grad)):
+                    mx, rm, rr = stats(a.detach().float().cpu(), b)
+                    worst = max(worst, mx / max(rm, 1e-30))
+                sc = []
+                if has_se3:
+                    sc.append(abs(float(tcp.grad.item()) - float(tco.grad.item())) / max(1.0, abs(float(tco.grad.item()))))
+                if tau is not None:
+                    sc.append(abs(float(taup.grad.item()) - float(tauo.grad.item())) / max(1.0, abs(float(tauo.grad.item()))))
+                good = worst <= (1e-3 if hot else 3e-4) and all(x <= 3e-3 for x in sc)
+                ok &= good
+                msgs.append(f"precise {worst:.1e} scalars {' '.join(f'{x:.1e}' for x in sc)}" + ("" if good else "!"))
+            bad += not ok
+            print(("ok  " if ok else "BAD ") + tag + " | " + " ".join(msgs), flush=True)
+        except Exception as e:  # noqa: BLE001
+            bad += 1
+            print("ERR " + tag + f" | {type(e).__name__}: {str(e)[:200]}", flush=True)
+    print("BAD:", bad)
+
+
+if __name__ == "__main__":
+    main()
