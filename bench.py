@@ -153,6 +153,7 @@ class PlannedStep:
         n_it, rows_it = ctypes.c_int32(0), ctypes.c_int32(0)
         self.kname = (L.gta_debug_attention_kernel(ctypes.byref(self.fwd.desc), ctypes.byref(n_it), ctypes.byref(rows_it)) or b"").decode()
         self.rows_it = rows_it.value
+        time_kernel = time_kernel and self.kname != "gta_fwd_kernel"       # (the single-kernel plan has no separate attention launch to bracket)
         self.time_kernel = time_kernel
         n_samp = steps if kernel_samples <= 0 else min(kernel_samples, steps)
         stride = max(1, steps // n_samp)
@@ -215,9 +216,9 @@ def workload_leg(name, dtype_name, device, L, seed, steps=30, warmup=5, kernel_s
     import gta_amd
     from gta_amd import native
     B = WORKLOADS[name][8]
-    # precise = the fp32-faithful mode (fp32 inputs, split-bf16 operands, three MFMAs per product: single-kernel plan, no separate attention launch to time)
+    # precise = the fp32-faithful mode (fp32 inputs, split-bf16 operands, three MFMAs per product; at dh <= 64 on the two-stage plan)
     ps = PlannedStep(name, B, dtype_name, device, L, seed=seed, steps=steps, kernel_samples=kernel_samples,
-                     flags=(native.FLAG_FUSED_KV | native.FLAG_FP32_PRODUCTS) if precise else 0, time_kernel=not precise)
+                     flags=native.FLAG_FP32_PRODUCTS if precise else 0, time_kernel=True)
     for _ in range(warmup):
         ps.step()
     torch.cuda.synchronize()
@@ -500,13 +501,13 @@ def main():
     if args.precise:
         if args.dtype != "f32":
             raise SystemExit("--precise is the fp32-faithful mode: use --dtype f32")
-        args.kv_mode = "fused"                             # (the timed forward of the mode is the single-kernel plan; its fwd_bwd leg runs
-                                                           #  rho in fp32 + the exact-fp32 backward of gta_plain32.hip)
+        # (r05: at dh <= 64 the mode runs the two-stage plan -- split hi / lo images + three MFMAs per product in the 32-row kernel -- unless
+        #  --kv-mode fused asks for the single-kernel plan; its fwd_bwd leg runs rho in fp32 + the exact-fp32 backward of gta_plain32.hip)
     fused = args.kv_mode == "fused"
     ps = PlannedStep(args.workload, B, args.dtype, device, L, seed=1234 + rank, steps=args.steps, kernel_samples=args.kernel_samples,
-                     flags=(native.FLAG_FUSED_KV | (native.FLAG_FP32_PRODUCTS if args.precise else 0)) if fused
+                     flags=(native.FLAG_FP32_PRODUCTS if args.precise else 0) | (native.FLAG_FUSED_KV if fused
                      else native.FLAG_ROWS32 if args.kv_mode == "prepass_rows32"
-                     else native.FLAG_ITEM_CXX if args.kv_mode == "prepass_item_cxx" else 0, time_kernel=not fused)
+                     else native.FLAG_ITEM_CXX if args.kv_mode == "prepass_item_cxx" else 0), time_kernel=not fused)
     step, fwd, q, k, v, exd, tc, ak, cross, kname, rows_it = ps.step, ps.fwd, ps.q, ps.k, ps.v, ps.exd, ps.tc, ps.ak, ps.cross, ps.kname, ps.rows_it
     qm, km, vm, ex = ps.masters
     Tq, Tk, dh = ps.Tq, ps.Tk, ps.dh

@@ -16,11 +16,12 @@
 
 int gta_fwd_lds_bytes(int dhp, int esz);
 int gta_fwd_dispatch(const GtaFwdParams& p, int dhp, int esz, bool dma, int n_wg, hipStream_t stream);
-long gta_fwd2_workspace_bytes(int B, int H, int Tk, int dhp, int Nq, int esz);
-long gta_fwd2_qtiles_offset(int B, int H, int Tk, int dhp);
+long gta_fwd2_workspace_bytes(int B, int H, int Tk, int dhp, int Nq, int esz, bool x3);
+long gta_fwd2_qtiles_offset(int B, int H, int Tk, int dhp, bool x3);
+bool gta_fwd2_x3_takes(int dhp, int esz);                                              // fp32-faithful products on the two-stage plan
 int gta_fwd2_rows_per_item(const GtaFwdParams& p, int dhp, int esz);                   // 256: gta_attn64_kernel, 128: gta_fwd2_kernel
 const char* gta_fwd2_attention_kernel_name(const GtaFwdParams& p, int dhp, int esz);
-long gta_fwd2_image_bytes(int B, int H, int Tk, int dhp);
+long gta_fwd2_image_bytes(int B, int H, int Tk, int dhp, bool x3);
 int gta_fwd2_lds_bytes(int dhp, int nq);
 int gta_fwd2_dispatch(GtaFwdParams& p, int dhp, int esz, bool run_prep, bool run_flash, hipStream_t stream);
 int gta_bwd_dispatch(const GtaBwdParams& p, int dhp, int esz, hipStream_t stream);
@@ -133,9 +134,17 @@ extern "C" int gta_attn_fwd_supported(const GtaAttnDesc* desc) {
     return check_common(desc);
 }
 
+// does this call run the two-stage plan when it is given a workspace?  (GTA_FLAG_FP32_PRODUCTS: where the split-bf16 instances exist)
+static bool two_stage_plan(const GtaAttnDesc* d) {
+    if (d->flags & (GTA_FLAG_FUSED_KV | GTA_FLAG_PRETRANSFORMED)) return false;
+    if (d->flags & GTA_FLAG_FP32_PRODUCTS) return gta_fwd2_x3_takes(padded_dh(d->dh), d->dtype == GTA_DTYPE_BF16 ? 2 : 4);
+    return true;
+}
 extern "C" int64_t gta_attn_fwd_workspace_bytes(const GtaAttnDesc* desc) {
     if (gta_attn_fwd_supported(desc)) return 0;
-    return gta_fwd2_workspace_bytes(desc->B, desc->H, desc->Tk, padded_dh(desc->dh), desc->Nq, desc->dtype == GTA_DTYPE_BF16 ? 2 : 4);
+    if ((desc->flags & GTA_FLAG_FP32_PRODUCTS) && !two_stage_plan(desc)) return 0;       // (that mode runs the single-kernel plan here)
+    return gta_fwd2_workspace_bytes(desc->B, desc->H, desc->Tk, padded_dh(desc->dh), desc->Nq, desc->dtype == GTA_DTYPE_BF16 ? 2 : 4,
+                                    (desc->flags & GTA_FLAG_FP32_PRODUCTS) != 0);
 }
 
 extern "C" int gta_attn_fwd_launch_info(const GtaAttnDesc* desc, int32_t* lds_bytes, int32_t* n_workgroups,
@@ -162,7 +171,7 @@ extern "C" const char* gta_debug_attention_kernel(const GtaAttnDesc* d, int32_t*
     p.Nq = d->Nq; p.Nk = d->Nk; p.Pq = d->Tq / d->Nq; p.Pk = d->Tk / d->Nk; p.nso2 = d->d_so2 / 2; p.lse = (float*)256;
     p.vrep_q = need_view ? (const float*)256 : nullptr; p.q_st = d->q_stride[2]; p.o_st = d->o_stride[2];
     p.qtiles = (padded_dh(d->dh) == 96 && esz == 2 && need_view) ? (void*)256 : nullptr;
-    const bool two_stage = !(d->flags & (GTA_FLAG_FUSED_KV | GTA_FLAG_FP32_PRODUCTS | GTA_FLAG_PRETRANSFORMED));
+    const bool two_stage = two_stage_plan(d);
     const int rows = !two_stage ? 128 : gta_fwd2_rows_per_item(p, padded_dh(d->dh), esz);
     if (n_items) *n_items = d->B * d->H * ((d->Tq + rows - 1) / rows);
     if (rows_per_item) *rows_per_item = rows;
@@ -207,7 +216,7 @@ extern "C" int gta_attn_fwd(const GtaAttnDesc* d, const void* q, const void* k, 
     if (t_prof && !(d->flags & GTA_FLAG_PREP_ONLY)) {      // (start / end stamps of every work item: gta_debug_profile_next_attention_kernel)
         GtaFwdParams pk = p;
         pk.kn = (float*)1;
-        const bool two_stage = workspace && !(d->flags & (GTA_FLAG_FUSED_KV | GTA_FLAG_FP32_PRODUCTS)) && !pre;
+        const bool two_stage = workspace && two_stage_plan(d);
         const int rows = two_stage ? gta_fwd2_rows_per_item(pk, padded_dh(d->dh), esz) : 128;
         if ((int64_t)d->B * d->H * ((d->Tq + rows - 1) / rows) <= t_prof_items) p.prof = t_prof;
         t_prof = nullptr;
@@ -216,13 +225,14 @@ extern "C" int gta_attn_fwd(const GtaAttnDesc* d, const void* q, const void* k, 
     if (n_wg > 0x7fffffffL) return fail(GTA_E_UNSUPPORTED, "grid too large");
     if ((d->flags & GTA_FLAG_FP32_PRODUCTS) && d->dtype != GTA_DTYPE_F32)
         return fail(GTA_E_BADARG, "GTA_FLAG_FP32_PRODUCTS is for fp32 inputs (bf16 inputs ask for bf16 arithmetic)");
-    if (workspace && !(d->flags & (GTA_FLAG_FUSED_KV | GTA_FLAG_FP32_PRODUCTS)) && !pre) {
-        if (workspace_bytes < gta_fwd2_workspace_bytes(d->B, d->H, d->Tk, padded_dh(d->dh), d->Nq, esz))
+    if (workspace && two_stage_plan(d)) {
+        const bool x3 = (d->flags & GTA_FLAG_FP32_PRODUCTS) != 0;
+        if (workspace_bytes < gta_fwd2_workspace_bytes(d->B, d->H, d->Tk, padded_dh(d->dh), d->Nq, esz, x3))
             return fail(GTA_E_BADARG, "workspace smaller than gta_attn_fwd_workspace_bytes()");
         if (d->H > 65535 || d->B > 65535) return fail(GTA_E_UNSUPPORTED, "B or H above 65535");
         p.kp = workspace;
-        p.kn = (float*)((char*)workspace + ((gta_fwd2_image_bytes(d->B, d->H, d->Tk, padded_dh(d->dh)) + 255) & ~255L));
-        if (padded_dh(d->dh) == 96 && esz == 2 && need_view) p.qtiles = (char*)workspace + gta_fwd2_qtiles_offset(d->B, d->H, d->Tk, 96);
+        p.kn = (float*)((char*)workspace + ((gta_fwd2_image_bytes(d->B, d->H, d->Tk, padded_dh(d->dh), x3) + 255) & ~255L));
+        if (padded_dh(d->dh) == 96 && esz == 2 && need_view) p.qtiles = (char*)workspace + gta_fwd2_qtiles_offset(d->B, d->H, d->Tk, 96, false);
         rc = gta_fwd2_dispatch(p, padded_dh(d->dh), esz, !(d->flags & GTA_FLAG_KV_READY), !(d->flags & GTA_FLAG_PREP_ONLY),
                                (hipStream_t)stream);
         if (rc) return fail(rc, rc == GTA_E_LAUNCH ? hipGetErrorString(hipGetLastError()) : "no kernel instance");
@@ -298,7 +308,7 @@ extern "C" int gta_attn_bwd(const GtaAttnDesc* d, const void* q, const void* k, 
         f.v_sb = d->v_stride[0]; f.v_sh = d->v_stride[1]; f.v_st = d->v_stride[2];
         f.B = d->B; f.H = d->H; f.Tq = d->Tq; f.Tk = d->Tk; f.Nq = d->Nq; f.Nk = d->Nk;
         f.Pq = d->Tq / d->Nq; f.Pk = d->Tk / d->Nk; f.invPq = 1.0f / f.Pq; f.invPk = 1.0f / f.Pk;
-        f.dh = d->dh; f.nso2 = d->d_so2 / 2; f.flags = d->flags; f.scale = d->scale;
+        f.dh = d->dh; f.nso2 = d->d_so2 / 2; f.flags = d->flags & ~GTA_FLAG_FP32_PRODUCTS; f.scale = d->scale;      // (the backward's images are the plain ones)
         rc = gta_fwd2_dispatch(f, padded_dh(d->dh), esz, true, false, (hipStream_t)stream);
         if (rc) return fail(rc, "K/V pre-pass launch failed");
         kv_images = ws + L.off_kv;

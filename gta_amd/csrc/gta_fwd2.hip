@@ -63,15 +63,18 @@ extern "C" float gta_debug_event_elapsed_ms(void* a, void* b) {
 
 namespace {
 
-template <int DHP>
+// X3 = the fp32-faithful instances (GTA_FLAG_FP32_PRODUCTS on the two-stage plan, fp32 inputs, dh <= 64): a tile is FOUR images
+// [K'hi | V'hi | K'lo | V'lo] (gta_prep.hip), the ring has two stages (2 x 32 KiB at dh = 64: two workgroups per CU).
+template <int DHP, bool X3 = false>
 struct Smem2 {
     static constexpr int NW = 4;
     static constexpr int BM = 32 * NW;                  // 128 query rows per work item
     static constexpr int NT = 64 * NW;
     static constexpr int CHP = DHP / 8;
     static constexpr int IMG = BN * DHP * 2;            // one K' or V' tile image
-    static constexpr int STAGE = 2 * IMG;               // K' image then V' image
-    static constexpr int RING_BYTES = NSTAGE * STAGE;
+    static constexpr int STAGE = (X3 ? 4 : 2) * IMG;    // K' image then V' image (X3: then their lo parts)
+    static constexpr int NST = X3 ? 2 : NSTAGE;         // ring stages
+    static constexpr int RING_BYTES = NST * STAGE;
     // layout: [ring | q-side view records, two buffers (item parity) of nrec records each]
     static constexpr int OFF_RING = 0;
     static constexpr int OFF_QREC = RING_BYTES;
@@ -79,9 +82,9 @@ struct Smem2 {
 };
 
 // issue the LDS-DMA of one K'/V' tile image pair (STAGE bytes, linear) into ring stage `st` (dma_group: gta_common.h)
-template <int DHP>
+template <int DHP, bool X3 = false>
 GTA_DEV void dma_stage(char* ring, int st, const char* img, int wave, int lane) {
-    using S = Smem2<DHP>;
+    using S = Smem2<DHP, X3>;
     constexpr int PIECES = S::STAGE / 1024;             // 1 KiB per wave-instruction
     constexpr int PER_WAVE = PIECES / 4;
     static_assert(PIECES % 4 == 0, "stage must split evenly over the waves");
@@ -200,9 +203,10 @@ GTA_DEV KArgs kargs() {
     return a;
 }
 
-template <int DHP, int ESZ, int LAYOUT>
-__global__ __launch_bounds__(256, (DHP <= 64 ? 3 : 2)) void gta_fwd2_kernel(const GtaFwdParams p_kernarg) {
-    using S = Smem2<DHP>;
+template <int DHP, int ESZ, int LAYOUT, bool X3 = false>
+__global__ __launch_bounds__(256, (X3 ? 2 : DHP <= 64 ? 3 : 2)) void gta_fwd2_kernel(const GtaFwdParams p_kernarg) {
+    static_assert(!X3 || (ESZ == 4 && DHP <= 64), "the fp32-faithful two-stage instances: fp32 inputs, dh <= 64");
+    using S = Smem2<DHP, X3>;
     // chunk descriptor: a compile-time constant for the shipped layouts (c is constant per unrolled item)
 #define GTA_DESC(c) (LAYOUT == GTA_LAYOUT_GENERIC ? pp->ctab[c] : gta_layout_desc(LAYOUT, c))
     constexpr int CHP = S::CHP, KS = DHP / 16, DB = DHP / 32, BM = S::BM;
@@ -249,8 +253,8 @@ __global__ __launch_bounds__(256, (DHP <= 64 ? 3 : 2)) void gta_fwd2_kernel(cons
     if (dma_V < n_items) dma_img = dma_img_of(dma_V);
     auto dma_next = [&](int lane) {
         if (dma_V < n_items) {
-            dma_stage<DHP>(ring, dma_st, dma_img + (long)dma_t * S::STAGE, wave, lane);
-            dma_st = dma_st == NSTAGE - 1 ? 0 : dma_st + 1;
+            dma_stage<DHP, X3>(ring, dma_st, dma_img + (long)dma_t * S::STAGE, wave, lane);
+            dma_st = dma_st == S::NST - 1 ? 0 : dma_st + 1;
             if (++dma_t == n_tiles) {
                 dma_t = 0;
                 dma_V += G;
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(256, (DHP <= 64 ? 3 : 2)) void gta_fwd2_kernel(cons
         if (pp->vrep_q) qrec_seg_load(rb0, pp->vrep_q, b, pp->Nq, n_first, n_cnt, wave, lane);
         if (V == (int)blockIdx.x) {          // the stream's first NSTAGE - 1 tiles (later ones: requested by the tile steps)
 #pragma unroll
-            for (int i0 = 0; i0 < NSTAGE - 1; ++i0) dma_next(lane);
+            for (int i0 = 0; i0 < S::NST - 1; ++i0) dma_next(lane);
         }
     }
     float* qrec = reinterpret_cast<float*>(smem + S::OFF_QREC) + par * pp->nrec * GTA_QREC;
@@ -348,6 +352,7 @@ __global__ __launch_bounds__(256, (DHP <= 64 ? 3 : 2)) void gta_fwd2_kernel(cons
     __builtin_amdgcn_s_barrier();
     GTA_STAMP(V, 1);
     bf16x8_t qf[KS];
+    bf16x8_t qfl[X3 ? KS : 1];     // (X3) lo parts: q' = hi + lo to 2^-17
     float qn;                      // |q'| of this lane's MFMA row: with the pre-pass's per-tile max |k'| it bounds every score of a tile
     {
         float qsq = 0.f;                                   // this lane's share of |q'_row|^2 (bf16-rounded values)
@@ -387,6 +392,13 @@ __global__ __launch_bounds__(256, (DHP <= 64 ? 3 : 2)) void gta_fwd2_kernel(cons
                 }
                 const u32x4_t qw = pack8(x[0]);
                 qf[ks] = __builtin_bit_cast(bf16x8_t, qw);
+                if constexpr (X3) {
+                    float xr[8];
+                    unpack8(qw, xr);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) xr[i] = x[0][i] - xr[i];
+                    qfl[ks] = __builtin_bit_cast(bf16x8_t, pack8(xr));
+                }
                 // |q'|^2 from the fp32 values; rounding to bf16 moves a value by at most 2^-8 of itself (covered by the factor below)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) qsq += x[0][i] * x[0][i];
@@ -430,6 +442,87 @@ __global__ __launch_bounds__(256, (DHP <= 64 ? 3 : 2)) void gta_fwd2_kernel(cons
     const float* kn_base = pp->kn + (long)(b * pp->H + h) * n_tiles;
 
     static_assert(!(PIPE1 && DHP == 96) || NSTAGE == 3, "the skewed loop keeps K'(j+1), V'(j) and one tile in flight: three stages");
+    if constexpr (X3) {
+    // ---- fp32-faithful tile loop: every product of the two contractions as three MFMAs on bf16 (hi, lo) operand pairs, small terms
+    // first (lo*hi + hi*lo + hi*hi, as gta_fwd_kernel<..., x3>); P = exp2(S') is split the same way; softmax, row sums, O in fp32.
+    // Plain order (QK^T, softmax, P V per tile); two ring stages: tile j + 1 streams in under tile j's 96 matrix instructions. ----
+    for (int j = 0; j < n_tiles; ++j) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // tile j has landed (nothing else is in flight), everyone is past tile j - 1
+        __builtin_amdgcn_s_barrier();
+        dma_next(lane);
+        const char* kf = ring + cons_st * S::STAGE;
+        cons_st = cons_st == S::NST - 1 ? 0 : cons_st + 1;
+        uint32_t kn_bits;
+        {
+            const float* kn_ptr = kn_base + __builtin_amdgcn_readfirstlane(j);
+            asm volatile("s_load_dword %0, %1, 0x0" : "=s"(kn_bits) : "s"(kn_ptr) : "memory");
+        }
+        f32x16_t s[2];
+        {
+            bf16x8_t kh[KS][2], kl[KS][2];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    kh[ks][hh] = *reinterpret_cast<const bf16x8_t*>(kf + koff[ks] + hh * 32 * CHP * 16);
+                    kl[ks][hh] = *reinterpret_cast<const bf16x8_t*>(kf + 2 * S::IMG + koff[ks] + hh * 32 * CHP * 16);
+                }
+            }
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) s[hh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl[0][hh], qf[0], msplat, 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    if (ks > 0) s[hh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl[ks][hh], qf[ks], s[hh], 0, 0, 0);
+                    s[hh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[ks][hh], qfl[ks], s[hh], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) s[hh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[ks][hh], qf[ks], s[hh], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(kn_bits));
+        bf16x8_t pf[2][2], pl[2][2];
+        {
+            const float kn_j = __uint_as_float(kn_bits);
+            const bool tail = has_tail && j == n_tiles - 1;
+            const bool need = (j == 0) || tail || (qn * kn_j - m_run > BOUND_THR);
+            if (__builtin_amdgcn_ballot_w64(need) != 0)
+                softmax_rebase<DHP>(s[0], s[1], m_run, l_run, oacc, msplat, j == 0, tail, j * BN + 4 * lh, pp->Tk);
+            softmax_exp_pack(s[0], s[1], l_run, pf);               // s now holds P in fp32
+            // lo = bf16(P - float(hi))
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float xh[8], xl[8];
+                    unpack8(__builtin_bit_cast(u32x4_t, pf[hh][t]), xh);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) xl[i] = s[hh][8 * t + i] - xh[i];
+                    pl[hh][t] = __builtin_bit_cast(bf16x8_t, pack8(xl));
+                }
+        }
+        // ---- O^T += V'^T P^T, slab by slab: (V'lo P_hi + V'hi P_lo) + V'hi P_hi ----
+        const uint32_t vb_h = lds_addr(kf + S::IMG), vb_l = lds_addr(kf + 3 * S::IMG);
+        static_for<4>([&](auto SC) {
+            constexpr int sl = decltype(SC)::value, kb = sl >> 1, t = sl & 1;
+            u32x2_t hl[DB], hh_[DB], ll[DB], lh_[DB];
+            pv_reads_slab<DHP, sl>(vb_h, voff, hl, hh_);
+            pv_reads_slab<DHP, sl>(vb_l, voff, ll, lh_);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int d = 0; d < DB; ++d) {
+                const u32x4_t ah = {hl[d].x, hl[d].y, hh_[d].x, hh_[d].y}, al = {ll[d].x, ll[d].y, lh_[d].x, lh_[d].y};
+                oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, al), pf[kb][t], oacc[d], 0, 0, 0);
+                oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ah), pl[kb][t], oacc[d], 0, 0, 0);
+                oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ah), pf[kb][t], oacc[d], 0, 0, 0);
+            }
+        });
+    }
+    } else
     if constexpr (PIPE1 && DHP == 96) {      // (dh = 64: 230 VGPRs would cost the third workgroup per CU)
     // ---- skewed tile loop: the QK^T MFMAs of tile j+1 issue beside the softmax VALU of tile j ----
     // Two of these waves share a SIMD (two workgroups per CU).  Measured (tests/probes/probe_coissue.hip): two
@@ -573,7 +666,7 @@ __global__ __launch_bounds__(256, (DHP <= 64 ? 3 : 2)) void gta_fwd2_kernel(cons
     for (int j = 0; j < n_tiles; ++j) {
         // tile j has landed (only the stream's next tile may still be in flight), everyone is past tile j-1.
         // (younger requests -- the next item's Q loads, this item's predecessor's stores -- only make the wait longer)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * DMA_PER_WAVE) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S::NST - 2) * DMA_PER_WAVE) : "memory");
         if (dma_V >= n_items) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the stream has ended: nothing younger to count on)
         __builtin_amdgcn_s_barrier();
         dma_next(lane);
@@ -720,11 +813,11 @@ __global__ __launch_bounds__(256, (DHP <= 64 ? 3 : 2)) void gta_fwd2_kernel(cons
 #undef GTA_DESC
 }
 
-template <int DHP, int ESZ, int LAYOUT>
+template <int DHP, int ESZ, int LAYOUT, bool X3 = false>
 int launch_fwd2(const GtaFwdParams& p, hipStream_t stream) {
-    using S = Smem2<DHP>;
-    const void* kfn = reinterpret_cast<const void*>(&gta_fwd2_kernel<DHP, ESZ, LAYOUT>);
-    if (int rc = gta_lds_optin<&gta_fwd2_kernel<DHP, ESZ, LAYOUT>>(S::total(GTA_MAX_VIEWS))) return rc;
+    using S = Smem2<DHP, X3>;
+    const void* kfn = reinterpret_cast<const void*>(&gta_fwd2_kernel<DHP, ESZ, LAYOUT, X3>);
+    if (int rc = gta_lds_optin<&gta_fwd2_kernel<DHP, ESZ, LAYOUT, X3>>(S::total(GTA_MAX_VIEWS))) return rc;
     int lds = S::total(p.vrep_q ? p.nrec : 0);
     // One workgroup per item, or (GTA_FLAG_PERSIST / the few-rounds rule below) a persistent grid of as many workgroups as are resident at once
     // (registers and LDS: two per CU at dh = 96, three at dh = 64), a multiple of 8 so that the virtual ids of a workgroup
@@ -741,7 +834,7 @@ int launch_fwd2(const GtaFwdParams& p, hipStream_t stream) {
         int cus = 0, per_cu = 0;
         long g = 0;
         const uint64_t c = (dev >= 0 && dev < 64) ? cache[dev].load(std::memory_order_acquire) : 0;
-        if (c && (int)(c >> 32) == lds) { g = (long)((c >> 8) & 0xffffff); per_cu = (int)(c & 0xff); }
+        if (c && (int)(c >> 32) == lds) { g = (long)((c >> 8) & 0xffffff); per_cu = (int)(c & 0xff); }      // (the cache is per template instance: a static of this function)
         else {
             if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
@@ -767,32 +860,36 @@ int launch_fwd2(const GtaFwdParams& p, hipStream_t stream) {
     if (g_fwd2_ev_start && g_fwd2_ev_stop) {
         // profiling hook (bench.py): start / stop events taken from the dispatch itself -- no marker packets, so the
         // kernel's neighbours in the stream are not pushed apart the way two hipEventRecord calls push them (~3 us each)
-        hipExtLaunchKernelGGL((gta_fwd2_kernel<DHP, ESZ, LAYOUT>), dim3((unsigned)grid), dim3(256), lds, stream,
+        hipExtLaunchKernelGGL((gta_fwd2_kernel<DHP, ESZ, LAYOUT, X3>), dim3((unsigned)grid), dim3(256), lds, stream,
                               (hipEvent_t)g_fwd2_ev_start, (hipEvent_t)g_fwd2_ev_stop, 0, pl);
         g_fwd2_ev_start = g_fwd2_ev_stop = nullptr;
     } else {
-        hipLaunchKernelGGL((gta_fwd2_kernel<DHP, ESZ, LAYOUT>), dim3((unsigned)grid), dim3(256), lds, stream, pl);
+        hipLaunchKernelGGL((gta_fwd2_kernel<DHP, ESZ, LAYOUT, X3>), dim3((unsigned)grid), dim3(256), lds, stream, pl);
     }
     return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH;
 }
 
 }  // namespace
 
-long gta_fwd2_image_bytes(int B, int H, int Tk, int dhp) {
+// (x3: the fp32-faithful two-stage instances store every image twice, hi and lo)
+long gta_fwd2_image_bytes(int B, int H, int Tk, int dhp, bool x3) {
     const long n_tiles = (Tk + BN - 1) / BN;
-    return (long)B * H * n_tiles * 2L * BN * dhp * 2;
+    return (long)B * H * n_tiles * (x3 ? 4L : 2L) * BN * dhp * 2;
 }
 // workspace = [K'/V' tile images | per-tile key norms | q-side rep tiles (dh = 96: gta_flash_common.h, 24 KiB per (scene, view))]
-long gta_fwd2_qtiles_offset(int B, int H, int Tk, int dhp) {
+long gta_fwd2_qtiles_offset(int B, int H, int Tk, int dhp, bool x3) {
     const long n_tiles = (Tk + BN - 1) / BN;
-    const long img = (gta_fwd2_image_bytes(B, H, Tk, dhp) + 255) & ~255L;
+    const long img = (gta_fwd2_image_bytes(B, H, Tk, dhp, x3) + 255) & ~255L;
     return img + (((long)B * H * n_tiles * 4 + 255) & ~255L);
 }
 // (the q-side tiles exist for the one instance that uses them: bf16 inputs at dh = 96 -- the only part of the workspace whose size
 //  depends on the QUERY side, through Nq)
-long gta_fwd2_workspace_bytes(int B, int H, int Tk, int dhp, int Nq, int esz) {
-    return gta_fwd2_qtiles_offset(B, H, Tk, dhp) + (dhp == 96 && esz == 2 ? (long)B * Nq * GTA_QT_TILES * GTA_QT_BYTES : 0L);
+long gta_fwd2_workspace_bytes(int B, int H, int Tk, int dhp, int Nq, int esz, bool x3) {
+    return gta_fwd2_qtiles_offset(B, H, Tk, dhp, x3) + (dhp == 96 && esz == 2 ? (long)B * Nq * GTA_QT_TILES * GTA_QT_BYTES : 0L);
 }
+// the fp32-faithful mode on the two-stage plan: fp32 inputs at dh <= 64 (CLEVR-TR, runs/clevrtr/GTA/gta/config.yaml:55); other head sizes
+// keep the single-kernel plan (gta_fwd_kernel<..., x3>)
+bool gta_fwd2_x3_takes(int dhp, int esz) { return esz == 4 && dhp <= 64; }
 int gta_fwd2_lds_bytes(int dhp, int nrec) {
     switch (dhp) {
         case 32: return Smem2<32>::total(nrec);
@@ -816,14 +913,28 @@ static int layout_of(const GtaFwdParams& p, int dhp) {
     return GTA_LAYOUT_GENERIC;
 }
 
-int gta_fwd2_rows_per_item(const GtaFwdParams& p, int dhp, int esz) { return gta_attn64_takes(p, dhp, layout_of(p, dhp), esz) ? 256 : 128; }
+int gta_fwd2_rows_per_item(const GtaFwdParams& p, int dhp, int esz) {
+    return !(p.flags & GTA_FLAG_FP32_PRODUCTS) && gta_attn64_takes(p, dhp, layout_of(p, dhp), esz) ? 256 : 128;
+}
 const char* gta_fwd2_attention_kernel_name(const GtaFwdParams& p, int dhp, int esz) {
+    if (p.flags & GTA_FLAG_FP32_PRODUCTS) return "gta_fwd2_kernel";
     return gta_attn64_takes(p, dhp, layout_of(p, dhp), esz) ? gta_attn64_kernel_name(p, esz, layout_of(p, dhp)) : "gta_fwd2_kernel";
 }
 
 // Compile-time layouts exist for the shipped configs; others read the chunk table.
 template <int DHP, int ESZ>
 static int launch_flash(const GtaFwdParams& p, hipStream_t stream) {
+    if (p.flags & GTA_FLAG_FP32_PRODUCTS) {              // split-bf16 operands, three MFMAs per product: the X3 instances of the 32-row kernel
+        if constexpr (ESZ == 4 && DHP <= 64) {
+            switch (layout_of(p, DHP)) {
+                case GTA_LAYOUT_CL:  if (DHP == 64) return launch_fwd2<DHP, ESZ, (DHP == 64 ? GTA_LAYOUT_CL : GTA_LAYOUT_GENERIC), true>(p, stream); break;
+                case GTA_LAYOUT_SO2: return launch_fwd2<DHP, ESZ, GTA_LAYOUT_SO2, true>(p, stream);
+            }
+            return launch_fwd2<DHP, ESZ, GTA_LAYOUT_GENERIC, true>(p, stream);
+        } else {
+            return GTA_E_UNSUPPORTED;
+        }
+    }
     if (gta_attn64_takes(p, DHP, layout_of(p, DHP), ESZ)) return gta_attn64_dispatch(p, ESZ, layout_of(p, DHP), stream);   // 64 rows per wave (gta_fwd64.hip)
     switch (layout_of(p, DHP)) {
         case GTA_LAYOUT_MS:  if (DHP == 96) return launch_fwd2<DHP, ESZ, (DHP == 96 ? GTA_LAYOUT_MS : GTA_LAYOUT_GENERIC)>(p, stream); break;

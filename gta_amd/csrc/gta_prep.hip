@@ -10,7 +10,9 @@
 
 namespace {
 
-template <int DHP, int ESZ>
+// X3 (fp32 inputs, GTA_FLAG_FP32_PRODUCTS on the two-stage plan): every image is written twice -- hi = bf16(x) and lo = bf16(x - hi), 16
+// significant bits together -- and the tile's four images lie [K'hi | V'hi | K'lo | V'lo] in the workspace (the first half is the plain layout).
+template <int DHP, int ESZ, bool X3 = false>
 struct PrepSmem {
     static constexpr int CHP = DHP / 8;
     static constexpr int RAW_UNITS = DHP * ESZ / 16;
@@ -24,7 +26,9 @@ struct PrepSmem {
     static constexpr int OFF_IMGV = (ESZ == 2) ? OFF_RAWV : OFF_IMGK + IMG;
     // the 4 x 64 row-norm partials and the k-side view records sit behind the data, sized by the actual number of views:
     // 5 workgroups per CU with 16 views' worth reserved, 6 with the 5 views of the MSN config
-    static constexpr int OFF_ROWSQ = (ESZ == 2) ? OFF_RAWV + RAW_BYTES : OFF_IMGV + IMG;
+    static constexpr int OFF_IMGK_LO = OFF_IMGV + IMG;             // (X3 only)
+    static constexpr int OFF_IMGV_LO = OFF_IMGK_LO + IMG;
+    static constexpr int OFF_ROWSQ = X3 ? OFF_IMGV_LO + IMG : (ESZ == 2) ? OFF_RAWV + RAW_BYTES : OFF_IMGV + IMG;
     static constexpr int OFF_KREC = OFF_ROWSQ + 1024;
     static int total(int Nk) { return OFF_KREC + Nk * GTA_KREC * 4; }
 };
@@ -37,9 +41,10 @@ GTA_DEV void dma_piece(const char* lds_dst, const char* src) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(lds)), "v"(src) : "memory");
 }
 
-template <int DHP, int ESZ>
+template <int DHP, int ESZ, bool X3 = false>
 __global__ __launch_bounds__(256) void gta_kv_prep_kernel(const GtaFwdParams p) {
-    using S = PrepSmem<DHP, ESZ>;
+    static_assert(!X3 || ESZ == 4, "split-bf16 images are for fp32 inputs");
+    using S = PrepSmem<DHP, ESZ, X3>;
     constexpr int CHP = S::CHP, U = S::RAW_UNITS;
     constexpr int IMG = BN * DHP * 2;                       // bytes of one bf16 tile image
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -170,6 +175,7 @@ __global__ __launch_bounds__(256) void gta_kv_prep_kernel(const GtaFwdParams p) 
         constexpr bool is_k = decltype(ISK)::value, xf = decltype(XF)::value, joint = decltype(JOINTC)::value;
         const char* raw = smem + (is_k ? S::OFF_RAWK : S::OFF_RAWV);
         char* img = smem + (is_k ? S::OFF_IMGK : S::OFF_IMGV);
+        char* img_lo = smem + (is_k ? S::OFF_IMGK_LO : S::OFF_IMGV_LO);      // (X3)
 #pragma unroll
         for (int it = 0; it < CHP / 4; ++it) {
             const int c = wave + 4 * it;
@@ -201,7 +207,17 @@ __global__ __launch_bounds__(256) void gta_kv_prep_kernel(const GtaFwdParams p) 
                 }
                 const u32x4_t w = pack8(x[0]);
                 *reinterpret_cast<u32x4_t*>(img + off) = w;
-                if (is_k) {
+                if constexpr (X3) {                        // the residual the rounding left: x = hi + lo to 2^-17
+                    float kr[8], lo8[8];
+                    unpack8(w, kr);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) lo8[i] = x[0][i] - kr[i];
+                    *reinterpret_cast<u32x4_t*>(img_lo + off) = pack8(lo8);
+                    if (is_k) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) ksq += x[0][i] * x[0][i];
+                    }
+                } else if (is_k) {
                     float kr[8];
                     unpack8(w, kr);
 #pragma unroll
@@ -245,12 +261,13 @@ __global__ __launch_bounds__(256) void gta_kv_prep_kernel(const GtaFwdParams p) 
                 }
             } else {
                 *reinterpret_cast<u32x4_t*>(img + off) = u32x4_t{0u, 0u, 0u, 0u};
+                if constexpr (X3) *reinterpret_cast<u32x4_t*>(img_lo + off) = u32x4_t{0u, 0u, 0u, 0u};
                 if constexpr (joint) *reinterpret_cast<u32x4_t*>(smem + S::OFF_IMGV + off) = u32x4_t{0u, 0u, 0u, 0u};
             }
         }
     };
     // LDS image -> workspace, 1 KiB contiguous per wave-instruction
-    char* gimg = (char*)p.kp + (((long)b * p.H + h) * n_tiles + j) * (2L * IMG);
+    char* gimg = (char*)p.kp + (((long)b * p.H + h) * n_tiles + j) * ((X3 ? 4L : 2L) * IMG);
     constexpr int PIECES = IMG / 1024;            // per image
     auto store_image = [&](const char* img_l, char* g) {
 #pragma unroll
@@ -270,12 +287,13 @@ __global__ __launch_bounds__(256) void gta_kv_prep_kernel(const GtaFwdParams p) 
     __builtin_amdgcn_s_barrier();                                  // K' image complete
     asm volatile("" ::: "memory");
     store_image(smem + S::OFF_IMGK, gimg);                         // K' goes out while V is transformed
+    if constexpr (X3) store_image(smem + S::OFF_IMGK_LO, gimg + 2 * IMG);
     // per-tile bound for the flash kernel's deferred max: max over the tile's keys of |k'| (exactly the rows the MFMA will see)
     if (p.kn && wave == 0) {
         float tot = rowsq[lane] + rowsq[64 + lane] + rowsq[128 + lane] + rowsq[192 + lane];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) tot = fmaxf(tot, __shfl_xor(tot, o));
-        if (lane == 0) p.kn[((long)b * p.H + h) * n_tiles + j] = sqrtf(tot) * 1.0001f;
+        if (lane == 0) p.kn[((long)b * p.H + h) * n_tiles + j] = sqrtf(tot) * (X3 ? 1.0002f : 1.0001f);
     }
     if constexpr (!JOINT) {
 #if !defined(GTA_PREP_ABL) || GTA_PREP_ABL < 2      // (level 2: the V rows go out as they came in)
@@ -286,23 +304,32 @@ __global__ __launch_bounds__(256) void gta_kv_prep_kernel(const GtaFwdParams p) 
         asm volatile("" ::: "memory");
     }
     store_image(smem + S::OFF_IMGV, gimg + IMG);
+    if constexpr (X3) store_image(smem + S::OFF_IMGV_LO, gimg + 3 * IMG);
 }
 
-template <int DHP, int ESZ>
+template <int DHP, int ESZ, bool X3 = false>
 int launch_prep(const GtaFwdParams& p, hipStream_t stream) {
-    using S = PrepSmem<DHP, ESZ>;
-    if (int rc = gta_lds_optin<&gta_kv_prep_kernel<DHP, ESZ>>(S::total(GTA_MAX_VIEWS))) return rc;
+    using S = PrepSmem<DHP, ESZ, X3>;
+    if (int rc = gta_lds_optin<&gta_kv_prep_kernel<DHP, ESZ, X3>>(S::total(GTA_MAX_VIEWS))) return rc;
     const int n_tiles = (p.Tk + BN - 1) / BN;
     const long rows = (long)p.B * n_tiles;
     long grid = (rows + 7) / 8 * 8 * p.H;
     if (p.qtiles && p.vrep_q) grid += ((long)p.B * p.Nq + 7) / 8 * 8;        // the q-side tile builders (see the kernel's head)
     if (grid > 0x7fffffffL) return GTA_E_UNSUPPORTED;
-    hipLaunchKernelGGL((gta_kv_prep_kernel<DHP, ESZ>), dim3((unsigned)grid), dim3(256), S::total(p.vrep_k ? p.Nk : 0), stream, p);
+    hipLaunchKernelGGL((gta_kv_prep_kernel<DHP, ESZ, X3>), dim3((unsigned)grid), dim3(256), S::total(p.vrep_k ? p.Nk : 0), stream, p);
     return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH;
 }
 }  // namespace
 
 int gta_prep_dispatch(const GtaFwdParams& p, int dhp, int esz, hipStream_t stream) {
+    if (p.flags & GTA_FLAG_FP32_PRODUCTS) {             // split-bf16 images (gta_fwd2_x3_takes: fp32 inputs, dh <= 64)
+        if (esz != 4) return GTA_E_UNSUPPORTED;
+        switch (dhp) {
+            case 32: return launch_prep<32, 4, true>(p, stream);
+            case 64: return launch_prep<64, 4, true>(p, stream);
+        }
+        return GTA_E_UNSUPPORTED;
+    }
     switch (dhp) {
         case 32: return esz == 2 ? launch_prep<32, 2>(p, stream) : launch_prep<32, 4>(p, stream);
         case 64: return esz == 2 ? launch_prep<64, 2>(p, stream) : launch_prep<64, 4>(p, stream);

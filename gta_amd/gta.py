@@ -270,7 +270,8 @@ class _GtaAttn(torch.autograd.Function):
             if _GtaAttn.flash_events is not None:
                 _GtaAttn.flash_events[1].record()
         ctx.cfg = cfg
-        ctx.kv_images = ws          # K'/V' tile images of the two-stage plan: reused by the backward
+        # K'/V' tile images of the two-stage plan: reused by the backward (not the split hi / lo images of the fp32-faithful plan)
+        ctx.kv_images = ws if not (flags & native.FLAG_FP32_PRODUCTS) else None
         ctx.save_for_backward(q, k, v, out, lse, tc, ta, vrep_q, vrep_k, cs_q, cs_k)
         ctx.tc_shape = None if trans_coeff is None else trans_coeff.shape
         ctx.tc_dtype = None if trans_coeff is None else trans_coeff.dtype
@@ -451,7 +452,7 @@ def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: 
     precise: float32 inputs only.  False / None (default): operands are rounded to bf16 once, after
              rho, and the two contractions run on the bf16 MFMA (fp32 accumulation) -- the reference's bf16-autocast
              accuracy.  True: operands are kept as bf16 hi+lo pairs and every product is three MFMAs -- fp32-class results
-             (max |error| ~1e-5 of max |out|) at 3x the matrix work, single-kernel plan.  When a gradient is wanted the call runs
+             (max |error| ~1e-5 of max |out|) at 3x the matrix work; two-stage plan at dh <= 64 (r05), single-kernel plan otherwise.  When a gradient is wanted the call runs
              rho in fp32 (gta_rep_apply), the split-bf16 plain forward and an EXACT-fp32 backward (gta_plain32.hip: f32 matrix
              instructions, 1/16 of the bf16 rate) -- the arithmetic of the reference's ``mixed_prec: False`` training.
     kv_cache: a dict owned by the caller (inference only).  The first call stores the K'/V' tile images of the
@@ -493,19 +494,26 @@ def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: 
     if precise:
         if q.dtype != torch.float32:
             raise native.GtaError("precise=True is for float32 inputs (bf16 inputs ask for bf16 arithmetic)")
-        if kv_cache is not None:
-            raise native.GtaError("precise=True runs the single-kernel plan: no kv_cache")
         flags |= native.FLAG_FP32_PRODUCTS
-        kv_mode = "fused"
+        # r05: at dh <= 64 (CLEVR-TR, the reference's fp32 config) the mode has a two-stage plan of its own -- the pre-pass writes hi and lo
+        # images, the 32-row kernel runs three MFMAs per product; other head sizes keep the single-kernel plan (asked of the library below)
+        if kv_mode == "prepass_rows32":
+            kv_mode = "prepass"
     if kv_cache is not None:
         if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in (q, k, v, trans_coeff)):
             raise native.GtaError("kv_cache is an inference feature: call under torch.no_grad()")
         kv_mode = "prepass"
     if kv_mode == "auto":
         kv_mode = "prepass" if q.shape[2] > 256 else "fused"
+    Nq, Nk = _views(f_dims, packed, q, k)
+    if precise and kv_mode == "prepass" and q.is_cuda and not pretransformed:
+        probe = native.make_desc(q, k, v, q, f_dims, so3_degree, Nq, Nk, scale, flags)
+        if native.attn_fwd_supported(probe) == 0 and native.attn_fwd_workspace_bytes(probe) == 0:       # no split-bf16 two-stage instance here
+            if kv_cache is not None:
+                raise native.GtaError("precise=True at this head size runs the single-kernel plan: no kv_cache")
+            kv_mode = "fused"
     if kv_mode == "fused" or not use_dma:
         flags |= native.FLAG_FUSED_KV
-    Nq, Nk = _views(f_dims, packed, q, k)
     if isinstance(trans_coeff, (int, float)):
         trans_coeff = torch.tensor([float(trans_coeff)], device=q.device, dtype=torch.float32)
     if isinstance(tau, (int, float)):

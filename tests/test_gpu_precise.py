@@ -169,3 +169,51 @@ def test_baseline_shape_gradients_fp32_faithful(shape):
         assert abs(got - ref) <= 3e-4 * max(1.0, abs(ref)), (got, ref)
     ref, got = float(taus.grad.item()), float(taud.grad.item())
     assert abs(got - ref) <= 3e-4 * max(1.0, abs(ref)), (got, ref)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# r05: the fp32-faithful forward on the TWO-STAGE plan at dh <= 64 (gta_prep.hip writes hi and lo images, gta_fwd2_kernel<..., X3> runs
+# three MFMAs per product): same bars, against the fp64 oracle and against the single-kernel plan of the same mode.
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", ["CL-enc", "CL-dec", "DT", "ragged"])
+def test_two_stage_plan_fp32_faithful(shape):
+    from tests.test_gpu_forward import SHAPES
+    B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3 = SHAPES[shape]
+    if shape == "ragged":
+        Pq, Pk = 137, 151                      # (dh = 32; ragged rows, a masked key tail, more than 256 query rows)
+    q, k, v, ex, ak, cross = C.synth_inputs(B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, torch.float32, seed=33)
+    ref = C.oracle_forward(q, k, v, ex, ak, cross, 0.3, dtype=torch.float64).float()
+    exd = {kk: vv.cuda() for kk, vv in ex.items()}
+    gta_amd.pre_compute_reps_encoder(ak, exd)
+    if cross:
+        gta_amd.pre_compute_reps_decoder(ak, exd)
+    packed = gta_amd.pack_reps(exd, f_dims)
+    tc = torch.tensor([0.3], device="cuda") if f_dims.get("se3", 0) > 0 else None
+    qd, kd, vd = q.cuda(), k.cuda(), v.cuda()
+    need_view = f_dims.get("se3", 0) > 0 or f_dims.get("so3", 0) > 0
+    desc = native.make_desc(qd, kd, vd, qd, f_dims, 0, Nq if need_view else 1, Nk if need_view else 1, q.shape[-1] ** -0.5,
+                            native.FLAG_V_TRANSFORM | native.FLAG_FP32_PRODUCTS)
+    assert native.attention_kernel(desc)[0] == "gta_fwd2_kernel" and native.attn_fwd_workspace_bytes(desc) > 0
+    outs = {}
+    for mode in ("prepass", "fused"):
+        outs[mode] = gta_amd.gta_attention(qd, kd, vd, f_dims, packed, so3_degree=0, trans_coeff=tc, precise=True, kv_mode=mode).float().cpu()
+        st = C.err_stats(outs[mode], ref)
+        assert st["finite"] and st["max_abs"] <= REL_MAX * st["ref_max"] and st["rel_rms"] <= REL_RMS, (mode, st)
+    st = C.err_stats(outs["prepass"], outs["fused"])
+    assert st["max_abs"] <= 3e-5 * st["ref_max"] and st["rel_rms"] <= 2e-5, st
+    # the key side's images serve a second query set (chunked decode): same result as the uncached call
+    if Nq * Pq > 300:
+        cache = {}
+        with torch.no_grad():
+            a = gta_amd.gta_attention(qd, kd, vd, f_dims, packed, so3_degree=0, trans_coeff=tc, precise=True, kv_cache=cache)
+            b = gta_amd.gta_attention(qd, kd, vd, f_dims, packed, so3_degree=0, trans_coeff=tc, precise=True, kv_cache=cache)
+        assert torch.equal(a, b) and torch.equal(a.float().cpu(), outs["prepass"])
+
+
+def test_two_stage_plan_fp32_faithful_not_at_dh96():
+    """dh = 96 keeps the single-kernel plan in this mode: the library says so through the workspace size (0), the host mirror follows"""
+    from tests.test_gpu_forward import SHAPES
+    B, H, Nq, Pq, Nk, Pk, f_dims, so2, so3 = SHAPES["MS-enc"]
+    q = torch.zeros(B, H, Nq * Pq, 96, device="cuda")
+    desc = native.make_desc(q, q, q, q, f_dims, so3, Nq, Nk, 96 ** -0.5, native.FLAG_V_TRANSFORM | native.FLAG_FP32_PRODUCTS)
+    assert native.attn_fwd_workspace_bytes(desc) == 0 and native.attention_kernel(desc)[0] == "gta_fwd_kernel"

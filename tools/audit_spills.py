@@ -26,17 +26,18 @@ def audit():
                         "--cuda-device-only", "-o", out, src], check=True, stderr=subprocess.DEVNULL)
         text = open(out).read()
     report, problems = [], []
-    for m in re.finditer(r"^(_ZN\w*gta_fwd2_kernelILi(\d+)ELi(\d+)ELi(\d+)E\w+):", text, re.M):
-        name, key = m.group(1), (int(m.group(2)), int(m.group(3)), int(m.group(4)))
+    for m in re.finditer(r"^(_ZN\w*gta_fwd2_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)E\w+):", text, re.M):
+        x3 = m.group(5) == "1"          # the fp32-faithful instances (split-bf16 operands): two workgroups per CU, 256 registers
+        name, key = m.group(1), (int(m.group(2)), int(m.group(3)), int(m.group(4))) + (("x3",) if x3 else ())
         body = text[m.start():text.index(".Lfunc_end", m.start())]
         meta = text[text.index(".amdhsa_kernel " + name):][:4000]
         vgpr = int(re.search(r"\.amdhsa_next_free_vgpr\s+(\d+)", meta).group(1))
         row = {"instance": key, "vgpr": vgpr, "scratch": body.count("scratch_"), "sgpr_spill_writes": body.count("v_writelane"),
                "sgpr_spill_reads": body.count("v_readlane")}
         report.append(row)
-        if key in SHIPPED and row["scratch"]:
+        if (key in SHIPPED or (x3 and key[:3] in SHIPPED)) and row["scratch"]:
             problems.append(f"gta_fwd2_kernel<{key}> has {row['scratch']} scratch accesses")
-        if key[0] <= 64 and vgpr > 168:
+        if key[0] <= 64 and vgpr > (256 if x3 else 168):
             problems.append(f"gta_fwd2_kernel<{key}> needs {vgpr} VGPRs: the dh <= 64 instances must allow three waves per SIMD")
     return report, problems
 
