@@ -425,7 +425,7 @@ def block_layer_leg(B, steps, device):
     finally:
         tr.fused_blocks = True
     res["config"] = f"one pre-LN layer of the MSN gta_so3 encoder: d=768 (8 x 96), mlp 1536, B={B}, 1280 tokens, bf16 autocast"
-    res["note"] = "fused = libgta_block.so (DESIGN.md section 8); modules = nn.LayerNorm / nn.Linear / nn.GELU + autograd; not part of `value`"
+    res["note"] = "fused = libgta_block.so (DESIGN.md section 9); modules = nn.LayerNorm / nn.Linear / nn.GELU + autograd; not part of `value`"
     return res
 
 

@@ -567,7 +567,7 @@ def multihead_geometric_transform_attention(q, k, v, attn_fn=None, f_dims=None, 
     running with tau = 1.
 
     Arithmetic: products run on the bf16 MFMA with fp32 accumulation for fp32 inputs too (rho and the softmax are
-    fp32); see DESIGN.md section 5 for the measured gap to the fp32 reference.
+    fp32); see DESIGN.md section 7 for the measured gap to the fp32 reference.
     """
     if f_dims is None or reps is None:
         raise TypeError("f_dims and reps are required")

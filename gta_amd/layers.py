@@ -114,7 +114,7 @@ class Attention(nn.Module):
         else:
             self.attend = None
         self.euclid = self.method_args.get("euclid_sim", False)
-        # fp32-faithful products for float32 inputs (split-bf16 operands, DESIGN.md section 5): a per-module setting -- the reference's
+        # fp32-faithful products for float32 inputs (split-bf16 operands, DESIGN.md section 7): a per-module setting -- the reference's
         # ``mixed_prec: False`` configs (runs/clevrtr/GTA/gta/config.yaml:55) set it through ``attn_args['method']['args']['precise']``
         # or on the instance; bf16 / autocast inputs are not affected
         self.precise = bool(self.method_args.get("precise", False))

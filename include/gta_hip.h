@@ -42,7 +42,10 @@ extern "C" {
 #define GTA_FLAG_PERSIST       (1u << 9) /* tuning: persistent grid (resident workgroups walk the query tiles) instead of one workgroup per tile; */
                                          /* chosen automatically for launches of 1..2 rounds of resident workgroups (short sequences) */
 #define GTA_FLAG_FP32_PRODUCTS (1u << 10) /* fp32 inputs: split-bf16 (hi+lo) operands, three MFMAs per product: fp32-class */
-                                         /* results for the reference's mixed_prec: False configs, single-kernel plan, 3x the MFMAs */
+                                         /* results for the reference's mixed_prec: False configs, 3x the MFMAs; with a workspace   */
+                                         /* at padded dh <= 64 the two-stage plan (hi and lo images: twice the image bytes; such a    */
+                                         /* workspace is NOT what gta_attn_bwd's kv_images wants), the single-kernel plan otherwise   */
+                                         /* (gta_attn_fwd_workspace_bytes then returns 0)                                              */
 #define GTA_FLAG_ROWS32        (1u << 11) /* tuning: keep the 32-rows-per-wave attention kernel (gta_fwd2.hip) where the     */
                                           /* 64-rows-per-wave one (gta_fwd64.hip: dh = 96, whole ring turns of key tiles) would run */
 #define GTA_FLAG_ITEM_CXX      (1u << 12) /* tuning / diagnostics: keep the 64-rows-per-wave kernel's compiler-scheduled item prologue and epilogue  */
@@ -149,7 +152,8 @@ int gta_attn_fwd(const GtaAttnDesc* desc,
  *   Size: [K'/V' images | per-tile key norms] depend on (B, H, Tk, dh) only.  For bf16 inputs at dh in (64, 96] the workspace ends
  *       with B * Nq * 24 KiB of query-side operand tiles (rewritten by every call), so the size ALSO depends on the query side's
  *       number of views: a workspace kept for GTA_FLAG_KV_READY calls must be sized for the largest Nq it will see (query the size
- *       with that Nq; a too-small buffer returns GTA_E_BADARG). */
+ *       with that Nq; a too-small buffer returns GTA_E_BADARG).  The size depends on desc->flags: GTA_FLAG_FP32_PRODUCTS doubles the
+ *       images where that mode has a two-stage plan (fp32 inputs, padded dh <= 64) and makes the size 0 where it has none. */
 int64_t gta_attn_fwd_workspace_bytes(const GtaAttnDesc* desc);
 
 /* -------------------------------------------------------------------------------------------

@@ -3,7 +3,7 @@
 The reference's ``mixed_prec: False`` configs (runs/clevrtr/GTA/gta/config.yaml:55) compute the operator in true fp32.
 The default kernels round q', k', v', P to bf16 once (the reference's bf16-autocast accuracy: tolerance 2.5e-2 * max,
 1.2e-2 rel-RMS, tests/test_gpu_forward.py).  The precise mode keeps every operand as a bf16 hi+lo pair (16 significant
-bits) and spends three MFMAs per product; its tolerance, stated here and in DESIGN.md section 5, is
+bits) and spends three MFMAs per product; its tolerance, stated here and in DESIGN.md section 7, is
 
     max |hip - ref| <= 1e-4 * max |ref|        rms(hip - ref) <= 3e-5 * rms(ref)
 

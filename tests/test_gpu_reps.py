@@ -49,7 +49,7 @@ def test_view_reps_gimbal_rows_follow_the_reference_formula():
 
 def test_view_reps_r22_minus_one_rows_follow_the_reference_formula():
     """R22 = -1 takes the reference's other masked branch, gamma1 = atan2(-R10, -R00) (wigner_d.py:46-47) -- whose
-    output is NOT the closed-form representation (DESIGN.md section 5: a quirk kept on purpose).  The rotations of
+    output is NOT the closed-form representation (DESIGN.md section 7: a quirk kept on purpose).  The rotations of
     fixture wigner.npz (the last one is that gimbal case) go through the HIP builder as inverse(E) blocks and must
     reproduce the REFERENCE's matrices, quirk included."""
     from tests import _golden as G
