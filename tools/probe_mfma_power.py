@@ -35,6 +35,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--precondition-s", dest="pre", type=float, default=0.0,
+                    help="seconds of the variant's own launches (alone) / of the step (in the step) in front of each timed figure: the sustained "
+                         "clock instead of the first milliseconds after idle (tools/clock_ramp.py)")
     args = ap.parse_args()
     so = os.path.join(ROOT, "tests", "probes", "libprobe_mfma_power.so")
     P = ctypes.CDLL(so)
@@ -54,13 +57,19 @@ def main():
                                        torch.cuda.current_stream().cuda_stream)
         assert rc == 0, rc
 
-    res = {"device": torch.cuda.get_device_name(0), "matrix_instructions_per_launch": GRID * 4 * ITEMS * 960, "flops_per_launch": FLOPS,
+    res = {"device": torch.cuda.get_device_name(0), "precondition_s": args.pre, "matrix_instructions_per_launch": GRID * 4 * ITEMS * 960, "flops_per_launch": FLOPS,
            "alone": [], "in_step": []}
     st1 = torch.zeros(GRID, 4, dtype=torch.int64, device=dev)
     for gap, zero in ((0, 0), (0, 1), (4, 0), (8, 0), (16, 0), (32, 0), (0, 0)):
         for _ in range(5):
             launch(gap, zero, st1)
         torch.cuda.synchronize()
+        import time as _t
+        tp = _t.perf_counter()
+        while _t.perf_counter() - tp < args.pre:
+            for _ in range(50):
+                launch(gap, zero, st1)
+            torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.reps):
@@ -100,6 +109,16 @@ def main():
             else:
                 launch(gap, zero, stamps[0])
         torch.cuda.synchronize()
+        import time as _t
+        tp = _t.perf_counter()
+        while _t.perf_counter() - tp < args.pre:
+            for it in range(50):
+                vk, ck = prefix()
+                if gap is None:
+                    fwd(q, k, v, vk, vk, ck, ck, tc, flags_extra=native.FLAG_KV_READY)
+                else:
+                    launch(gap, zero, stamps[0])
+            torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for it in range(args.steps):
