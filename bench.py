@@ -27,6 +27,13 @@ import os
 import sys
 import time
 
+# The GPU boxes run this in a container with a CPU QUOTA (cgroup cpu.max: 16 CPUs' worth per 100-ms period on the r05 boxes) under 256
+# visible CPUs.  torch's default of 128 intra-op threads, spinning after every small CPU op, burns that quota in a fraction of the period and
+# the WHOLE process -- the thread that launches kernels included -- is then descheduled until the period ends: 70-ms holes in the launch
+# stream every 100 ms (tools/clock_ramp.py "small" shows them).  So: passive OpenMP waits, and a thread count inside the quota.
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -47,6 +54,27 @@ WORKLOADS = {
 }
 
 
+def cpu_quota():
+    """CPUs this process may use per scheduling period (cgroup v2 cpu.max / v1 cfs quota), capped by the visible CPUs"""
+    n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+HOST_THREADS = max(1, min(8, cpu_quota()))      # torch's intra-op threads while the GPU is being timed (the launching thread needs one of the quota's CPUs)
+
+
 def oracle_forward(q, k, v, ex, ak, cross, trans_coeff):
     """CPU oracle (oracle/gta_oracle.py: a restatement of the reference's PyTorch path, pinned to it by tests/golden)."""
     from oracle import gta_oracle as O
@@ -64,10 +92,11 @@ def cpu_baseline(workload, seed):
     Bs = 2
     q, k, v, ex, ak, cross = synth.attention_inputs(Bs, H, Nq, Pq, Nk, Pk, f_dims, so2, so3, seed=seed)
     ncpu = os.cpu_count() or 1
+    quota = cpu_quota()
     best = None
     t_end = time.time() + 25.0
-    # intra-op threading of many small einsums stops scaling early: try a few counts, keep the best
-    for nthreads in sorted({min(ncpu, n) for n in (8, 16, 32, 64)}):
+    # intra-op threading of many small einsums stops scaling early: try a few counts (inside the container's CPU quota), keep the best
+    for nthreads in sorted({min(quota, n) for n in (8, 16, 32, 64)}):
         if time.time() > t_end:
             break
         torch.set_num_threads(nthreads)
@@ -83,7 +112,8 @@ def cpu_baseline(workload, seed):
             if best is None or med_n < best[0]:
                 best = (med_n, nthreads, len(times))
     med, cores, nruns = best
-    return {"value": Bs * Nq * Pq / med / 1e6, "unit": "Mtokens/s", "cores": cores, "host_cpus": ncpu,
+    torch.set_num_threads(HOST_THREADS)
+    return {"value": Bs * Nq * Pq / med / 1e6, "unit": "Mtokens/s", "cores": cores, "host_cpus": ncpu, "host_cpu_quota": quota,
             "kind": "port",
             "sample": f"oracle/gta_oracle.py fp32 (rep build + attention), B={Bs} scenes of the same workload, "
                       f"median of {nruns} runs, {med * 1e3:.1f} ms each"}
@@ -93,7 +123,11 @@ def parity_check(out, masters, ak, cross, scenes):
     """Output of the timed configuration (full batch) against the oracle on a few scenes, all heads."""
     q, k, v, ex = masters
     idx = torch.tensor(scenes)
-    ref = oracle_forward(q[idx], k[idx], v[idx], {kk: vv[idx] for kk, vv in ex.items()}, ak, cross, 0.01)
+    torch.set_num_threads(max(1, min(16, cpu_quota())))
+    try:
+        ref = oracle_forward(q[idx], k[idx], v[idx], {kk: vv[idx] for kk, vv in ex.items()}, ak, cross, 0.01)
+    finally:
+        torch.set_num_threads(HOST_THREADS)
     got = out[idx.to(out.device)].float().cpu()
     diff = (got - ref).abs()
     return {"scenes": list(scenes), "parity_max_abs": float(diff.max()), "ref_max_abs": float(ref.abs().max()),
@@ -516,6 +550,7 @@ def main():
 
     import gta_amd
     from gta_amd import native, plan, synth
+    torch.set_num_threads(HOST_THREADS)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -9,6 +9,7 @@ from gta_amd import native
 
 total = float(sys.argv[1]) if len(sys.argv) > 1 else 3.0
 wl = sys.argv[2] if len(sys.argv) > 2 else "ms-enc"
+big = (sys.argv[3] if len(sys.argv) > 3 else "big") == "big"      # "small": keep 50-step chunks (a synchronisation every 10 ms) throughout
 dev = torch.device("cuda", 0)
 L = native.lib()
 ps = bench.PlannedStep(wl, bench.WORKLOADS[wl][8], "bf16", dev, L, seed=1234, steps=1, kernel_samples=1, time_kernel=True)
@@ -29,5 +30,5 @@ while time.perf_counter() - t_start < total:
     print(f"t = {1e3 * (time.perf_counter() - t_start):8.1f} ms  steps {n:6d}  ms/step {dt:.4f}  kernel {kms * 1e3:6.1f} us  {mhz:5.0f} MHz  {cyc / 1e3:6.1f}k cycles", flush=True)
     if n >= 40:
         chunk = 50
-    if n >= 1000:
+    if n >= 1000 and big:
         chunk = 1000

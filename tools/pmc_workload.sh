@@ -5,8 +5,8 @@ WL=${WL:-cl-dec}
 OUT=$R/gpurun_out/pmc_$WL
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT; mkdir -p $OUT
-B="--workload $WL --workloads none --no-cpu-baseline --no-parity --block-steps 0 --train-steps 0 --steps 4 --warmup 2"
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --workload $WL --workloads none --no-cpu-baseline --no-parity --block-steps 0 --train-steps 0 --steps 20 --warmup 5 > $OUT/stats.log 2>&1
+B="--workload $WL --workloads none --no-cpu-baseline --no-parity --block-steps 0 --train-steps 0 --steps 4 --warmup 2 --precondition-s 0"
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --workload $WL --workloads none --no-cpu-baseline --no-parity --block-steps 0 --train-steps 0 --steps 20 --warmup 5 --precondition-s 0.6 > $OUT/stats.log 2>&1
 timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py $B > $OUT/fetch.log 2>&1
 timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $R/bench.py $B > $OUT/write.log 2>&1
 timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace --output-format csv -d $OUT/pmc_sq -- python $R/bench.py $B > $OUT/sq.log 2>&1
