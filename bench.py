@@ -168,7 +168,8 @@ def precondition(fn, seconds, chunk=20):
         for _ in range(chunk):
             fn()
         n += chunk
-        torch.cuda.synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
     return n
 
 

@@ -536,3 +536,25 @@ def test_attention_kernel_selection_and_backward_workspace_without_gpu():
     w0 = native.lib().gta_attn_bwd_workspace_bytes(ctypes.byref(d0))
     img = 2 * 8 * 20 * 2 * 64 * 96 * 2                                                  # Q''/dO~ (and recomputed K'/V') tile images
     assert 2 * img < w0 < 2 * img + 2 * 8 * 20 * 128 * 4 + 64 * 1024                     # + per-row statistics and the partial sums
+
+
+def test_bench_host_helpers():
+    """bench.py's host-side helpers (r05): the container's CPU quota is read from the cgroup and bounds the thread counts the timed legs use;
+    `precondition` runs its callable for the asked time in whole chunks; the workload table covers the five BASELINE workloads."""
+    import importlib.util
+    import os
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    q = bench.cpu_quota()
+    assert 1 <= q <= (os.cpu_count() or 1)
+    assert 1 <= bench.HOST_THREADS <= min(8, q)
+    calls = []
+    t0 = time.perf_counter()
+    n = bench.precondition(lambda: calls.append(1), 0.05, chunk=7)
+    assert n == len(calls) and n % 7 == 0 and n >= 7 and time.perf_counter() - t0 >= 0.05
+    assert bench.precondition(lambda: calls.append(1), 0.0) == 0
+    assert set(bench.WORKLOADS) == {"ms-enc", "ms-dec", "cl-enc", "cl-dec", "dit"}
+    assert os.environ.get("OMP_WAIT_POLICY") == "PASSIVE"

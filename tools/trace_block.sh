@@ -1,7 +1,7 @@
 # kernel sequence of one fused block layer (forward + backward) under rocprofv3: every launch of the LAST step with its duration and the idle time in front of it
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/trace_block; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/t -- python $R/tools/bench_block.py --mode fused --no-launch-count --iters 6 > $OUT/run.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/t -- python $R/tools/bench_block.py --mode fused --no-launch-count --iters 400 > $OUT/run.log 2>&1
 tail -3 $OUT/run.log
 f=$(ls $OUT/t/*/*kernel_trace.csv | head -1)
 python - $f <<'PY'
