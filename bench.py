@@ -551,9 +551,11 @@ def main():
 
     import gta_amd
     from gta_amd import native, plan, synth
-    torch.set_num_threads(HOST_THREADS)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    global HOST_THREADS
+    HOST_THREADS = max(1, min(8, cpu_quota() // max(world, 1)))      # (the ranks of one node share the container's quota)
+    torch.set_num_threads(HOST_THREADS)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 or world > 1:
