@@ -525,7 +525,7 @@ def main():
                     help="comma-separated list of OTHER BASELINE workloads to measure after the headline's timed region (100 steps each, same "
                          "planned step, dispatch events and per-item stamps; under a second of GPU time each) -> the `workloads` object of the "
                          "JSON line; never part of `value`.  auto = ms-dec,cl-enc,cl-dec,dit when the headline workload is ms-enc on bf16 and "
-                         "this is rank 0, none otherwise; none = skip")
+                         "the run has one rank, none otherwise; none = skip")
     ap.add_argument("--precondition-s", dest="precondition_s", type=float, default=1.2,
                     help="seconds of the SAME step run back to back, untimed, BEFORE the W warmup steps and the timed region.  A process that has "
                          "just built its inputs starts on an idle GPU; MI355X then grants the attention kernel 1.30-1.50 GHz for the first tens of "
@@ -687,7 +687,7 @@ def main():
             extra_errors["block_layer"] = f"{type(e).__name__}: {str(e)[:300]}"
     workloads = None
     wl_names = ([w for w in ("ms-dec", "cl-enc", "cl-dec", "dit") if w != args.workload]
-                if (args.workloads == "auto" and args.workload == "ms-enc" and args.dtype == "bf16" and not fused and args.kv_mode == "prepass")
+                if (args.workloads == "auto" and args.workload == "ms-enc" and args.dtype == "bf16" and not fused and args.kv_mode == "prepass" and world <= 1)
                 else [] if args.workloads in ("auto", "none", "") else [w for w in args.workloads.split(",") if w])
     if wl_names and rank == 0:
         # the other BASELINE workloads (configs 2, 3's decoder, 5) on the same box, right behind the headline: what only the builder's
