@@ -67,3 +67,32 @@ def test_rep_plan_equals_the_builders():
     vrep, cs = rp(E, coord)
     v2, c2 = native.build_reps(E, 2, coord.reshape(4, -1, 2), 6, 1.0, 1.0, False)
     assert torch.equal(vrep, v2) and torch.equal(cs, c2)
+
+
+def test_bench_line_contract_on_the_gpu():
+    """`bench.py` end to end with small counts (the driver's command line shape): ONE JSON line with the contract's keys, the roofline and
+    cpu-baseline objects, the r05 additions (`cold_start`, `preconditioning`, `workloads` with per-workload kernel time and parity) and no failed
+    extra leg."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--precondition-s", "0.05",
+                        "--workloads", "cl-enc", "--block-steps", "0", "--train-steps", "1", "--batch", "4"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline", "cpu_baseline", "parity", "cold_start", "preconditioning", "workloads"):
+        assert key in d, key
+    assert d["steps"] == 4 and d["warmup"] == 2 and d["n_gpus"] == 1 and d["extra_leg_errors"] is None
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["kernel"] == "gta_attn64_items_kernel" and 0 < rf["frac"] < 1 and rf["kernel_ms"] < d["ms_per_step"]
+    assert d["parity"]["parity_max_abs"] <= 2.5e-2 * d["parity"]["ref_max_abs"]
+    w = d["workloads"]["cl-enc"]
+    assert "error" not in w and w["kernel"] == "gta_fwd2_kernel" and 0 < w["frac"] < 1 and len(w["ms_per_step_regions"]) == 3
+    assert w["parity"]["parity_max_abs"] <= 2.5e-2 * w["parity"]["ref_max_abs"]
+    assert d["cold_start"]["value"] > 0 and d["preconditioning"]["steps"] > 0
