@@ -1287,7 +1287,10 @@ def production_variants():
     """what gta_attn64_loop.inc holds, as (macro, dh, options): V0 = the shipped schedule, V1 = the same instructions un-interleaved
     (GTA_ATTN64_VARIANT=1), for dh = 96 and for dh = 64 (there with the row sums on the matrix pipe: msum)"""
     return [("GTA_ATTN64_LOOP_V0", 96, dict(BEST)), ("GTA_ATTN64_LOOP_V1", 96, dict(sched=False)),
-            ("GTA_ATTN64_LOOP64_V0", 64, dict(BEST, msum=True)), ("GTA_ATTN64_LOOP64_V1", 64, dict(sched=False, msum=True))]
+            # (r05: at dh = 64 tile 0 takes the lazy path when its bound allows -- first_fast -- as the 32-row kernel does for key sides of more
+            #  than one tile: these kernels run near the part's clock, where a cycle is a cycle, and the two kernels keep rounding P alike)
+            ("GTA_ATTN64_LOOP64_V0", 64, dict(BEST, msum=True, first_fast=True)),
+            ("GTA_ATTN64_LOOP64_V1", 64, dict(sched=False, msum=True, first_fast=True))]
 
 
 def build_program(dh, kw, R=4, kread_early=True, check=True, verbose=False):

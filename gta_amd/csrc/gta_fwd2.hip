@@ -713,14 +713,15 @@ __global__ __launch_bounds__(256, (X3 ? 2 : DHP <= 64 ? 3 : 2)) void gta_fwd2_ke
             // (r05) A masked tail tile whose valid keys are whole 8-key groups is no reason for the full path: its dead keys are struck
             // (mask_tail8) and the lazy softmax's bound decides as for any other tile.  At the CLEVR-TR shapes (10 key tiles, 24 keys in
             // the last) the forced full path was ~250 VALU instructions per item and wave, a ninth of its vector work: -3 % kernel cycles
-            // (profiles/r05).  Tile 0 keeps the full path (true row max): taking it lazily as well (valid: |S| <= |q'| max|k'| bounds
-            // the scores from both sides) measured another -1 % and would make this kernel round P differently from the single-kernel
-            // plan and the 64-row kernel on one-tile key sides, where they agree to the last bits today.
+            // (profiles/r05).  Tile 0 is no reason either when more tiles follow: the state before it (m = 0, l = 0, O = 0, splat = 0) is a
+            // valid lazy-softmax state and |S| <= |q'| max|k'| bounds the scores from BOTH sides, so while the bound holds exp2(S) neither
+            // overflows nor leaves a row all zero (-2.6 % cycles at cl-dec).  One-tile key sides keep the true row max: there this kernel
+            // and the single-kernel plan agree to the last bits (the chunked decode's cached against uncached layers).
             const float kn_j = __uint_as_float(kn_bits);
             const bool tail = has_tail && j == n_tiles - 1;
             const int rem = pp->Tk & (BN - 1);
             const bool tail8 = tail && (rem & 7) == 0;
-            const bool need = (j == 0) || (tail && !tail8) || (qn * kn_j - m_run > BOUND_THR);
+            const bool need = (j == 0 && n_tiles == 1) || (tail && !tail8) || (qn * kn_j - m_run > BOUND_THR);
             if (tail8) mask_tail8(s[0], s[1], __builtin_amdgcn_readfirstlane(rem >> 3));
             if (__builtin_amdgcn_ballot_w64(need) != 0)
                 softmax_rebase<DHP>(s[0], s[1], m_run, l_run, oacc, msplat, j == 0, tail && !tail8, j * BN + 4 * lh, pp->Tk);
