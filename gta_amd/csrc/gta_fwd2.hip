@@ -232,8 +232,12 @@ __global__ __launch_bounds__(256, (X3 ? 2 : DHP <= 64 ? 3 : 2)) void gta_fwd2_ke
 #define GTA_STAMPR(V_, k) do { if (pp->prof && tid == 0) pp->prof[(long)(V_) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #ifdef GTA_ABLATE
 #define GTA_STAMP(V_, k) GTA_STAMP_ON(V_, k)
+#define GTA_STAMP_HW(V_) do { } while (0)
 #else
 #define GTA_STAMP(V_, k) do { if ((k) == 0 || (k) == 4) GTA_STAMP_ON(V_, k); } while (0)
+    // [1] where the item ran: HW_ID (wave / SIMD / CU / SH / SE fields) | XCC_ID << 32 -- tools/wg_timeline.py rebuilds every CU's occupancy from it
+#define GTA_STAMP_HW(V_) do { if (pp->prof && tid == 0) pp->prof[(long)(V_) * 8 + 1] = (long)(unsigned)__builtin_amdgcn_s_getreg(63492) | \
+                                  ((long)(unsigned)__builtin_amdgcn_s_getreg(63508) << 32); } while (0)
 #endif
 
     const bool has_tail = (pp->Tk & (BN - 1)) != 0;
@@ -804,11 +808,12 @@ __global__ __launch_bounds__(256, (X3 ? 2 : DHP <= 64 ? 3 : 2)) void gta_fwd2_ke
     }
 #undef GTA_CE
 #undef GTA_DLE
-    GTA_STAMP(V, 4); GTA_STAMPR(V, 6);
+    GTA_STAMP(V, 4); GTA_STAMPR(V, 6); GTA_STAMP_HW(V);
     par ^= 1;
     }
 #undef GTA_STAMP
 #undef GTA_STAMP_ON
+#undef GTA_STAMP_HW
 #undef GTA_STAMPR
 #undef GTA_DL
 #undef GTA_DESC

@@ -242,8 +242,9 @@ int gta_attn_fwd_launch_info(const GtaAttnDesc* desc, int32_t* lds_bytes, int32_
  *   gta_debug_event_*: thin wrappers so a ctypes caller needs no second HIP binding.
  *   gta_debug_profile_next_attention_kernel: device buffer [capacity_items][8] of uint64 (or NULL): the NEXT attention kernel launched
  *       by THIS thread through gta_attn_fwd writes, per work item, [0] / [4] = s_memtime at its start / end (shader cycles) and
- *       [5] / [6] = s_memrealtime (100 MHz) -- kernel cycles and the granted shader clock of a launch follow from them; -DGTA_ABLATE
- *       builds add per-phase stamps.  One-shot and thread-local; a launch with more work items than capacity_items writes nothing.
+ *       [5] / [6] = s_memrealtime (100 MHz) -- kernel cycles and the granted shader clock of a launch follow from them; gta_fwd2_kernel
+ *       also writes [1] = HW_ID | XCC_ID << 32 of the item's first wave (which CU it ran on: tools/wg_timeline.py); -DGTA_ABLATE
+ *       builds write per-phase stamps to [1], [2], [3], [7] instead.  One-shot and thread-local; a launch with more work items than capacity_items writes nothing.
  *   gta_debug_attention_kernel: name of the attention kernel a workspace call of gta_attn_fwd launches for desc, its number of
  *       work items and query rows per item ("" if desc is not supported). */
 void gta_debug_time_next_attention_kernel(void* start_event, void* stop_event);

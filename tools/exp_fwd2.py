@@ -3,7 +3,7 @@
 kernel alone (K'/V' images ready), alternating over the settings on one box; event time, kernel cycles and granted clock from the per-item
 stamps, output compared bit for bit with the first setting's.
 
-    python tools/exp_fwd2.py cl-dec,cl-enc,dit 0,16,64,80 [reps]
+    python tools/exp_fwd2.py cl-dec,cl-enc,dit 0,16,64,80 [reps] [variable = GTA_DBG]
 """
 import ctypes
 import os
@@ -20,6 +20,7 @@ def main():
     wls = (sys.argv[1] if len(sys.argv) > 1 else "cl-dec,cl-enc").split(",")
     settings = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "0,16").split(",")]
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    var = sys.argv[4] if len(sys.argv) > 4 else "GTA_DBG"          # the environment variable the settings go to
     dev = torch.device("cuda", 0)
     L = native.lib()
     for wl in wls:
@@ -28,7 +29,7 @@ def main():
         ps = bench.PlannedStep(name, bench.WORKLOADS[name][8], "bf16", dev, L, seed=1, steps=1, kernel_samples=1,
                                flags=native.FLAG_ROWS32 if rows32 else 0, time_kernel=False)
         vq, vk, cq, ck = ps.build_reps()
-        os.environ["GTA_DBG"] = "0"
+        os.environ[var] = "0"
         ps.fwd(ps.q, ps.k, ps.v, vq, vk, cq, ck, ps.tc)           # fills the workspace
         torch.cuda.synchronize()
         n_it, rows_it = ctypes.c_int32(0), ctypes.c_int32(0)
@@ -42,10 +43,11 @@ def main():
             return ps.fwd(ps.q, ps.k, ps.v, vq, vk, cq, ck, ps.tc, flags_extra=native.FLAG_KV_READY)
         for rep in range(reps):
             for s in settings:
-                os.environ["GTA_DBG"] = str(s)
+                os.environ[var] = str(s)
                 for _ in range(4):
                     run()
                 torch.cuda.synchronize()
+                bench.precondition(run, float(os.environ.get("PRE_S", "0.4")))       # the sustained clock (tools/clock_ramp.py)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(30):
@@ -67,7 +69,7 @@ def main():
         print(f"== {wl}: {kname}, {n_it.value} items of {rows_it.value} rows", flush=True)
         for s in settings:
             r = res[s]
-            print(f"   GTA_DBG={s:6d}: " + "  ".join(f"{u:6.1f} us" for u, *_ in r) + f" | launch+gap time; stamps: {r[-1][1] / 1e3:7.1f}k cycles at {r[-1][2]:6.0f} MHz, "
+            print(f"   {var}={s:6d}: " + "  ".join(f"{u:6.1f} us" for u, *_ in r) + f" | launch+gap time; stamps: {r[-1][1] / 1e3:7.1f}k cycles at {r[-1][2]:6.0f} MHz, "
                   f"item {r[-1][3] / 1e3:5.1f}k cycles; frac(events) {fl / (min(u for u, *_ in r) * 1e-6) / 2.5e15:.3f}; bit-identical: {all(x[4] for x in r)}", flush=True)
         del ps
         torch.cuda.empty_cache()
