@@ -142,6 +142,9 @@ __global__ __launch_bounds__(256) void gta_kv_prep_kernel(const GtaFwdParams p) 
             gu = gu < real_units ? gu : real_units - 1;
             int gr = j * BN + r;
             gr = gr < p.Tk ? gr : p.Tk - 1;
+#if defined(GTA_PREP_ABL) && GTA_PREP_ABL >= 4       // (levels 4, 5: no loads)
+            if (p.Tk < 0)
+#endif
             dma_piece(smem + (w2 ? S::OFF_RAWV : S::OFF_RAWK) + u0 * 16, g + (long)gr * rs + gu * 16);
         }
     }
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(256) void gta_kv_prep_kernel(const GtaFwdParams p) 
                 }
             };
             if (c < ch_real && valid) {
-#ifdef GTA_PREP_ABL          // timing-only ablation (tools/r04_ablate_prep.sh): no transform
+#ifdef GTA_PREP_ABL          // timing-only ablation (tools/ablate_prep.sh): no transform
                 const uint32_t desc = 0u;
 #else
                 const uint32_t desc = xf ? p.ctab[c] : 0u;
@@ -273,7 +276,11 @@ __global__ __launch_bounds__(256) void gta_kv_prep_kernel(const GtaFwdParams p) 
 #pragma unroll
         for (int i = 0; i < (PIECES + 3) / 4; ++i) {
             const int piece = wave + 4 * i;
+#if defined(GTA_PREP_ABL) && (GTA_PREP_ABL == 3 || GTA_PREP_ABL == 5)       // (levels 3, 5: no image stores)
+            if (piece < PIECES && p.Tk < 0)
+#else
             if (piece < PIECES)
+#endif
                 *reinterpret_cast<u32x4_t*>(g + piece * 1024 + lane * 16) = *reinterpret_cast<const u32x4_t*>(img_l + piece * 1024 + lane * 16);
         }
     };

@@ -1,12 +1,21 @@
-# timing-only ablation of the K/V pre-pass inside the step (results meaningless): what would a pre-pass without its VALU work buy?
-#   full = the product library; abl1 = no rho transform (unpack / pack / |k'|^2 kept); abl2 = abl1 + the V rows go out as they came in
-# built by: hipcc ... -DGTA_PREP_ABL={1,2} -c gta_prep.hip, linked with the other objects into libgta_hip_abl{1,2}.so (dev_log.md, call 39)
-R=$GRAFT_REPO_ROOT; cd $R
-for i in 1 2 3; do
-for v in full abl1 abl2; do
-LIB=$R/gta_amd/csrc/libgta_hip.so; [ $v != full ] && LIB=$R/gta_amd/csrc/libgta_hip_$v.so
-GTA_HIP_LIB=$LIB timeout 200 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-parity --block-steps 0 --train-steps 0 2>/dev/null | python -c "
-import sys,json
-d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); r=d['roofline']; print('$v$i step %.1f us kernel %.1f us rest %.1f us sclk %.0f' % (d['ms_per_step']*1e3, r['kernel_ms']*1e3, (d['ms_per_step']-r['kernel_ms'])*1e3, r.get('sclk_mhz') or 0))"
-done
+#!/bin/bash
+# Timing-only ablation of the K/V pre-pass (results meaningless): which part of its launch is what?
+#   1 = no rho transform (unpack / pack / |k'|^2 kept); 2 = 1 + the V rows go out as they came in; 3 = 2 + no image stores;
+#   4 = 2 + no loads (stale LDS); 5 = neither loads nor stores.
+# build (here, on CPU):  bash tools/ablate_prep.sh build      -> gta_amd/csrc/libgta_hip_abl{1..5}.so (git-ignored)
+# run (on the GPU box):  bash tools/ablate_prep.sh [workload]
+cd "$(dirname "$0")/.."
+if [ "$1" = build ]; then
+  cd gta_amd/csrc; make -j8 > /dev/null; mkdir -p build_var
+  for n in 1 2 3 4 5; do
+    /opt/rocm/bin/hipcc -DGTA_PREP_ABL=$n -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -fno-slp-vectorize -c gta_prep.hip -o build_var/gta_prep_abl$n.o
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libgta_hip_abl$n.so $(ls build/*.o | grep -v "gta_prep.hip.o\|gta_block\|gta_wgrad\|gta_gemm\|fwd64_diag") build_var/gta_prep_abl$n.o
+  done
+  ls -la libgta_hip_abl*.so
+  exit 0
+fi
+WL=${1:-ms-enc}
+for rep in 1 2; do
+  python tools/time_prep.py $WL full 2>&1 | grep -v amdgpu.ids
+  for n in 1 2 3 4 5; do GTA_HIP_LIB=$PWD/gta_amd/csrc/libgta_hip_abl$n.so python tools/time_prep.py $WL abl$n 2>&1 | grep -v amdgpu.ids; done
 done
