@@ -26,6 +26,9 @@ Register map (dh = 96: KS = 6 k-steps, DB = 3 channel blocks, RB = 2 row blocks 
                                                    v[208:239]  -m splat[rb]  16 each (C operand of a tile's first MFMAs)
                                                    v[ 32: 63]  addresses, row sums, m, temporaries
   v[0:31] and the SGPRs not named here belong to the compiler (operands of the statement).
+  What crosses the statement's boundary in the accumulator file is in its operand list (emit(): GTA_ATTN64_QFRAGS_*, "+{a[124:127]}"(qfr[0][0]) ...;
+  GTA_ATTN64_RESULTS_*, "={a[28:43]}"(oacc[0][0]) ...): hipcc writes the fragments and reads O itself.  The stream ends >= 18 issue states behind
+  its last MFMA (the XDL-write -> VALU-read distance: hipcc places no wait states behind inline asm).
 """
 import argparse
 import sys
@@ -1265,8 +1268,19 @@ def emit(progs, path):
                     continue
                 f.write(f'    "{ins.text}\\n\\t" \\\n')
             f.write('    ""\n')
-        regs = [f"v{i}" for i in range(32, 256)] + [f"a{i}" for i in range(AB, 256)] + [f"s{i}" for i in range(84, 97)]
-        f.write("#define GTA_ATTN64_CLOBBERS \\\n    " + ", ".join(f'"{r}"' for r in regs) + ', "m0", "vcc", "scc", "memory"\n')
+        # Per head dimension: what the statement TAKES in the accumulator file (the Q' fragments, written by the compiled prologue) and what it
+        # LEAVES there (O) are operands of the statement by register -- "+{a[124:127]}"(qfr[0][0]), "={a[28:43]}"(oacc[0][0]) -- so hipcc knows
+        # what lives where on both sides (r05; before, literal v_accvgpr_write / _read statements beside it did the hand-off behind its back);
+        # every other register the stream names is clobbered.  a[0:AB-1] stay hipcc's across the statement.
+        for dh in (96, 64):
+            configure(dh)
+            taken = [(f"qfr[{rb}][{ks}]", _qb() + 4 * (rb * KS + ks), 4) for rb in range(RB) for ks in range(KS)]
+            left = [(f"oacc[{rb}][{d}]", AB + 16 * (rb * DB + d), 16) for rb in range(RB) for d in range(DB)]
+            named = {a0 + i for _, a0, n in taken + left for i in range(n)}
+            regs = [f"v{i}" for i in range(32, 256)] + [f"a{i}" for i in range(AB, 256) if i not in named] + [f"s{i}" for i in range(84, 97)]
+            f.write(f"#define GTA_ATTN64_CLOBBERS_{dh} \\\n    " + ", ".join(f'"{r}"' for r in regs) + ', "m0", "vcc", "scc", "memory"\n')
+            f.write(f"#define GTA_ATTN64_RESULTS_{dh} \\\n    " + ", ".join(f'"={{a[{a0}:{a0 + n - 1}]}}"({lv})' for lv, a0, n in left) + "\n")
+            f.write(f"#define GTA_ATTN64_QFRAGS_{dh} \\\n    " + ", ".join(f'"+{{a[{a0}:{a0 + n - 1}]}}"({lv})' for lv, a0, n in taken) + "\n")
 
 
 def check_all(gen, prog, verbose=False):

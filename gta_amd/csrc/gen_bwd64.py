@@ -574,6 +574,9 @@ class GenDQ(Gen):
             a.v_add_u32(rt[i], S_T0, op(nm))
         g = self.d_segment(0, 0, rt) + self.d_segment(0, 1, rt)
         self.weave(a, g, [(0, 2, self.softmax(1))], slot)
+        # the stream ends on its last MFMAs and its results are read by COMPILED code (outputs of the statement): hipcc places no wait states
+        # behind inline asm, so the XDL-write -> VALU-read distance of a 16-pass MFMA (18 states) is kept here
+        a.nop(20)
         a.pseudo("end")
         return auto_waits(a.out)
 
@@ -839,7 +842,15 @@ def check(verbose=False, cases=((1, 0), (2, 1), (5, 3), (6, 2))):
 # ------------------------------------------------------------------------------------------------------------------
 # emission
 # ------------------------------------------------------------------------------------------------------------------
-def emit(path, prog, macro="GTA_BWD64_DKV", vops=VOPS, sops=SOPS):
+# what a stream leaves in the accumulator file, as (C lvalue of the kernel, first register) per 16-register tile: named as OUTPUTS of the
+# statement ("={a[0:15]}"(dk[0][0]) ...), so that hipcc knows the values live there behind it and reads them out itself (r05; before, literal
+# v_accvgpr_read statements fetched them from registers the compiler believed dead)
+DKV_RESULTS = [(f"dk[{kb}][{d}]", 16 * (3 * kb + d)) for kb in range(2) for d in range(3)] + \
+              [(f"dv[{kb}][{d}]", 96 + 16 * (3 * kb + d)) for kb in range(2) for d in range(3)]
+DQ_RESULTS = [(f"dq[{rb}][{d}]", 16 * (3 * rb + d)) for rb in range(2) for d in range(3)]
+
+
+def emit(path, prog, macro="GTA_BWD64_DKV", vops=VOPS, sops=SOPS, results=DKV_RESULTS):
     with open(path, "w") as f:
         f.write("// generated by gen_bwd64.py (make regen) -- do not edit\n")
         for name, val in (("STAGES", R), ("OFF_STATS", OFF_STATS), ("HI_BASE", HI_BASE)):
@@ -849,8 +860,10 @@ def emit(path, prog, macro="GTA_BWD64_DKV", vops=VOPS, sops=SOPS):
             if ins.kind != "pseudo":
                 f.write(f'    "{ins.text}\\n\\t" \\\n')
         f.write('    ""\n')
-        regs_ = [f"v{i}" for i in CLOBBER_V] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in CLOBBER_S]
+        out_regs = {a0 + i for _, a0 in results for i in range(16)}
+        regs_ = [f"v{i}" for i in CLOBBER_V] + [f"a{i}" for i in range(256) if i not in out_regs] + [f"s{i}" for i in CLOBBER_S]
         f.write(f"#define {macro}_CLOBBERS \\\n    " + ", ".join(f'"{r}"' for r in regs_) + ', "m0", "vcc", "scc", "memory"\n')
+        f.write(f"#define {macro}_RESULTS \\\n    " + ", ".join(f'"={{a[{a0}:{a0 + 15}]}}"({lv})' for lv, a0 in results) + "\n")
         f.write(f"#define {macro}_OPERANDS \\\n    " + ", ".join(f'[{n}] "v"({n})' for n in vops) + ", \\\n    " + ", ".join(f'[{n}] "s"({n})' for n in sops) + "\n")
 
 
@@ -892,4 +905,4 @@ if __name__ == "__main__":
     if args.out:
         emit(args.out, Gen().program())
     if args.out_dq:
-        emit(args.out_dq, GenDQ().program(), "GTA_BWD64_DQ", Q_VOPS, Q_SOPS)
+        emit(args.out_dq, GenDQ().program(), "GTA_BWD64_DQ", Q_VOPS, Q_SOPS, DQ_RESULTS)

@@ -976,6 +976,7 @@ GTA_DEV void bwd_dkv64_body(const GtaBwdParams& p, char* smem, const int L, cons
     const float tc = p.trans_coeff ? *p.trans_coeff : 1.0f;
     if (p.vrep_k) stage_brec(rec, p.vrep_k, (long)b * p.Nk + n_first, n_cnt, 1, tc, tid, 256);
 
+    f32x16_t dk[KB][DB], dv[KB][DB];
     {
         // operands of the stream: the lane's offsets in a tile image (rows of 12 rotation-swizzled 16-byte units) as LDS addresses of ring
         // stage 0 (and of stage 2: immediates stay inside the 16-bit field); fragment rows: lane (row l31, unit 2 ks + lh) -- linear in ks
@@ -1020,24 +1021,9 @@ GTA_DEV void bwd_dkv64_body(const GtaBwdParams& p, char* smem, const int L, cons
                 });
             }
         }
-        asm volatile(GTA_BWD64_DKV : : GTA_BWD64_DKV_OPERANDS : GTA_BWD64_DKV_CLOBBERS);
-    }
-    // the accumulators: dK'^T[kb][d] = a[16 (3 kb + d) ..], dV'^T[kb][d] = a[96 + 16 (3 kb + d) ..]
-    f32x16_t dk[KB][DB], dv[KB][DB];
-#define GTA_ACC16(DST, BASE) asm volatile( \
-        "v_accvgpr_read_b32 %0, a[" #BASE "+0]\n\tv_accvgpr_read_b32 %1, a[" #BASE "+1]\n\tv_accvgpr_read_b32 %2, a[" #BASE "+2]\n\tv_accvgpr_read_b32 %3, a[" #BASE "+3]\n\t" \
-        "v_accvgpr_read_b32 %4, a[" #BASE "+4]\n\tv_accvgpr_read_b32 %5, a[" #BASE "+5]\n\tv_accvgpr_read_b32 %6, a[" #BASE "+6]\n\tv_accvgpr_read_b32 %7, a[" #BASE "+7]\n\t" \
-        "v_accvgpr_read_b32 %8, a[" #BASE "+8]\n\tv_accvgpr_read_b32 %9, a[" #BASE "+9]\n\tv_accvgpr_read_b32 %10, a[" #BASE "+10]\n\tv_accvgpr_read_b32 %11, a[" #BASE "+11]\n\t" \
-        "v_accvgpr_read_b32 %12, a[" #BASE "+12]\n\tv_accvgpr_read_b32 %13, a[" #BASE "+13]\n\tv_accvgpr_read_b32 %14, a[" #BASE "+14]\n\tv_accvgpr_read_b32 %15, a[" #BASE "+15]" \
-        : "=v"(DST[0]), "=v"(DST[1]), "=v"(DST[2]), "=v"(DST[3]), "=v"(DST[4]), "=v"(DST[5]), "=v"(DST[6]), "=v"(DST[7]), \
-          "=v"(DST[8]), "=v"(DST[9]), "=v"(DST[10]), "=v"(DST[11]), "=v"(DST[12]), "=v"(DST[13]), "=v"(DST[14]), "=v"(DST[15]))
-    {
-        float t[16];
-#define GTA_ACC(ARR, KBI, D, BASE) GTA_ACC16(t, BASE); _Pragma("unroll") for (int i = 0; i < 16; ++i) ARR[KBI][D][i] = t[i];
-        GTA_ACC(dk, 0, 0, 0) GTA_ACC(dk, 0, 1, 16) GTA_ACC(dk, 0, 2, 32) GTA_ACC(dk, 1, 0, 48) GTA_ACC(dk, 1, 1, 64) GTA_ACC(dk, 1, 2, 80)
-        GTA_ACC(dv, 0, 0, 96) GTA_ACC(dv, 0, 1, 112) GTA_ACC(dv, 0, 2, 128) GTA_ACC(dv, 1, 0, 144) GTA_ACC(dv, 1, 1, 160) GTA_ACC(dv, 1, 2, 176)
-#undef GTA_ACC
-#undef GTA_ACC16
+        // the accumulators are OUTPUTS of the statement, by register: dK'^T[kb][d] = a[16 (3 kb + d) ..], dV'^T[kb][d] = a[96 + 16 (3 kb + d) ..]
+        // (GTA_BWD64_DKV_RESULTS, gen_bwd64.py) -- hipcc knows they live there and reads them out itself where the epilogue wants them
+        asm volatile(GTA_BWD64_DKV : GTA_BWD64_DKV_RESULTS : GTA_BWD64_DKV_OPERANDS : GTA_BWD64_DKV_CLOBBERS);
     }
 
     // ---- epilogue: dk = B_k^T (ln2 dK'), dv = B_k^T dV' ; d trans_coeff through B_k.  No staging: lane (key l31, half lh) of a 32-key
@@ -1166,6 +1152,7 @@ GTA_DEV void bwd_dq64_body(const GtaBwdParams& p, char* smem, const int L, const
     const float tc = p.trans_coeff ? *p.trans_coeff : 1.0f;
     if (p.vrep_q) stage_brec(rec, p.vrep_q, (long)b * p.Nq + n_first, n_cnt, 0, tc, tid, 256);
 
+    f32x16_t dq[2][DB];
     {
         const uint32_t rb = lds_addr(ring);
         auto koff_of = [&](int ks) { return (uint32_t)((l31 * CHP + swz<CHP>(l31, 2 * ks + lh)) * 16) + rb; };
@@ -1217,23 +1204,8 @@ GTA_DEV void bwd_dq64_body(const GtaBwdParams& p, char* smem, const int L, const
                 });
             }
         }
-        asm volatile(GTA_BWD64_DQ : : GTA_BWD64_DQ_OPERANDS : GTA_BWD64_DQ_CLOBBERS);
-    }
-    // the accumulators: dQ'^T[rb][d] = a[16 (3 rb + d) ..]
-    f32x16_t dq[2][DB];
-#define GTA_ACC16(DST, BASE) asm volatile( \
-        "v_accvgpr_read_b32 %0, a[" #BASE "+0]\n\tv_accvgpr_read_b32 %1, a[" #BASE "+1]\n\tv_accvgpr_read_b32 %2, a[" #BASE "+2]\n\tv_accvgpr_read_b32 %3, a[" #BASE "+3]\n\t" \
-        "v_accvgpr_read_b32 %4, a[" #BASE "+4]\n\tv_accvgpr_read_b32 %5, a[" #BASE "+5]\n\tv_accvgpr_read_b32 %6, a[" #BASE "+6]\n\tv_accvgpr_read_b32 %7, a[" #BASE "+7]\n\t" \
-        "v_accvgpr_read_b32 %8, a[" #BASE "+8]\n\tv_accvgpr_read_b32 %9, a[" #BASE "+9]\n\tv_accvgpr_read_b32 %10, a[" #BASE "+10]\n\tv_accvgpr_read_b32 %11, a[" #BASE "+11]\n\t" \
-        "v_accvgpr_read_b32 %12, a[" #BASE "+12]\n\tv_accvgpr_read_b32 %13, a[" #BASE "+13]\n\tv_accvgpr_read_b32 %14, a[" #BASE "+14]\n\tv_accvgpr_read_b32 %15, a[" #BASE "+15]" \
-        : "=v"(DST[0]), "=v"(DST[1]), "=v"(DST[2]), "=v"(DST[3]), "=v"(DST[4]), "=v"(DST[5]), "=v"(DST[6]), "=v"(DST[7]), \
-          "=v"(DST[8]), "=v"(DST[9]), "=v"(DST[10]), "=v"(DST[11]), "=v"(DST[12]), "=v"(DST[13]), "=v"(DST[14]), "=v"(DST[15]))
-    {
-        float t[16];
-#define GTA_ACC(RB, D, BASE) GTA_ACC16(t, BASE); _Pragma("unroll") for (int i = 0; i < 16; ++i) dq[RB][D][i] = t[i];
-        GTA_ACC(0, 0, 0) GTA_ACC(0, 1, 16) GTA_ACC(0, 2, 32) GTA_ACC(1, 0, 48) GTA_ACC(1, 1, 64) GTA_ACC(1, 2, 80)
-#undef GTA_ACC
-#undef GTA_ACC16
+        // (the accumulators are outputs of the statement: dQ'^T[rb][d] = a[16 (3 rb + d) ..], GTA_BWD64_DQ_RESULTS)
+        asm volatile(GTA_BWD64_DQ : GTA_BWD64_DQ_RESULTS : GTA_BWD64_DQ_OPERANDS : GTA_BWD64_DQ_CLOBBERS);
     }
 
     // ---- epilogue: dq = A_q^T (c1 dQ') ; d trans_coeff through A_q.  As gta_bwd_dkv64_kernel's: lane (row l31, half lh) of a 32-row block holds

@@ -344,7 +344,7 @@ def test_dq64_stream_generator_simulates_and_is_current():
         assert g.assemble_check(prog, g.Q_VOPS, g.Q_SOPS)
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "dq.inc")
-        g.emit(out, prog, "GTA_BWD64_DQ", g.Q_VOPS, g.Q_SOPS)
+        g.emit(out, prog, "GTA_BWD64_DQ", g.Q_VOPS, g.Q_SOPS, g.DQ_RESULTS)
         assert open(out).read() == open(os.path.join(d, "gta_bwd64_dq.inc")).read(), "gta_bwd64_dq.inc is stale: make -C gta_amd/csrc regen"
 
 
@@ -394,9 +394,9 @@ def test_dkv64_stream_simulation_catches_faults(fault):
 
 
 def test_dkv64_kernel_leaves_the_register_files_to_the_stream():
-    """tools/audit_spills.py audit_dkv64: around the generated statement of gta_bwd_dkv64_kernel hipcc must not touch an accumulator register
-    (the stream owns all 256 and leaves dK'^T / dV'^T in a[0:191], read out by statements of literal v_accvgpr_read right behind it), and the
-    statement's operands must have found room in v0..v23."""
+    """tools/audit_spills.py audit_dkv64: the generated statements of gta_bwd_dkv64_kernel / gta_bwd_dq64_kernel own the accumulator file and
+    hand dK'^T / dV'^T (a[0:191]) / dQ'^T (a[0:95]) over as OUTPUTS of the statement; hipcc reads every result register once and does
+    nothing else with the file; the statement's operands must have found room in v0..v23."""
     import importlib.util
     import os
     import shutil
@@ -413,8 +413,9 @@ def test_dkv64_kernel_leaves_the_register_files_to_the_stream():
 
 
 def test_attn64_kernel_leaves_the_accumulator_file_to_the_loop_statement():
-    """tools/audit_spills.py audit_attn64: hipcc must not touch accumulator registers in gta_attn64_kernel (the loop statement and
-    the fragment writes / O reads around it own them by literal number), one loop statement, 256 + 256 register split."""
+    """tools/audit_spills.py audit_attn64: gta_attn64_kernel's loop statement names what crosses its boundary in the accumulator file in its
+    operand list (Q' fragments in, O out); one loop statement, 256 + 256 register split, (nearly) no scratch; the item stream's kernel keeps
+    hipcc out of the accumulator file altogether."""
     import importlib.util
     import os
     import shutil
@@ -427,6 +428,32 @@ def test_attn64_kernel_leaves_the_accumulator_file_to_the_loop_statement():
     report, problems = mod.audit_attn64()
     assert len(report) >= 5 and any(r["instance"] == "items" for r in report), report
     assert not problems, problems
+
+
+def test_generated_streams_end_with_the_matrix_pipes_wait_states():
+    """A stream whose accumulators are read by COMPILED code (outputs of the asm statement) must itself keep the XDL-write -> VALU-read distance
+    of its last MFMAs: hipcc places no wait states behind inline asm.  r05 found the dQ walk ending on an MFMA (harmless while literal reads of
+    a[0:15] .. a[80:95] followed in that order, wrong results in a[80:95] once hipcc picked the order).  18 states for a 16-pass MFMA."""
+    import os
+    import re
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gta_amd", "csrc")
+    seen = 0
+    for fname, macros in (("gta_bwd64_dkv.inc", ("GTA_BWD64_DKV",)), ("gta_bwd64_dq.inc", ("GTA_BWD64_DQ",)),
+                          ("gta_attn64_loop.inc", ("GTA_ATTN64_LOOP_V0", "GTA_ATTN64_LOOP_V1", "GTA_ATTN64_LOOP64_V0", "GTA_ATTN64_LOOP64_V1"))):
+        text = open(os.path.join(d, fname)).read()
+        for mac in macros:
+            i = text.index(f"#define {mac} \\\n")
+            body = text[i:text.index('    ""\n', i)]
+            ins = [m.group(1) for m in re.finditer(r'^\s+"([^"\\]+)\\n\\t"', body, re.M)]
+            assert len(ins) > 500, (mac, len(ins))
+            last = max(k for k, t in enumerate(ins) if t.startswith("v_mfma"))
+            states = 0
+            for t in ins[last + 1:]:
+                m = re.match(r"s_nop (\d+)", t)
+                states += int(m.group(1)) + 1 if m else (0 if t.endswith(":") else 1)
+            assert states >= 18, (mac, states, ins[last:][:6])
+            seen += 1
+    assert seen == 6
 
 
 def test_srt_wrapper_state_dict_is_reference_compatible():
