@@ -137,7 +137,8 @@ def parity_check(out, masters, ak, cross, scenes):
 def latest_traffic(workload, B, dtype, kernel):
     """HBM bytes per launch of the dominant kernel from the newest committed PMC measurement of this workload AND this kernel
     (a counter pass cannot share a run with the timed region; a measurement of another kernel is not quoted)."""
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")), reverse=True):
+    files = glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")) + glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_{workload}.json"))
+    for f in sorted(files, reverse=True):
         try:
             t = json.load(open(f))
             if (t["workload"], t["batch"], t["dtype"]) == (workload, B, dtype) and t.get("kernel", "gta_fwd2_kernel") == kernel:
@@ -296,6 +297,11 @@ def workload_leg(name, dtype_name, device, L, seed, steps=100, warmup=10, kernel
            "step_frac": fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "kernel_cycles": cyc, "sclk_mhz": mhz, "ms_per_step_regions": regions,
            "mfma_busy": (fl / MFMA_FLOP_PER_CYCLE / cyc) if cyc else None, "algorithmic_flops": fl,
            "shape": {"H": ps.H, "Tq": ps.Tq, "Tk": ps.Tk, "dh": ps.dh}}
+    if not precise:
+        # HBM bytes per launch of this workload's attention kernel from its committed PMC pass (profiles/rNN/pmc_<workload>.json), as `roofline.traffic`
+        tr, busy_sq, src = latest_traffic(name, B, dtype_name, ps.kname)
+        out.update({"traffic": tr, "traffic_source": src, "mfma_busy_sq": busy_sq,
+                    "algorithmic_bytes": (2 * ps.Tq + 2 * ps.Tk) * ps.H * ps.dh * (2 if dtype_name == "bf16" else 4) * B})
     # the full-batch output against the oracle on one scene (the GPU tests hold the full parity matrix of this workload)
     out["parity"] = parity_check(ps.fwd.out, ps.masters, ps.ak, ps.cross, [B - 1])
     if bwd_steps > 0:
