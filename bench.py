@@ -85,6 +85,18 @@ def oracle_forward(q, k, v, ex, ak, cross, trans_coeff):
     return out
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
 def cpu_baseline(workload, seed):
     """The CPU oracle on a bounded sample of the same workload, host cores.  Reported beside the GPU number; baseline only."""
     from gta_amd import synth
@@ -100,7 +112,8 @@ def cpu_baseline(workload, seed):
         if time.time() > t_end:
             break
         torch.set_num_threads(nthreads)
-        oracle_forward(q, k, v, ex, ak, cross, 0.01)          # warm-up
+        for _ in range(2):                                    # two warm-ups
+            oracle_forward(q, k, v, ex, ak, cross, 0.01)
         times = []
         while len(times) < 5 and time.time() < t_end:
             t0 = time.perf_counter()
@@ -114,7 +127,7 @@ def cpu_baseline(workload, seed):
     med, cores, nruns = best
     torch.set_num_threads(HOST_THREADS)
     return {"value": Bs * Nq * Pq / med / 1e6, "unit": "Mtokens/s", "cores": cores, "host_cpus": ncpu, "host_cpu_quota": quota,
-            "kind": "port",
+            "cpu_model": cpu_model(), "kind": "port", "warmups": 2,
             "sample": f"oracle/gta_oracle.py fp32 (rep build + attention), B={Bs} scenes of the same workload, "
                       f"median of {nruns} runs, {med * 1e3:.1f} ms each"}
 
@@ -288,10 +301,12 @@ def workload_leg(name, dtype_name, device, L, seed, steps=100, warmup=10, kernel
         regions.append(e0.elapsed_time(e1) / steps)
     gc.enable()
     ms = min(regions)
+    ms_med = sorted(regions)[len(regions) // 2]            # (the median of the three regions rides beside the best one: ADVICE r05)
     kern_ms, cyc, mhz = ps.kernel_times()
     ps.release_events()
     fl = ps.flops()
-    out = {"value": B * ps.Tq / (ms * 1e-3) / 1e6, "unit": "Mtokens/s", "ms_per_step": ms, "steps": steps, "warmup": warmup, "batch": B, "dtype": dtype_name,
+    out = {"value": B * ps.Tq / (ms * 1e-3) / 1e6, "value_median": B * ps.Tq / (ms_med * 1e-3) / 1e6, "unit": "Mtokens/s", "ms_per_step": ms,
+           "ms_per_step_median": ms_med, "steps": steps, "warmup": warmup, "batch": B, "dtype": dtype_name,
            "mode": "fp32-faithful products (GTA_FLAG_FP32_PRODUCTS)" if precise else "default (bf16 products, fp32 accumulation)",
            "kernel": ps.kname, "kernel_ms": kern_ms, "frac": (fl / (kern_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if kern_ms else None,
            "step_frac": fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "kernel_cycles": cyc, "sclk_mhz": mhz, "ms_per_step_regions": regions,
@@ -332,6 +347,46 @@ def workload_leg(name, dtype_name, device, L, seed, steps=100, warmup=10, kernel
             torch.cuda.synchronize()
             fb.append(e0.elapsed_time(e1) / bwd_steps)
         out["fwd_bwd_ms"] = min(fb)
+        out["fwd_bwd_ms_median"] = sorted(fb)[len(fb) // 2]
+        out["fwd_bwd_ms_regions"] = fb
+    return out
+
+
+def render_leg(device, B=4, chunk=20480, reps=3, precondition_s=0.6):
+    """SURVEY 8 f4 at the CLEVR-TR size: full-image decode of one 240 x 320 target view per scene (76 800 query rays, trainer.py:137-181) through the
+    CLEVR-TR model (runs/clevrtr/GTA/gta/config.yaml: 600 scene tokens, dh = 64), chunked like the reference (max_num_rays = num_points * batch_size / B
+    = 20 480 at B = 4, trainer.py:155-157), per-layer K'/V' images cached across the chunks; bf16 autocast, random-init weights.  Never part of `value`."""
+    from gta_amd import srt
+    torch.manual_seed(4321)
+    model = srt.TransformingSRT(srt.clevrtr_gta_cfg(dropout=0.0)).to(device).eval()
+    data = srt.synthetic_batch(B, n_in=2, n_tgt=1, image=(120, 160), points_per_view=8, device=device, seed=17)
+    h, w = 240, 320
+    rays = torch.nn.functional.normalize(torch.randn(B, h, w, 3, device=device), dim=-1)
+    cam = torch.randn(B, 3, device=device)
+    extras = {"input_transforms": data["input_transforms"], "input_coord": data["input_coord"], "target_transforms": data["target_transforms"][:, :1]}
+    out = {"config": f"CLEVR-TR TransformingSRT decoder (2 cross-attention blocks, 6 heads x 64, Tk = 600) + render MLP, B={B} scenes x one 240x320 view, "
+                     f"{chunk}-ray chunks, K'/V' cache reused, bf16 autocast", "batch": B, "rays_per_view": h * w, "chunk": chunk}
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        z, extras = model.encoder(data["input_images"], data["input_camera_pos"], data["input_rays"], extras)
+
+        def run(reuse):
+            return srt.render_image(model, z, cam, rays, extras, max_num_rays=chunk, reuse_kv=reuse)[0]
+        for reuse, key in ((True, "ms_per_image_batch"), (False, "ms_per_image_batch_no_cache")):
+            precondition(lambda: run(reuse), precondition_s, 2)
+            ts = []
+            for _ in range(reps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                img = run(reuse)
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            out[key] = min(ts)
+            out[key + "_median"] = sorted(ts)[len(ts) // 2]
+        out["finite"] = bool(torch.isfinite(img).all())
+    out["value"] = B * h * w / (out["ms_per_image_batch"] * 1e-3) / 1e6
+    out["value_median"] = B * h * w / (out["ms_per_image_batch_median"] * 1e-3) / 1e6
+    out["unit"] = "Mrays/s"
     return out
 
 
@@ -602,11 +657,15 @@ def main():
             step()
         torch.cuda.synchronize()
         tc0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
+        for i in range(args.steps):
+            step(i)                                         # (the same sampled steps carry dispatch events and stamps as in the timed region below)
         torch.cuda.synchronize()
         cold_ms = (time.perf_counter() - tc0) / args.steps * 1e3
+        c_kern_ms, c_cycles, c_mhz = ps.kernel_times()      # read out now: the timed region re-records the same events and stamp buffers
+        c_flops = 4.0 * B * H * Tq * Tk * dh
         cold_start = {"value": B * Tq / (cold_ms * 1e-3) / 1e6, "ms_per_step": cold_ms, "steps": args.steps, "warmup": args.warmup,
+                      "kernel_ms": c_kern_ms, "frac": (c_flops / (c_kern_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if c_kern_ms else None,
+                      "kernel_cycles": c_cycles, "sclk_mhz": c_mhz,
                       "note": "this rank, W warmup + K steps right after the process built its inputs (idle GPU): the protocol of rounds 1-4"}
         # ---- preconditioning: the same step, untimed, until the part has settled on its sustained clock ----
         tp0 = time.perf_counter()
@@ -712,6 +771,11 @@ def main():
             except Exception as e:  # noqa: BLE001
                 workloads["cl-enc-f32-faithful"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
             torch.cuda.empty_cache()
+            try:
+                workloads["render-cl"] = render_leg(device, precondition_s=min(0.6, args.precondition_s))
+            except Exception as e:  # noqa: BLE001
+                workloads["render-cl"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+            torch.cuda.empty_cache()
     srt_train = None
     if args.model_train_steps > 0:
         # whole-model optimizer step (conv stem, 5 + 2 Transformer blocks on the HIP attention path,
@@ -750,6 +814,8 @@ def main():
                                    f"B={B}/GPU, H={H}, Tq={Tq}, Tk={Tk}, dh={dh}, f_dims={f_dims}, "
                                    f"views q/k={Nq}/{Nk}" + (", fp32-faithful products (GTA_FLAG_FP32_PRODUCTS)" if args.precise else ""),
                        "global_batch": n * B, "parallelism": f"dp{n}"},
+            "protocol": ("sustained: K steps behind W warmup steps behind ~%.1f s of the same step untimed (r05 on); `cold_start` = rounds 1-4's protocol, same run"
+                         % args.precondition_s) if args.precondition_s > 0 else "cold: W warmup + K steps from whatever state the GPU was in (rounds 1-4's protocol)",
             "preconditioning": precond, "cold_start": cold_start,
             "host_ms_per_step": t_host / args.steps * 1e3, "per_rank_ms_per_step": per_rank, "extra_leg_errors": extra_errors or None,
             "per_rank_sclk_mhz": per_rank_sclk, "per_rank_kernel_ms": per_rank_kern,

@@ -158,9 +158,12 @@ def _views(f_dims, packed, q, k) -> Tuple[int, int]:
 # --------------------------------------------------------------------------------------------
 def _as_kernel_layout(t: torch.Tensor) -> torch.Tensor:
     """[B,H,T,dh] view usable by the kernel as is (unit channel stride, 16-B aligned rows)."""
+    return t if _kernel_layout_ok(t) else t.contiguous()
+
+
+def _kernel_layout_ok(t: torch.Tensor) -> bool:
     esz = t.element_size()
-    ok = t.stride(3) == 1 and t.data_ptr() % 16 == 0 and all((s * esz) % 16 == 0 for s in t.stride()[:3])
-    return t if ok else t.contiguous()
+    return t.stride(3) == 1 and t.data_ptr() % 16 == 0 and all((s * esz) % 16 == 0 for s in t.stride()[:3])
 
 
 def _check_tables(q, k, f_dims, Nq, Nk, vrep_q, vrep_k, cs_q, cs_k, coord_q, coord_k, tc, ta, k_side=True):
@@ -237,9 +240,17 @@ class _GtaAttn(torch.autograd.Function):
                       k_side=not (flags & native.FLAG_PRETRANSFORMED))
         ws = None
         if not (flags & (native.FLAG_FUSED_KV | native.FLAG_PRETRANSFORMED)):
+            # what the images of a cache depend on: the key side's shape and layout, the dtype (bf16 / fp32 inputs pick different instances) and the
+            # arithmetic mode -- the fp32-faithful plan stores FOUR images per tile [K'hi | V'hi | K'lo | V'lo], the default plan two: a cache
+            # written under one plan must never be streamed under the other (the byte-size check alone let that through)
+            plan_key = (bool(flags & native.FLAG_FP32_PRODUCTS), bool(flags & native.FLAG_V_TRANSFORM), str(dt), B, H, int(k.shape[2]), dh,
+                        tuple(sorted((g, int(n)) for g, n in f_dims.items() if n)), int(so3_degree), int(Nk))
             if kv_cache is not None and kv_cache.get("images") is not None:
                 # K'/V' tile images of an earlier call against the same keys (chunked decode): skip the pre-pass
                 ws = kv_cache["images"]
+                if kv_cache.get("plan") != plan_key:
+                    raise native.GtaError(f"kv_cache holds images written under another plan {kv_cache.get('plan')} (this call: {plan_key}): "
+                                          "use one cache dict per (key set, dtype, precise mode)")
                 if ws.numel() < native.attn_fwd_workspace_bytes(desc) or ws.device != q.device:
                     raise native.GtaError("kv_cache holds images of a different key set")
                 desc.flags = flags | native.FLAG_KV_READY
@@ -254,7 +265,7 @@ class _GtaAttn(torch.autograd.Function):
                     need = max(need, native.attn_fwd_workspace_bytes(widest))
                 ws = torch.empty(need, device=q.device, dtype=torch.uint8)
                 if kv_cache is not None:
-                    kv_cache["images"] = ws
+                    kv_cache["images"], kv_cache["plan"] = ws, plan_key
         if ws is not None and _GtaAttn.flash_events is not None and not (desc.flags & native.FLAG_KV_READY):
             # instrumentation (bench.py): bracket the attention kernel alone with stream events
             desc.flags = flags | native.FLAG_PREP_ONLY
@@ -497,8 +508,6 @@ def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: 
         flags |= native.FLAG_FP32_PRODUCTS
         # r05: at dh <= 64 (CLEVR-TR, the reference's fp32 config) the mode has a two-stage plan of its own -- the pre-pass writes hi and lo
         # images, the 32-row kernel runs three MFMAs per product; other head sizes keep the single-kernel plan (asked of the library below)
-        if kv_mode == "prepass_rows32":
-            kv_mode = "prepass"
     if kv_cache is not None:
         if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in (q, k, v, trans_coeff)):
             raise native.GtaError("kv_cache is an inference feature: call under torch.no_grad()")
@@ -507,8 +516,12 @@ def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: 
         kv_mode = "prepass" if q.shape[2] > 256 else "fused"
     Nq, Nk = _views(f_dims, packed, q, k)
     if precise and kv_mode == "prepass" and q.is_cuda and not pretransformed:
-        probe = native.make_desc(q, k, v, q, f_dims, so3_degree, Nq, Nk, scale, flags)
-        if native.attn_fwd_supported(probe) == 0 and native.attn_fwd_workspace_bytes(probe) == 0:       # no split-bf16 two-stage instance here
+        # (probed with the tensors the kernel will see: _as_kernel_layout fixes unaligned strides that the raw views would be refused for)
+        def _shape_of(t):          # same shape in the layout the call will use (no data: only sizes, dtype and strides matter to the question)
+            return t if (t.dtype == q.dtype and _kernel_layout_ok(t)) else q.new_empty(t.shape)
+        qp_, kp_, vp_ = _shape_of(q), _shape_of(k), _shape_of(v)
+        probe = native.make_desc(qp_, kp_, vp_, qp_, f_dims, so3_degree, Nq, Nk, scale, flags)
+        if native.attn_fwd_workspace_bytes(probe) == 0:       # no split-bf16 two-stage instance at this head size
             if kv_cache is not None:
                 raise native.GtaError("precise=True at this head size runs the single-kernel plan: no kv_cache")
             kv_mode = "fused"

@@ -241,12 +241,13 @@ def synthetic_batch(B, n_in=5, n_tgt=5, image=128, points_per_view=512, device="
         E[:, 0] = torch.eye(4, dtype=torch.float64)
         return E.to(dtype)
 
-    grid = torch.from_numpy(make_2dcoord(image, image))
+    ih, iw = (image, image) if isinstance(image, int) else image      # (CLEVR-TR: 120 x 160 inputs, clevr_tr.py:255-260)
+    grid = torch.from_numpy(make_2dcoord(ih, iw))
     coord_in = grid[4::8, 4::8].reshape(-1, 2)
     flat = grid.reshape(-1, 2)
     idx = torch.randint(0, flat.shape[0], (B, n_tgt, points_per_view), generator=g)
     batch = {
-        "input_images": torch.rand(B, n_in, 3, image, image, generator=g, dtype=dtype),
+        "input_images": torch.rand(B, n_in, 3, ih, iw, generator=g, dtype=dtype),
         "input_camera_pos": torch.randn(B, n_in, 3, generator=g, dtype=dtype),
         "input_rays": torch.zeros(B, n_in, 1, 1, 3, dtype=dtype),          # unused on the gta path (emb: False)
         "target_camera_pos": torch.randn(B, n_tgt, points_per_view, 3, generator=g, dtype=dtype),
@@ -267,3 +268,16 @@ def msn_gta_so3_cfg(dropout=0.01):
             "encoder_kwargs": dict(pos_start_octave=-5, dropout=dropout, heads=8, emb=False, attn_args=aa),
             "decoder_kwargs": dict(z_dim=768, pos_start_octave=-5, dropout=dropout, heads=8, emb="const",
                                    attn_args={"method": {"name": "gta", "args": dict(args)}})}
+
+
+def clevrtr_gta_cfg(dropout=0.01, precise=False):
+    """model.args of runs/clevrtr/GTA/gta/config.yaml:14-52 (SE(3) + SO(2) reps; 2 input views of 120 x 160 -> 600 scene tokens, dh = 64).
+    ``precise`` = this build's fp32-faithful arithmetic for the config's ``mixed_prec: False`` (config.yaml:55)."""
+    def aa():
+        args = dict(so2=8, max_freq_h=1, max_freq_w=1, f_dims=dict(se3=32, so2=32))
+        if precise:
+            args["precise"] = True
+        return {"method": {"name": "gta", "args": args}}
+    return {"encoder": "isrt", "decoder": "isrt",
+            "encoder_kwargs": dict(pos_start_octave=-5, dim=768, attdim=384, heads=6, dropout=dropout, emb=False, attn_args=aa()),
+            "decoder_kwargs": dict(z_dim=384, rmlp_dim=768, heads=6, pos_start_octave=-5, dropout=dropout, emb="const", attn_args=aa())}

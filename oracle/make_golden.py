@@ -295,6 +295,84 @@ def srt_case(name, seed, P=5, layout="ms"):
     np.savez_compressed(os.path.join(OUT, f"srt_{name}.npz"), **rec)
 
 
+def checkpoint_case(name, seed, P=16):
+    """SURVEY 8 f3 with what the image has: a checkpoint FILE written by the reference's own ``Checkpoint.save``
+    (source/checkpoint.py:21-35) the way train.py:181-199,301-308 uses it -- encoder, decoder and optimizer registered, the
+    scalars of train.py:301-305 passed as keywords -- from a reference ``TransformingSRT`` in fp32 after ONE AdamW step (so the
+    optimizer entry carries real moments), and a second file whose modules were saved WITH their wrapper's ``module.`` prefix
+    (what a user gets who registers the DistributedDataParallel objects instead of ``.module``).  The reference model then
+    renders a batch from the saved weights (computed in fp64 from the fp32 weights): ``ckpt_<name>_io.npz`` holds those inputs and
+    the prediction.  The files hold state dicts and scalars only (``torch.load(weights_only=True)`` reads them): data."""
+    import shutil
+    import source.checkpoint as ref_ckpt
+    torch.manual_seed(seed)
+    g = gen(seed)
+    f_dims = {"triv": 0, "se3": 8, "so3": 8, "so2": 8}
+    ak = attn_kwargs(f_dims, 2, 2)
+    aa = {"method": {"name": "gta", "args": ak}}
+    cfg = {"encoder": "isrt", "decoder": "isrt",
+           "encoder_kwargs": dict(dim=48, attdim=48, num_conv_blocks=3, num_att_blocks=2, heads=2, dropout=0.0,
+                                  emb=False, attn_args=aa),
+           "decoder_kwargs": dict(dim=20, num_att_blocks=1, z_dim=48, heads=2, dropout=0.0, emb="const", rmlp_dim=32,
+                                  attn_args=aa)}
+    model = ref_nvs.TransformingSRT(cfg)                      # fp32, the reference's own initialisation
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01)      # (train.py:214-215)
+    B, N, Nt, HW = 2, 2, 2, 32
+    h = HW // 8
+
+    def batch(dtype):
+        images = torch.rand(B, N, 3, HW, HW, generator=g, dtype=torch.float64).to(dtype)
+        coord_in = O.patch_coords(HW, HW, 8).to(dtype)[None, None].expand(B, N, h * h, 2).contiguous()
+        extras = {"input_transforms": O.random_extrinsics(B, N, g, torch.float64).to(dtype),
+                  "target_transforms": O.random_extrinsics(B, Nt, g, torch.float64).to(dtype),
+                  "input_coord": coord_in, "target_coord": rand_coords(B, Nt, P, g).to(dtype)}
+        cam_in = torch.randn(B, N, 3, generator=g, dtype=torch.float64).to(dtype)
+        rays_in = torch.randn(B, N, HW, HW, 3, generator=g, dtype=torch.float64).to(dtype)
+        cam_t = torch.randn(B, Nt, P, 3, generator=g, dtype=torch.float64).to(dtype)
+        rays_t = torch.randn(B, Nt, P, 3, generator=g, dtype=torch.float64).to(dtype)
+        target = torch.rand(B, Nt, P, 3, generator=g, dtype=torch.float64).to(dtype)
+        return images, cam_in, rays_in, cam_t, rays_t, target, extras
+
+    images, cam_in, rays_in, cam_t, rays_t, target, extras = batch(torch.float32)
+    pred, _ = model(images, cam_in, rays_in, cam_t, rays_t, dict(extras))
+    loss = ((pred.reshape(B, Nt * P, 3) - target.flatten(1, 2)) ** 2).mean()
+    loss.backward()
+    opt.step()
+    tmp = tempfile.mkdtemp(prefix="gta_ckpt_")
+    scalars = {"epoch_it": 3, "it": 1234, "t": 56.5, "loss_val_best": 21.25, "run_id": "golden"}
+    ref_ckpt.Checkpoint(tmp, device=None, encoder=model.encoder, decoder=model.decoder, optimizer=opt).save("model.pt", **dict(scalars))
+    shutil.copyfile(os.path.join(tmp, "model.pt"), os.path.join(OUT, f"ckpt_{name}.pt"))
+
+    class _Wrapped(torch.nn.Module):                          # the key prefix DistributedDataParallel gives its module's state dict
+        def __init__(self, m):
+            super().__init__()
+            self.module = m
+    ref_ckpt.Checkpoint(tmp, device=None, encoder=_Wrapped(model.encoder), decoder=_Wrapped(model.decoder)).save("model_ddp.pt", **dict(scalars))
+    shutil.copyfile(os.path.join(tmp, "model_ddp.pt"), os.path.join(OUT, f"ckpt_{name}_ddp.pt"))
+    # the file reads back through the reference's own Checkpoint.load into a fresh reference model, which renders a second batch
+    fresh = ref_nvs.TransformingSRT(cfg)
+    rest = ref_ckpt.Checkpoint(tmp, device=None, encoder=fresh.encoder, decoder=fresh.decoder).load("model.pt")
+    assert {k: rest[k] for k in scalars} == scalars and "optimizer" in rest
+    fresh = fresh.double().eval()
+    images, cam_in, rays_in, cam_t, rays_t, target, extras = batch(torch.float64)
+    with torch.no_grad():
+        pred, _ = fresh(images, cam_in, rays_in, cam_t, rays_t, dict(extras))
+    pred = pred.reshape(B, Nt * P, 3)
+    om = O.OracleSRT(cfg).double().eval()
+    om.load_state_dict(fresh.state_dict(), strict=True)
+    with torch.no_grad():
+        pred2 = om(images, cam_in, rays_in, cam_t, rays_t, dict(extras))
+    worst = (pred2 - pred).abs().max().item()
+    print(f"ckpt_{name:23s} oracle-vs-reference max dev {worst:.2e}  (weights read back through the reference's Checkpoint.load)")
+    assert worst < 5e-9, worst
+    rec = {"images": images.numpy(), "cam_in": cam_in.numpy(), "rays_in": rays_in.float().numpy(), "cam_t": cam_t.numpy(),
+           "rays_t": rays_t.numpy(), "target": target.numpy(), "pred": pred.numpy(), "meta": np.array(repr(cfg)),
+           "scalars": np.array(repr(scalars))}
+    rec.update(flat("extras.", extras))
+    np.savez_compressed(os.path.join(OUT, f"ckpt_{name}_io.npz"), **rec)
+    shutil.rmtree(tmp)
+
+
 def vecrep_case(name, seed):
     """The ``elementwise_mul`` ablation, as far as the reference can run it: ``pre_compute_reps`` builds the flattened reps
     (encoder.py:200-206,238-243,263-265), the ``rep_to_vec`` Linear of ``Attention(elementwise_mul=True)``
@@ -407,6 +485,9 @@ if __name__ == "__main__":
         operator_case("euclid_tau", {"se3": 6, "so2": 8}, 2, 0, H=2, B=2, Nq=2, Pq=5, Nk=2, Pk=5, seed=13,
                       cross=False, euclid=True, tau=1.3)
         sys.exit(0)
+    if sys.argv[1:] == ["--checkpoint-only"]:
+        checkpoint_case("ref_ms", seed=50)
+        sys.exit(0)
     operator_case("cl_self", CL, 2, 0, H=2, B=2, Nq=2, Pq=6, Nk=2, Pk=6, seed=0, cross=False)
     operator_case("cl_cross", CL, 2, 0, H=2, B=2, Nq=3, Pq=7, Nk=2, Pk=6, seed=1, cross=True)
     operator_case("ms_self", MS, 2, 2, H=2, B=2, Nq=3, Pq=5, Nk=3, Pk=5, seed=2, cross=False)
@@ -432,6 +513,7 @@ if __name__ == "__main__":
     srt_case("ms_tiny", seed=30)
     srt_case("ms_rays", seed=31, P=128)
     srt_case("cl_rays", seed=32, P=128, layout="cl")
+    checkpoint_case("ref_ms", seed=50)
     vecrep_case("vecrep_attn", seed=40)
     module_case("enc_cl", CL, 2, 0, dim=32, depth=2, H=2, dh=16, B=2, Nq=2, Pq=6, Nk=2, Pk=6, seed=20,
                 cross=False)

@@ -131,6 +131,39 @@ def test_srt_model_matches_reference(fixture, mixed):
     _srt_grad_check(model, d, mixed)
 
 
+@pytest.mark.parametrize("fname", ["ckpt_ref_ms.pt", "ckpt_ref_ms_ddp.pt"])
+def test_checkpoint_written_by_the_reference_renders_on_the_hip_path(fname):
+    """a checkpoint file written by the reference's own ``Checkpoint.save`` (checkpoint.py:21-35; fixture from oracle/make_golden.py
+    ``checkpoint_case``: fp32 weights after one AdamW step, encoder / decoder / optimizer + scalars; the ``_ddp`` file with the ``module.`` prefix)
+    -> ``gta_amd.checkpoint.load_checkpoint`` -> HIP forward of the whole TransformingSRT -> the pixels the REFERENCE model rendered from that file.
+    (The J-convention half of f3 needs the released J_dense.pt, which is not in the image: parked)"""
+    import ast
+    import numpy as np
+    from gta_amd import srt, checkpoint
+    io = np.load(G.GOLDEN + "/ckpt_ref_ms_io.npz")
+    cfg = ast.literal_eval(str(io["meta"]))
+    model = srt.TransformingSRT(cfg)
+    rest = checkpoint.load_checkpoint(G.GOLDEN + "/" + fname, device="cuda", encoder=model.encoder, decoder=model.decoder)
+    assert rest["it"] == 1234 and rest["run_id"] == "golden"
+    model = model.cuda().eval()
+    t = lambda n: torch.from_numpy(io[n]).float().cuda()
+    ex = {k[len("extras."):]: torch.from_numpy(io[k]).float().cuda() for k in io.files if k.startswith("extras.")}
+    ref = torch.from_numpy(io["pred"]).float()
+    B, NtP = ref.shape[0], ref.shape[1]
+    from gta_amd import layers
+    for precise in (False, True):             # default (bf16 products) and fp32-faithful arithmetic
+        for m in model.modules():
+            if isinstance(m, layers.Attention):
+                m.precise = precise
+        with torch.no_grad():
+            pred, _ = model(t("images"), t("cam_in"), t("rays_in"), t("cam_t"), t("rays_t"), dict(ex))
+        torch.cuda.synchronize()
+        st = C.err_stats(pred.reshape(B, NtP, 3).cpu(), ref)
+        assert st["finite"] and st["max_abs"] <= (1e-4 if precise else 1e-2) and st["rel_rms"] <= (2e-5 if precise else 5e-3), (precise, st)
+        psnr = lambda x: -10.0 * torch.log10(((x - torch.from_numpy(io["target"]).float().flatten(1, 2)) ** 2).mean((1, 2)))
+        assert (psnr(pred.reshape(B, NtP, 3).cpu()) - psnr(ref)).abs().max() <= 0.05        # dB
+
+
 def test_srt_clevr_layout_fp32_faithful_psnr_parity():
     """The CLEVR-TR layout (se3 + so2, no so3: runs/clevrtr/GTA/gta/config.yaml:19-52), the config the reference trains in fp32
     (`mixed_prec: False`, config.yaml:55): whole TransformingSRT under the reference's weights (fixture srt_cl_rays: 2 x 128 rays per
@@ -306,6 +339,54 @@ def test_render_image_full_size_view():
     st = C.err_stats(img.cpu(), ref)
     assert st["finite"] and st["max_abs"] < 1e-2, st
     assert ((img.cpu() - ref) ** 2).mean() < 1e-5
+
+
+def test_render_image_clevrtr_size_view():
+    """Full-image decode at the CLEVR-TR evaluation size (trainer.py:137-181, evaluate.py:122-131; SURVEY 8 f4 names both sizes): one
+    240 x 320 target view per scene = 76 800 query rays against the 600 scene tokens of two 120 x 160 input views, CLEVR-TR layout (se3 32 + so2 32,
+    dh = 64: the gta_fwd2 / KV_READY instances), in 20 480-ray chunks (the reference's max_num_rays = num_points * batch_size / B at B = 4,
+    trainer.py:155-157) with the per-layer K'/V' cache reused across the chunks.  The oracle decodes 2 400 sampled pixels per scene (every query of a
+    cross-attention decoder is independent of the others) under the same weights; the last chunk is ragged (76 800 = 3 x 20 480 + 15 360)."""
+    from gta_amd import srt
+    from oracle import gta_oracle as O
+    torch.manual_seed(7)
+    aa = {"method": {"name": "gta", "args": dict(so2=8, max_freq_h=1, max_freq_w=1, f_dims=dict(se3=32, so2=32))}}
+    cfg = {"encoder": "isrt", "decoder": "isrt",
+           "encoder_kwargs": dict(pos_start_octave=-5, dim=96, attdim=128, num_att_blocks=2, heads=2, dropout=0.0, emb=False, attn_args=aa),
+           "decoder_kwargs": dict(dim=36, z_dim=128, rmlp_dim=64, heads=2, pos_start_octave=-5, dropout=0.0, emb="const", attn_args=aa)}
+    model = srt.TransformingSRT(cfg).cuda().eval()
+    B, h, w = 2, 240, 320
+    data = srt.synthetic_batch(B, n_in=2, n_tgt=1, image=(120, 160), points_per_view=8, device="cuda", seed=3)
+    assert data["input_coord"].shape[2] == 300                                     # 15 x 20 patch tokens per view -> Tk = 600
+    g = torch.Generator().manual_seed(5)
+    rays = torch.nn.functional.normalize(torch.randn(B, h, w, 3, generator=g), dim=-1).cuda()
+    cam = torch.randn(B, 3, generator=g).cuda()
+    extras = {"input_transforms": data["input_transforms"], "input_coord": data["input_coord"],
+              "target_transforms": data["target_transforms"][:, :1]}
+    with torch.no_grad():
+        z, extras = model.encoder(data["input_images"], data["input_camera_pos"], data["input_rays"], extras)
+        assert z.shape == (B, 600, 128)
+        img, _ = srt.render_image(model, z, cam, rays, extras, max_num_rays=20480, reuse_kv=True)
+        img_nc, _ = srt.render_image(model, z, cam, rays, extras, max_num_rays=32768, reuse_kv=False)    # other chunking, no cache
+    torch.cuda.synchronize()
+    assert img.shape == (B, h, w, 3) and bool(torch.isfinite(img).all())
+    assert (img - img_nc).abs().max() < 2e-3                                        # cached vs recomputed K'/V', different chunk edges
+    om = O.OracleSRT(cfg)
+    om.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()}, strict=True)
+    om.eval()
+    n_s = 2400
+    idx = torch.stack([torch.randperm(h * w, generator=g)[:n_s] for _ in range(B)])              # [B, n_s]
+    idx[:, :4] = torch.tensor([0, w - 1, (h - 1) * w, h * w - 1])                                 # the four corners ride along
+    coord_all = torch.from_numpy(gta_amd.gta.make_2dcoord(h, w)).flatten(0, 1)
+    rays_s = torch.gather(rays.cpu().flatten(1, 2), 1, idx[..., None].expand(-1, -1, 3))
+    ex_o = {"input_transforms": data["input_transforms"].cpu(), "input_coord": data["input_coord"].cpu(),
+            "target_transforms": data["target_transforms"][:, :1].cpu(), "target_coord": coord_all[idx][:, None]}
+    with torch.no_grad():
+        ref = om(data["input_images"].cpu(), None, None, None, rays_s, ex_o).view(B, n_s, 3)
+    got = torch.gather(img.cpu().flatten(1, 2), 1, idx[..., None].expand(-1, -1, 3))
+    st = C.err_stats(got, ref)
+    assert st["finite"] and st["max_abs"] < 1e-2, st
+    assert ((got - ref) ** 2).mean() < 1e-5
 
 
 def test_gta2d_transformer_dit_shape_vs_oracle():

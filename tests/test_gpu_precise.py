@@ -208,6 +208,21 @@ def test_two_stage_plan_fp32_faithful(shape):
             a = gta_amd.gta_attention(qd, kd, vd, f_dims, packed, so3_degree=0, trans_coeff=tc, precise=True, kv_cache=cache)
             b = gta_amd.gta_attention(qd, kd, vd, f_dims, packed, so3_degree=0, trans_coeff=tc, precise=True, kv_cache=cache)
         assert torch.equal(a, b) and torch.equal(a.float().cpu(), outs["prepass"])
+        #  a cache written under one plan is refused by the other: the fp32-faithful plan stores four images per tile, the default
+        # plan two, and bf16 inputs pick other instances again -- before, only the byte size was looked at and the mixed call read lo parts as tiles
+        with torch.no_grad():
+            with pytest.raises(native.GtaError, match="another plan"):
+                gta_amd.gta_attention(qd, kd, vd, f_dims, packed, so3_degree=0, trans_coeff=tc, precise=False, kv_cache=cache)
+            with pytest.raises(native.GtaError, match="another plan"):
+                gta_amd.gta_attention(qd.bfloat16(), kd.bfloat16(), vd.bfloat16(), f_dims, packed, so3_degree=0, trans_coeff=tc, kv_cache=cache)
+            fresh = {}
+            c = gta_amd.gta_attention(qd, kd, vd, f_dims, packed, so3_degree=0, trans_coeff=tc, precise=False, kv_cache=fresh)
+            d = gta_amd.gta_attention(qd, kd, vd, f_dims, packed, so3_degree=0, trans_coeff=tc, precise=False, kv_cache=fresh)
+            with pytest.raises(native.GtaError, match="another plan"):
+                gta_amd.gta_attention(qd, kd, vd, f_dims, packed, so3_degree=0, trans_coeff=tc, precise=True, kv_cache=fresh)
+        assert torch.equal(c, d)
+        st = C.err_stats(c.float().cpu(), ref)
+        assert st["finite"] and st["max_abs"] <= 2.5e-2 * st["ref_max"], st
 
 
 def test_two_stage_plan_fp32_faithful_not_at_dh96():

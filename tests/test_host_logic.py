@@ -498,6 +498,45 @@ def test_reference_checkpoint_layout_round_trip(tmp_path):
     assert sorted(again) == ["decoder", "encoder", "it"] and list(again["encoder"]) == list(ref_file["encoder"])
 
 
+def test_checkpoint_written_by_the_reference_loads_strictly():
+    """``tests/golden/ckpt_ref_ms.pt`` was written by the reference's own ``Checkpoint.save`` (checkpoint.py:21-35) with encoder,
+    decoder and optimizer registered and train.py:301-305's scalars (oracle/make_golden.py ``checkpoint_case``); ``ckpt_ref_ms_ddp.pt`` carries the
+    ``module.`` prefix of wrapped modules.  Both load into gta_amd.TransformingSRT with ``strict=True`` under ``weights_only=True``, the optimizer
+    entry restores an AdamW over the same parameters, the scalars come back as ``Checkpoint.load`` returns them, and the oracle model under the
+    loaded weights reproduces the reference's rendering of the fixture batch (CPU leg; the HIP leg is tests/test_gpu_modules.py)."""
+    import ast
+    from tests import _golden as G
+    from gta_amd import srt, checkpoint
+    from oracle import gta_oracle as O
+    io = np.load(G.GOLDEN + "/ckpt_ref_ms_io.npz")
+    cfg = ast.literal_eval(str(io["meta"]))
+    scalars = ast.literal_eval(str(io["scalars"]))
+    model = srt.TransformingSRT(cfg)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01)
+    rest = checkpoint.load_checkpoint(G.GOLDEN + "/ckpt_ref_ms.pt", encoder=model.encoder, decoder=model.decoder, optimizer=opt)
+    assert rest == scalars
+    st = opt.state_dict()["state"]
+    assert len(st) == len(list(model.parameters())) and all(float(v["step"]) == 1.0 for v in st.values())
+    raw = torch.load(G.GOLDEN + "/ckpt_ref_ms.pt", weights_only=True)
+    for part in ("encoder", "decoder"):
+        for n, v in getattr(model, part).state_dict().items():
+            assert torch.equal(v, raw[part][n]), (part, n)
+    ddp = srt.TransformingSRT(cfg)
+    rest = checkpoint.load_checkpoint(G.GOLDEN + "/ckpt_ref_ms_ddp.pt", encoder=ddp.encoder, decoder=ddp.decoder)
+    assert rest == scalars
+    for (n, a), (_, b) in zip(model.state_dict().items(), ddp.state_dict().items()):
+        assert torch.equal(a, b), n
+    with pytest.raises(KeyError):
+        checkpoint.load_checkpoint(G.GOLDEN + "/ckpt_ref_ms_ddp.pt", optimizer=opt)
+    om = O.OracleSRT(cfg).double().eval()
+    om.load_state_dict({k: v.double() for k, v in model.state_dict().items()}, strict=True)
+    t = lambda n: torch.from_numpy(io[n]).double()
+    ex = {k[len("extras."):]: torch.from_numpy(io[k]).double() for k in io.files if k.startswith("extras.")}
+    with torch.no_grad():
+        pred = om(t("images"), t("cam_in"), t("rays_in"), t("cam_t"), t("rays_t"), ex)
+    assert (pred - t("pred")).abs().max() < 1e-9
+
+
 def test_j_convention_check(tmp_path):
     """a J_dense.pt is compared with the build's J before a released so3 checkpoint is served.  The real
     blob is not in the image, so the check itself is tested: identical J -> trivial signs; a sign-conjugated J (another
