@@ -595,7 +595,7 @@ def main():
                          "without this phase `value` is a number about the clock ramp, not about the kernels.  The line reports both: `value` "
                          "(sustained) and `cold_start` (W warmup + K steps from idle, what rounds 1-4 reported).  0 = no preconditioning, "
                          "value == the cold number")
-    ap.add_argument("--kv-mode", dest="kv_mode", default="prepass", choices=["prepass", "fused", "prepass_rows32", "prepass_item_cxx", "prepass_bwd_keys32", "prepass_bwd_keys64", "prepass_bwd_split", "prepass_bwd_keys64_split"],
+    ap.add_argument("--kv-mode", dest="kv_mode", default="prepass", choices=["prepass", "fused", "prepass_rows32", "prepass_fwd2", "prepass_item_cxx", "prepass_bwd_keys32", "prepass_bwd_keys64", "prepass_bwd_split", "prepass_bwd_keys64_split"],
                     help="execution plan of gta_attn_fwd (see include/gta_hip.h); prepass_rows32 = GTA_FLAG_ROWS32: the 32-rows-per-wave "
                          "attention kernel where the 64-rows one would run; prepass_item_cxx = GTA_FLAG_ITEM_CXX: the 64-rows kernel with its "
                          "compiler-scheduled item prologue / epilogue where the generated item stream would run (A/B)")
@@ -644,6 +644,7 @@ def main():
     ps = PlannedStep(args.workload, B, args.dtype, device, L, seed=1234 + rank, steps=args.steps, kernel_samples=args.kernel_samples,
                      flags=(native.FLAG_FP32_PRODUCTS if args.precise else 0) | (native.FLAG_FUSED_KV if fused
                      else native.FLAG_ROWS32 if args.kv_mode == "prepass_rows32"
+                     else (native.FLAG_ROWS32 | native.FLAG_FWD2_GENERIC) if args.kv_mode == "prepass_fwd2"
                      else native.FLAG_ITEM_CXX if args.kv_mode == "prepass_item_cxx" else 0), time_kernel=not fused)
     step, fwd, q, k, v, exd, tc, ak, cross, kname, rows_it = ps.step, ps.fwd, ps.q, ps.k, ps.v, ps.exd, ps.tc, ps.ak, ps.cross, ps.kname, ps.rows_it
     qm, km, vm, ex = ps.masters

@@ -40,6 +40,8 @@ bool gta_attn64_takes(const GtaFwdParams& p, int dhp, int layout, int esz);     
 int gta_qtiles_dispatch(const GtaFwdParams& p, hipStream_t stream);
 int gta_attn64_dispatch(const GtaFwdParams& p, int esz, int layout, hipStream_t stream);
 const char* gta_attn64_kernel_name(const GtaFwdParams& p, int esz, int layout);
+bool gta_fwdc_takes(const GtaFwdParams& p, int dhp, int layout, int esz);                                    // gta_fwd_cl.hip
+int gta_fwdc_dispatch(const GtaFwdParams& p, int layout, hipStream_t stream);
 
 // profiling hook (not part of the product ABI, see gta_hip.h): events for the NEXT attention-kernel launch of this thread
 thread_local void* gta_dbg_fwd_ev_start = nullptr;      // (also read by gta_fwd64.hip)
@@ -924,7 +926,8 @@ int gta_fwd2_rows_per_item(const GtaFwdParams& p, int dhp, int esz) {
 }
 const char* gta_fwd2_attention_kernel_name(const GtaFwdParams& p, int dhp, int esz) {
     if (p.flags & GTA_FLAG_FP32_PRODUCTS) return "gta_fwd2_kernel";
-    return gta_attn64_takes(p, dhp, layout_of(p, dhp), esz) ? gta_attn64_kernel_name(p, esz, layout_of(p, dhp)) : "gta_fwd2_kernel";
+    if (gta_attn64_takes(p, dhp, layout_of(p, dhp), esz)) return gta_attn64_kernel_name(p, esz, layout_of(p, dhp));
+    return gta_fwdc_takes(p, dhp, layout_of(p, dhp), esz) ? "gta_fwdc_kernel" : "gta_fwd2_kernel";
 }
 
 // Compile-time layouts exist for the shipped configs; others read the chunk table.
@@ -942,6 +945,7 @@ static int launch_flash(const GtaFwdParams& p, hipStream_t stream) {
         }
     }
     if (gta_attn64_takes(p, DHP, layout_of(p, DHP), ESZ)) return gta_attn64_dispatch(p, ESZ, layout_of(p, DHP), stream);   // 64 rows per wave (gta_fwd64.hip)
+    if (gta_fwdc_takes(p, DHP, layout_of(p, DHP), ESZ)) return gta_fwdc_dispatch(p, layout_of(p, DHP), stream);             // the dh = 64 bf16 instance (gta_fwd_cl.hip)
     switch (layout_of(p, DHP)) {
         case GTA_LAYOUT_MS:  if (DHP == 96) return launch_fwd2<DHP, ESZ, (DHP == 96 ? GTA_LAYOUT_MS : GTA_LAYOUT_GENERIC)>(p, stream); break;
         case GTA_LAYOUT_CL:  if (DHP == 64) return launch_fwd2<DHP, ESZ, (DHP == 64 ? GTA_LAYOUT_CL : GTA_LAYOUT_GENERIC)>(p, stream); break;

@@ -486,6 +486,9 @@ def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: 
     if kv_mode == "prepass_rows32":    # tuning knob: keep the 32-rows-per-wave attention kernel where the 64-rows one would run
         flags |= native.FLAG_ROWS32
         kv_mode = "prepass"
+    if kv_mode == "prepass_fwd2":      # tuning knob (r06): the generic 32-row kernel gta_fwd2_kernel where the dh = 64 bf16 instance gta_fwdc_kernel would run
+        flags |= native.FLAG_ROWS32 | native.FLAG_FWD2_GENERIC
+        kv_mode = "prepass"
     if kv_mode == "prepass_item_cxx":  # tuning knob: the 64-rows kernel with its compiler-scheduled item prologue / epilogue (not the item stream)
         flags |= native.FLAG_ITEM_CXX
         kv_mode = "prepass"

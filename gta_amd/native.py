@@ -28,6 +28,7 @@ FLAG_NO_DMA = 1 << 8
 FLAG_PERSIST = 1 << 9
 FLAG_FP32_PRODUCTS = 1 << 10
 FLAG_ROWS32 = 1 << 11
+FLAG_FWD2_GENERIC = 1 << 6      # (r06) keep gta_fwd2_kernel where the dh = 64 bf16 instance gta_fwdc_kernel would run
 FLAG_ITEM_CXX = 1 << 12
 FLAG_BWD_KEYS32 = 1 << 13
 FLAG_BWD_KEYS64 = 1 << 14

@@ -16,7 +16,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define C(r) "v_cvt_pk_bf16_f32 %" #r ", %" #r ", %" #r "\n"
 #define OPS : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(Af), "v"(Bf)
 
-enum { SEP, MIX6, MIX5, MIX4, MIX3, MFMA_ONLY, SEP_LEAN, MIX6_DOT };
+enum { SEP, MIX6, MIX5, MIX4, MIX3, MFMA_ONLY, SEP_LEAN, MIX6_DOT, DEP, DEP2, HALF, HALF_LDS, SEP_LDS, MIX5_LDS, HALF3_LDS };
 
 // the filler multisets (per 16 MFMAs): SEP / MIX6 = 32 E + 48 A + 16 C (96); MIX5 = 32 E + 32 A + 16 C (80); MIX4 = 32 E + 16 A + 16 C (64); MIX3 = 32 E + 16 C (48)
 #define G6(m, e1, a1, e2, a2, c1, a3) M(m) E(e1) A(a1) E(e2) A(a2) C(c1) A(a3)
@@ -30,6 +30,12 @@ __global__ __launch_bounds__(256, 3) void probe(uint64_t* out, float* sink, int 
     f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
     bf16x8 Af, Bf;
     for (int i = 0; i < 8; ++i) { Af[i] = (__bf16)(0.01f * i + 0.003f * (threadIdx.x & 31)); Bf[i] = (__bf16)(0.02f * i - 0.001f * (threadIdx.x & 63)); }
+    __shared__ __attribute__((aligned(16))) char lds_buf[17 * 1024];
+    for (int i = threadIdx.x; i < 17 * 256; i += 256) ((float*)lds_buf)[i] = 0.f;
+    const unsigned la = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_buf + (threadIdx.x & 63) * 16;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x4 kd, kd1, kd2, kd3; u32x2 vd, vd1, vd2, vd3;
     __syncthreads();
     const uint64_t t0 = __builtin_amdgcn_s_memtime();
 #pragma unroll 1
@@ -81,6 +87,78 @@ __global__ __launch_bounds__(256, 3) void probe(uint64_t* out, float* sink, int 
                          G3(0, 4, 5, 6) G3(1, 7, 8, 9) G3(2, 10, 11, 4) G3(3, 5, 6, 7)
                          G3(0, 8, 9, 10) G3(1, 11, 4, 5) G3(2, 6, 7, 8) G3(3, 9, 10, 11) OPS);
         }
+
+        if (MODE == DEP) {        // one dependent chain per accumulator, four in a row: does a same-accumulator MFMA issue back to back?
+            asm volatile(M(0) M(0) M(0) M(0) M(1) M(1) M(1) M(1) M(2) M(2) M(2) M(2) M(3) M(3) M(3) M(3) OPS);
+        }
+        if (MODE == DEP2) {       // two chains interleaved (the shipped order)
+            asm volatile(M(0) M(1) M(0) M(1) M(0) M(1) M(0) M(1) M(2) M(3) M(2) M(3) M(2) M(3) M(2) M(3) OPS);
+        }
+#define V10a E(4) A(5) E(6) A(7) C(8) E(9) A(10) E(11) A(4) C(5)
+#define V10b E(6) A(7) E(8) A(9) C(10) E(11) A(4) E(5) A(6) C(7)
+        if (MODE == HALF) {       // S0 chain | S1 chain beside softmax(S0) | P0 V beside softmax(S1) | P1 V beside 12 misc   (32 E + 44 A + 16 C = 92)
+            asm volatile(M(0) M(0) M(0) M(0)
+                         M(1) V10a M(1) V10b M(1) V10a M(1) V10b
+                         M(2) V10a M(3) V10b M(2) V10a M(3) V10b
+                         M(2) A(4) A(5) A(6) M(3) A(7) A(8) A(9) M(2) A(10) A(11) A(4) M(3) A(5) A(6) A(7) OPS);
+        }
+#define KR_0 "ds_read_b128 %[k0], %[la] offset:0\n"
+#define KR_1024 "ds_read_b128 %[k1], %[la] offset:1024\n"
+#define KR_2048 "ds_read_b128 %[k2], %[la] offset:2048\n"
+#define KR_3072 "ds_read_b128 %[k3], %[la] offset:3072\n"
+#define KR_4096 "ds_read_b128 %[k0], %[la] offset:4096\n"
+#define KR_5120 "ds_read_b128 %[k1], %[la] offset:5120\n"
+#define KR_6144 "ds_read_b128 %[k2], %[la] offset:6144\n"
+#define KR_7168 "ds_read_b128 %[k3], %[la] offset:7168\n"
+#define VR_8192 "ds_read_b64_tr_b16 %[v0], %[la] offset:8192\n"
+#define VR_8704 "ds_read_b64_tr_b16 %[v1], %[la] offset:8704\n"
+#define VR_9216 "ds_read_b64_tr_b16 %[v2], %[la] offset:9216\n"
+#define VR_9728 "ds_read_b64_tr_b16 %[v3], %[la] offset:9728\n"
+#define VR_10240 "ds_read_b64_tr_b16 %[v0], %[la] offset:10240\n"
+#define VR_10752 "ds_read_b64_tr_b16 %[v1], %[la] offset:10752\n"
+#define VR_11264 "ds_read_b64_tr_b16 %[v2], %[la] offset:11264\n"
+#define VR_11776 "ds_read_b64_tr_b16 %[v3], %[la] offset:11776\n"
+#define VR_12288 "ds_read_b64_tr_b16 %[v0], %[la] offset:12288\n"
+#define VR_12800 "ds_read_b64_tr_b16 %[v1], %[la] offset:12800\n"
+#define VR_13312 "ds_read_b64_tr_b16 %[v2], %[la] offset:13312\n"
+#define VR_13824 "ds_read_b64_tr_b16 %[v3], %[la] offset:13824\n"
+#define VR_14336 "ds_read_b64_tr_b16 %[v0], %[la] offset:14336\n"
+#define VR_14848 "ds_read_b64_tr_b16 %[v1], %[la] offset:14848\n"
+#define VR_15360 "ds_read_b64_tr_b16 %[v2], %[la] offset:15360\n"
+#define VR_15872 "ds_read_b64_tr_b16 %[v3], %[la] offset:15872\n"
+#define KRn(o) KR_##o
+#define VRn(o) VR_##o
+#define KR(o) KRn(o)
+#define VR(o) VRn(o)
+#define OPSL : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), [k0] "=&v"(kd), [k1] "=&v"(kd1), [k2] "=&v"(kd2), [k3] "=&v"(kd3), [v0] "=&v"(vd), [v1] "=&v"(vd1), [v2] "=&v"(vd2), [v3] "=&v"(vd3) : "v"(Af), "v"(Bf), [la] "v"(la)
+#define ML(acc) "v_mfma_f32_32x32x16_bf16 %" #acc ", %20, %21, %" #acc "\n"
+        if (MODE == SEP_LDS) {    // hipcc's order with the tile's LDS reads: 8 K' fragment reads in front of QK^T, 16 V' transpose-reads along P V
+            asm volatile(KR(0) KR(1024) KR(2048) KR(3072) KR(4096) KR(5120) KR(6144) KR(7168)
+                         ML(0) ML(1) ML(0) ML(1) ML(0) ML(1) ML(0) ML(1)
+                         VR(8192) VR(8704) VR(9216) VR(9728)
+                         E(4) E(5) E(6) E(7) E(8) E(9) E(10) E(11) E(4) E(5) E(6) E(7) E(8) E(9) E(10) E(11)
+                         A(4) A(5) A(6) A(7) A(8) A(9) A(10) A(11) A(4) A(5) A(6) A(7) A(8) A(9) A(10) A(11)
+                         E(4) E(5) E(6) E(7) E(8) E(9) E(10) E(11) E(4) E(5) E(6) E(7) E(8) E(9) E(10) E(11)
+                         A(4) A(5) A(6) A(7) A(8) A(9) A(10) A(11) A(4) A(5) A(6) A(7) A(8) A(9) A(10) A(11)
+                         C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11)
+                         VR(10240) VR(10752) VR(11264) VR(11776) ML(2) ML(3) VR(12288) VR(12800) VR(13312) VR(13824) ML(2) ML(3)
+                         VR(14336) VR(14848) VR(15360) VR(15872) ML(2) ML(3) ML(2) ML(3)
+                         A(4) A(5) A(6) A(7) A(8) A(9) A(10) A(11) A(4) A(5) A(6) A(7) "s_waitcnt lgkmcnt(0)\n" OPSL);
+        }
+        if (MODE == HALF_LDS) {
+            asm volatile(KR(0) KR(1024) KR(2048) KR(3072) ML(0) KR(4096) ML(0) KR(5120) ML(0) KR(6144) ML(0) KR(7168)
+                         ML(1) V10a VR(8192) ML(1) V10b VR(8704) ML(1) V10a VR(9216) ML(1) V10b VR(9728)
+                         ML(2) V10a VR(10240) VR(10752) ML(3) V10b VR(11264) VR(11776) ML(2) V10a VR(12288) VR(12800) ML(3) V10b VR(13312) VR(13824)
+                         ML(2) A(4) A(5) A(6) VR(14336) ML(3) A(7) A(8) A(9) VR(14848) ML(2) A(10) A(11) A(4) VR(15360) ML(3) A(5) A(6) A(7) VR(15872) "s_waitcnt lgkmcnt(0)\n" OPSL);
+        }
+#define G5L(m, e1, a1, e2, a2, c1) ML(m) E(e1) A(a1) E(e2) A(a2) C(c1)
+        if (MODE == MIX5_LDS) {   // the skewed stream (80 fillers) + 12 misc + the LDS reads, one or two per gap
+            asm volatile(G5L(0, 4, 5, 6, 7, 8) KR(0) G5L(1, 9, 10, 11, 4, 5) KR(1024) G5L(2, 6, 7, 8, 9, 10) KR(2048) G5L(3, 11, 4, 5, 6, 7) KR(3072)
+                         G5L(0, 8, 9, 10, 11, 4) KR(4096) A(4) G5L(1, 5, 6, 7, 8, 9) KR(5120) A(5) G5L(2, 10, 11, 4, 5, 6) KR(6144) A(6) G5L(3, 7, 8, 9, 10, 11) KR(7168) A(7)
+                         G5L(0, 4, 5, 6, 7, 8) VR(8192) VR(8704) A(8) G5L(1, 9, 10, 11, 4, 5) VR(9216) VR(9728) A(9) G5L(2, 6, 7, 8, 9, 10) VR(10240) VR(10752) A(10) G5L(3, 11, 4, 5, 6, 7) VR(11264) VR(11776) A(11)
+                         G5L(0, 8, 9, 10, 11, 4) VR(12288) VR(12800) A(4) G5L(1, 5, 6, 7, 8, 9) VR(13312) VR(13824) A(5) G5L(2, 10, 11, 4, 5, 6) VR(14336) VR(14848) A(6) G5L(3, 7, 8, 9, 10, 11) VR(15360) VR(15872) A(7)
+                         "s_waitcnt lgkmcnt(0)\n" OPSL);
+        }
     }
     const uint64_t t1 = __builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
@@ -112,6 +190,13 @@ void run(const char* name, int n_fill, uint64_t* d, float* sink) {
 int main() {
     uint64_t* d; float* sink;
     hipMalloc(&d, 8 * 768); hipMalloc(&sink, 4);
+    run<DEP>("dep", 0, d, sink);
+    run<DEP2>("dep2", 0, d, sink);
+    run<SEP_LDS>("sep+lds", 92, d, sink);
+    run<HALF>("half", 92, d, sink);
+    run<HALF_LDS>("half+lds", 92, d, sink);
+    run<MIX5_LDS>("mix5+lds", 92, d, sink);
+    return 0;
     run<MFMA_ONLY>("mfma", 0, d, sink);
     run<SEP>("sep", 96, d, sink);
     run<MIX6>("mix6", 96, d, sink);

@@ -93,6 +93,6 @@ def test_bench_line_contract_on_the_gpu():
     assert rf["bound"] == "mfma" and rf["kernel"] == "gta_attn64_items_kernel" and 0 < rf["frac"] < 1 and rf["kernel_ms"] < d["ms_per_step"]
     assert d["parity"]["parity_max_abs"] <= 2.5e-2 * d["parity"]["ref_max_abs"]
     w = d["workloads"]["cl-enc"]
-    assert "error" not in w and w["kernel"] == "gta_fwd2_kernel" and 0 < w["frac"] < 1 and len(w["ms_per_step_regions"]) == 3
+    assert "error" not in w and w["kernel"] == "gta_fwdc_kernel" and 0 < w["frac"] < 1 and len(w["ms_per_step_regions"]) == 3
     assert w["parity"]["parity_max_abs"] <= 2.5e-2 * w["parity"]["ref_max_abs"]
     assert d["cold_start"]["value"] > 0 and d["preconditioning"]["steps"] > 0

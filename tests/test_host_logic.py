@@ -595,7 +595,9 @@ def test_attention_kernel_selection_and_backward_workspace_without_gpu():
     assert kern(96, MS, 2, 125, 1280, bf, 5) == ("gta_fwd2_kernel", 128)            # no more than 128 query rows: the 32-row kernel
     assert kern(64, CL, 0, 512, 512, bf, 2) == ("gta_attn64_kernel", 256)
     assert kern(64, CL, 0, 512, 512, f32, 2) == ("gta_fwd2_kernel", 128)            # the dh = 64 instances are bf16
-    assert kern(64, CL, 0, 600, 600, bf, 2) == ("gta_fwd2_kernel", 128)             # CLEVR-TR's own Tk = 600: 9.4 key tiles
+    assert kern(64, CL, 0, 600, 600, bf, 2) == ("gta_fwdc_kernel", 128)             # CLEVR-TR's own Tk = 600: 9.4 key tiles -> the dh = 64 bf16 instance (r06)
+    assert kern(64, CL, 0, 600, 600, bf, 2, native.FLAG_FWD2_GENERIC) == ("gta_fwd2_kernel", 128)
+    assert kern(64, CL, 0, 600, 64, bf, 2) == ("gta_fwd2_kernel", 128)              # one key tile: the generic kernel (bit-for-bit with the single-kernel plan)
     assert kern(64, DIT, 0, 1024, 1024, bf) == ("gta_attn64_kernel", 256)
     q = torch.empty(2, 8, 1280, 96, dtype=bf)
     d0 = native.make_desc(q, q, q, q, MS, 2, 5, 5, 96 ** -0.5, native.FLAG_V_TRANSFORM)
