@@ -44,7 +44,7 @@ def _grad_buffers(q, k, v):
 def attn_bwd(cfg, q, k, v, out, dout, lse, tc, ta, vrep_q, vrep_k, cs_q, cs_k, kv_images=None, want_dtau=False):
     """Returns (dq, dk, dv, dtrans_coeff or None, dtau or None); dtau ([1] fp32) only with ``want_dtau``."""
     f_dims, so3_degree, Nq, Nk, scale, flags = cfg
-    flags = flags & ~(native.FLAG_FUSED_KV | native.FLAG_KV_READY | native.FLAG_PREP_ONLY | native.FLAG_PERSIST | native.FLAG_FP32_PRODUCTS)
+    flags = flags & ~(native.FLAG_FUSED_KV | native.FLAG_KV_READY | native.FLAG_PREP_ONLY | native.FLAG_PERSIST)      # (GTA_FLAG_FP32_PRODUCTS stays: the X3 walks)
     dt = q.dtype
     dout = dout.to(dt)
     if not _rows_ok(dout):

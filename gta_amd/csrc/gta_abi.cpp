@@ -253,7 +253,8 @@ BwdLayout bwd_layout(const GtaAttnDesc* d) {
     BwdLayout L;
     const int dhp = padded_dh(d->dh);
     const int64_t n_qt = (d->Tq + 63) / 64, n_kt = (d->Tk + 63) / 64;
-    const int64_t stage = 2LL * 64 * dhp * 2;
+    // (the fp32-faithful backward, r06: four images per tile -- hi and lo -- on both sides)
+    const int64_t stage = ((d->flags & GTA_FLAG_FP32_PRODUCTS) ? 4LL : 2LL) * 64 * dhp * 2;
     L.n_prep = (int)(d->B * d->H * n_qt);
     L.n_dq = d->B * d->H * ((d->Tq + 127) / 128);
     L.n_dkv = d->B * d->H * ((d->Tk + 127) / 128);
@@ -285,6 +286,8 @@ extern "C" int gta_attn_bwd(const GtaAttnDesc* d, const void* q, const void* k, 
     if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || !dqkv_stride || !dout_stride || !workspace)
         return fail(GTA_E_BADARG, "null argument");
     if (d->flags & GTA_FLAG_PRETRANSFORMED) return fail(GTA_E_UNSUPPORTED, "backward of the pretransformed mode");
+    if ((d->flags & GTA_FLAG_FP32_PRODUCTS) && (d->dtype != GTA_DTYPE_F32 || padded_dh(d->dh) > 64))
+        return fail(GTA_E_UNSUPPORTED, "GTA_FLAG_FP32_PRODUCTS backward: fp32 inputs at dh <= 64 (other sizes: gta_rep_apply + gta_attn_bwd_plain_f32)");
     GtaBwdParams p;
     memset(&p, 0, sizeof p);
     rc = build_ctab(d, p.ctab);
@@ -308,7 +311,7 @@ extern "C" int gta_attn_bwd(const GtaAttnDesc* d, const void* q, const void* k, 
         f.v_sb = d->v_stride[0]; f.v_sh = d->v_stride[1]; f.v_st = d->v_stride[2];
         f.B = d->B; f.H = d->H; f.Tq = d->Tq; f.Tk = d->Tk; f.Nq = d->Nq; f.Nk = d->Nk;
         f.Pq = d->Tq / d->Nq; f.Pk = d->Tk / d->Nk; f.invPq = 1.0f / f.Pq; f.invPk = 1.0f / f.Pk;
-        f.dh = d->dh; f.nso2 = d->d_so2 / 2; f.flags = d->flags & ~GTA_FLAG_FP32_PRODUCTS; f.scale = d->scale;      // (the backward's images are the plain ones)
+        f.dh = d->dh; f.nso2 = d->d_so2 / 2; f.flags = d->flags; f.scale = d->scale;      // (GTA_FLAG_FP32_PRODUCTS: the pre-pass writes hi and lo images, as the X3 walks read them)
         rc = gta_fwd2_dispatch(f, padded_dh(d->dh), esz, true, false, (hipStream_t)stream);
         if (rc) return fail(rc, "K/V pre-pass launch failed");
         kv_images = ws + L.off_kv;

@@ -174,24 +174,30 @@ GTA_DEV float wg_sum256(float v, float* scratch /*>= 4 floats LDS*/, int tid) {
 // ================================================================================================
 // 1. q-side pre-pass
 // ================================================================================================
-template <int DHP, int ESZ>
+// X3 = the fp32-faithful instances (GTA_FLAG_FP32_PRODUCTS, fp32 inputs, dh <= 64; r06): a tile is FOUR images [Q''hi | dO~hi | Q''lo | dO~lo]
+// (hi = bf16(x), lo = bf16(x - hi): x = hi + lo to 2^-17), as the forward's [K'hi | V'hi | K'lo | V'lo] of gta_prep.hip
+template <int DHP, int ESZ, bool X3 = false>
 struct BPrepSmem {
+    static_assert(!X3 || ESZ == 4, "the split images are built from fp32 inputs");
     static constexpr int U = DHP * ESZ / 16;
     static constexpr int RAW = BN * DHP * ESZ;
     static constexpr int IMG = BN * DHP * 2;
+    static constexpr int NIMG = X3 ? 4 : 2;
     static constexpr int OFF_RQ = 0;
     static constexpr int OFF_RDO = OFF_RQ + RAW;
     static constexpr int OFF_RO = OFF_RDO + RAW;
     static constexpr int OFF_IQ = (ESZ == 2) ? OFF_RQ : OFF_RO + RAW;      // images in place for bf16 input
     static constexpr int OFF_IDO = (ESZ == 2) ? OFF_RDO : OFF_IQ + IMG;
-    static constexpr int OFF_D = (ESZ == 2) ? OFF_RO + RAW : OFF_IDO + IMG;  // D partials [4 waves][64 rows] + 4 scratch floats
+    static constexpr int OFF_IQL = OFF_IDO + IMG;                            // (X3) the lo images, in the tile's order
+    static constexpr int OFF_IDOL = OFF_IQL + IMG;
+    static constexpr int OFF_D = (ESZ == 2) ? OFF_RO + RAW : OFF_IDO + IMG + (X3 ? 2 * IMG : 0);  // D partials [4 waves][64 rows] + 4 scratch floats
     static constexpr int OFF_REC = OFF_D + 4 * 64 * 4 + 16;                  // records last, sized by the actual number of views
     static int total(int nviews) { return OFF_REC + nviews * BREC * 4; }
 };
 
-template <int DHP, int ESZ>
+template <int DHP, int ESZ, bool X3 = false>
 __global__ __launch_bounds__(256) void gta_bwd_prep_kernel(const GtaBwdParams p) {
-    using S = BPrepSmem<DHP, ESZ>;
+    using S = BPrepSmem<DHP, ESZ, X3>;
     constexpr int CHP = DHP / 8, U = S::U, IMG = S::IMG;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -256,8 +262,17 @@ __global__ __launch_bounds__(256) void gta_bwd_prep_kernel(const GtaBwdParams p)
                 apply(x);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) x[0][i] *= qscale;
-                *reinterpret_cast<u32x4_t*>(smem + S::OFF_IQ + off) = pack8(x[0]);
-                *reinterpret_cast<u32x4_t*>(smem + S::OFF_IDO + off) = pack8(x[1]);
+                const u32x4_t hq = pack8(x[0]), hd = pack8(x[1]);
+                *reinterpret_cast<u32x4_t*>(smem + S::OFF_IQ + off) = hq;
+                *reinterpret_cast<u32x4_t*>(smem + S::OFF_IDO + off) = hd;
+                if constexpr (X3) {
+                    float tq[8], td[8];
+                    unpack8(hq, tq); unpack8(hd, td);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { x[0][i] -= tq[i]; x[1][i] -= td[i]; }
+                    *reinterpret_cast<u32x4_t*>(smem + S::OFF_IQL + off) = pack8(x[0]);
+                    *reinterpret_cast<u32x4_t*>(smem + S::OFF_IDOL + off) = pack8(x[1]);
+                }
             };
             constexpr std::true_type T{};
             constexpr std::false_type F{};
@@ -306,6 +321,10 @@ __global__ __launch_bounds__(256) void gta_bwd_prep_kernel(const GtaBwdParams p)
                 const u32x4_t z = {0u, 0u, 0u, 0u};
                 *reinterpret_cast<u32x4_t*>(smem + S::OFF_IQ + off) = z;
                 *reinterpret_cast<u32x4_t*>(smem + S::OFF_IDO + off) = z;
+                if constexpr (X3) {
+                    *reinterpret_cast<u32x4_t*>(smem + S::OFF_IQL + off) = z;
+                    *reinterpret_cast<u32x4_t*>(smem + S::OFF_IDOL + off) = z;
+                }
             }
         }
     };
@@ -314,13 +333,15 @@ __global__ __launch_bounds__(256) void gta_bwd_prep_kernel(const GtaBwdParams p)
     const float dc_wg = wg_sum256(dcpart, dsum + 256, tid);     // (includes a __syncthreads)
     __syncthreads();
     const long tile = ((long)b * p.H + h) * n_qt + j;
-    char* gimg = (char*)p.qimg + tile * (2L * IMG);
+    char* gimg = (char*)p.qimg + tile * ((long)S::NIMG * IMG);
     constexpr int PIECES = IMG / 1024;
+    static_assert(S::OFF_IDO == S::OFF_IQ + IMG || ESZ == 2, "fp32 input: the images are contiguous in LDS, in the tile's order");
 #pragma unroll
-    for (int i = 0; i < (2 * PIECES + 3) / 4; ++i) {
+    for (int i = 0; i < (S::NIMG * PIECES + 3) / 4; ++i) {
         const int piece = wave + 4 * i;
-        if (piece < 2 * PIECES) {
-            const char* src = (piece < PIECES ? smem + S::OFF_IQ + piece * 1024 : smem + S::OFF_IDO + (piece - PIECES) * 1024) + lane * 16;
+        if (piece < S::NIMG * PIECES) {
+            const int im = piece / PIECES, pc = piece - im * PIECES;
+            const char* src = smem + (im == 0 ? S::OFF_IQ : im == 1 ? S::OFF_IDO : im == 2 ? S::OFF_IQL : S::OFF_IDOL) + pc * 1024 + lane * 16;
             *reinterpret_cast<u32x4_t*>(gimg + piece * 1024 + lane * 16) = *reinterpret_cast<const u32x4_t*>(src);
         }
     }
@@ -1309,6 +1330,518 @@ __global__ __launch_bounds__(1024) void gta_reduce_kernel(const float* __restric
     if (threadIdx.x == 0) *out = neg_div ? -sm[0] / *neg_div : sm[0];
 }
 
+// ================================================================================================
+// 5. The fp32-faithful instances (r06; GTA_FLAG_FP32_PRODUCTS, fp32 inputs, dh <= 64): the compiled dQ and dK/dV walks over hi / lo image
+// pairs, every product of the five contractions as THREE matrix instructions (lo*hi + hi*lo + hi*hi, as the forward's X3 instances:
+// gta_fwd2.hip), P and dS split the same way before they become operands; rho_q / adjoint rho stay where they are (fp32, in the pre-pass and
+// the epilogues).  This is the backward of the reference's `mixed_prec: False` training (runs/clevrtr/GTA/gta/config.yaml:55,
+// source/trainer.py:106) on the matrix cores at 3/16 of the bf16 rate instead of 1/16 (gta_plain32.hip) and without the eight per-row rho
+// launches of the generic route.  A tile is four images [A hi | B hi | A lo | B lo] (K', V' from the forward's workspace; Q'', dO~ from
+// gta_bwd_prep_kernel<.., X3>); two ring stages of 4 images: tile j + 1 streams in under tile j's 72 matrix instructions.
+// ================================================================================================
+GTA_DEV void split_acc8(const f32x16_t& a, int t, bf16x8_t& hi, bf16x8_t& lo) {      // accumulator registers 8t..8t+7 -> bf16 hi, lo
+    const u32x4_t h = pack_acc8(a, t);
+    float x[8], r[8];
+    unpack8(h, x);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = a[8 * t + i] - x[i];
+    hi = __builtin_bit_cast(bf16x8_t, h);
+    lo = __builtin_bit_cast(bf16x8_t, pack8(r));
+}
+GTA_DEV f32x16_t mfma3(const bf16x8_t& ah, const bf16x8_t& al, const bf16x8_t& bh, const bf16x8_t& bl, f32x16_t c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+}
+
+template <int DHP>
+struct DqX3Smem {
+    static constexpr int CHP = DHP / 8;
+    static constexpr int IMG = BN * DHP * 2;
+    static constexpr int STAGE = 4 * IMG;
+    static constexpr int RING = 2 * STAGE;
+    static constexpr int OROW = DHP + 4;
+    static constexpr int OST = 128 * OROW * 4;
+    static_assert(OST <= RING, "dQ staging must fit the ring");
+    static constexpr int OFF_RING = 0;
+    static constexpr int OFF_SCR = RING;
+    static constexpr int OFF_REC = RING + 32;
+    static constexpr int total(int nviews) { return OFF_REC + nviews * BREC * 4; }
+};
+
+template <int DHP>
+GTA_DEV void bwd_dq_x3_body(const GtaBwdParams& p, char* smem, const int L, const int nwg) {
+    using S = DqX3Smem<DHP>;
+    constexpr int CHP = S::CHP, KS = DHP / 16, DB = DHP / 32, BM = 128, ESZ = 4, IMG = S::IMG;
+    constexpr int ITEMS = 2 * CHP / 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    int w;
+    {
+        const int xcd = L & 7, idx = L >> 3, q8 = nwg >> 3, r8 = nwg & 7;
+        w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int n_q128 = (p.Tq + BM - 1) / BM;
+    const int bh = w / n_q128, qt = w - bh * n_q128;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int q0 = qt * BM;
+    const int n_tiles = (p.Tk + BN - 1) / BN;
+    const int n_qt64 = (p.Tq + BN - 1) / BN;
+    const int ch_real = p.dh >> 3;
+    char* ring = smem + S::OFF_RING;
+    float* rec = reinterpret_cast<float*>(smem + S::OFF_REC);
+    const char* kvimg = (const char*)p.kvimg + ((long)b * p.H + h) * n_tiles * (long)S::STAGE;
+
+    // Q''/dO~ images (hi and lo) of this workgroup's two 64-row tiles -> ring stages 0, 1
+    const long qtile0 = ((long)b * p.H + h) * n_qt64 + 2 * qt;
+    const int n_my_qt = (2 * qt + 1 < n_qt64) ? 2 : 1;
+    dma_linear4<S::STAGE>(ring, (const char*)p.qimg + qtile0 * S::STAGE, wave, lane);
+    if (n_my_qt == 2) dma_linear4<S::STAGE>(ring + S::STAGE, (const char*)p.qimg + (qtile0 + 1) * S::STAGE, wave, lane);
+    const int t_last = (q0 + BM - 1 < p.Tq ? q0 + BM - 1 : p.Tq - 1);
+    const int n_first = q0 / p.Pq;
+    const int n_cnt = t_last / p.Pq - n_first + 1;
+    const float tc = p.trans_coeff ? *p.trans_coeff : 1.0f;
+    if (p.vrep_q) stage_brec(rec, p.vrep_q, (long)b * p.Nq + n_first, n_cnt, 0, tc, tid, 256);
+    const int my_row = wave * 32 + l31;
+    const int my_tile = my_row >> 6;
+    float lse2n = -1e30f, Dn = 0.f;
+    if (my_tile < n_my_qt) {
+        const float* st = p.stats + (qtile0 + my_tile) * 128;
+        lse2n = st[my_row & 63];
+        Dn = st[64 + (my_row & 63)];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    bf16x8_t qfh[KS], qfl[KS], dfh[KS], dfl[KS];
+    {
+        const char* qi = ring + my_tile * S::STAGE;
+        const int r = my_row & 63;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const u32x4_t z = {0, 0, 0, 0};
+            qfh[ks] = qfl[ks] = dfh[ks] = dfl[ks] = __builtin_bit_cast(bf16x8_t, z);
+            if (my_tile < n_my_qt) {
+                const int off = (r * CHP + swz<CHP>(r, 2 * ks + lh)) * 16;
+                qfh[ks] = *reinterpret_cast<const bf16x8_t*>(qi + off);
+                dfh[ks] = *reinterpret_cast<const bf16x8_t*>(qi + IMG + off);
+                qfl[ks] = *reinterpret_cast<const bf16x8_t*>(qi + 2 * IMG + off);
+                dfl[ks] = *reinterpret_cast<const bf16x8_t*>(qi + 3 * IMG + off);
+            }
+        }
+    }
+    __syncthreads();
+    dma_linear4<S::STAGE>(ring, kvimg, wave, lane);
+
+    f32x16_t dq[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dq[d][i] = 0.f;
+    int koff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) koff[ks] = (l31 * CHP + swz<CHP>(l31, 2 * ks + lh)) * 16;
+    const int g16 = lane >> 4, p16 = lane & 15;
+    int voff[DB][2];
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+        const int u = 4 * d + 2 * (g16 & 1) + ((p16 & 3) >> 1);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int r = 4 * lh + (p16 >> 2) + 8 * hf;
+            voff[d][hf] = (r * CHP + swz<CHP>(r, u)) * 16 + (p16 & 1) * 8;
+        }
+    }
+    const bool want_dtau = p.dt_partial != nullptr;
+    float tA = 0.f, tB = 0.f, tC = 0.f;
+#pragma unroll 1
+    for (int j = 0; j < n_tiles; ++j) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // tile j has landed (nothing else is in flight), everyone is past tile j - 1
+        __builtin_amdgcn_s_barrier();
+        if (j + 1 < n_tiles) dma_linear4<S::STAGE>(ring + ((j + 1) & 1) * S::STAGE, kvimg + (long)(j + 1) * S::STAGE, wave, lane);
+        const char* kf = ring + (j & 1) * S::STAGE;
+        f32x16_t s0, s1, e0, e1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s0[i] = lse2n; s1[i] = lse2n; e0[i] = Dn; e1[i] = Dn; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const char* a = kf + koff[ks];
+            const bf16x8_t k0h = *reinterpret_cast<const bf16x8_t*>(a), k1h = *reinterpret_cast<const bf16x8_t*>(a + 32 * CHP * 16);
+            const bf16x8_t v0h = *reinterpret_cast<const bf16x8_t*>(a + IMG), v1h = *reinterpret_cast<const bf16x8_t*>(a + IMG + 32 * CHP * 16);
+            const bf16x8_t k0l = *reinterpret_cast<const bf16x8_t*>(a + 2 * IMG), k1l = *reinterpret_cast<const bf16x8_t*>(a + 2 * IMG + 32 * CHP * 16);
+            const bf16x8_t v0l = *reinterpret_cast<const bf16x8_t*>(a + 3 * IMG), v1l = *reinterpret_cast<const bf16x8_t*>(a + 3 * IMG + 32 * CHP * 16);
+            s0 = mfma3(k0h, k0l, qfh[ks], qfl[ks], s0);      // S^T  = K' Q''^T
+            s1 = mfma3(k1h, k1l, qfh[ks], qfl[ks], s1);
+            e0 = mfma3(v0h, v0l, dfh[ks], dfl[ks], e0);      // dP^T = V' dO~^T
+            e1 = mfma3(v1h, v1l, dfh[ks], dfl[ks], e1);
+        }
+        const bool tail = (j == n_tiles - 1) && (p.Tk & (BN - 1));
+        const int kbase = j * BN + 4 * lh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float sv0 = s0[r], sv1 = s1[r];            // S - lse2 (log2 units)
+            float p0 = __builtin_amdgcn_exp2f(sv0), p1 = __builtin_amdgcn_exp2f(sv1);
+            if (tail) {
+                const int key = kbase + (r & 3) + 8 * (r >> 2);
+                if (key >= p.Tk) p0 = 0.f;
+                if (key + 32 >= p.Tk) p1 = 0.f;
+            }
+            const float d0 = p0 * e0[r], d1 = p1 * e1[r];
+            if (want_dtau) {                                 // row sums of dS (S - lse2), dS and P (S - lse2): see the epilogue
+                tA = __builtin_fmaf(d0, sv0, tA); tA = __builtin_fmaf(d1, sv1, tA);
+                tB += d0 + d1;
+                tC = __builtin_fmaf(p0, sv0, tC); tC = __builtin_fmaf(p1, sv1, tC);
+            }
+            s0[r] = d0;
+            s1[r] = d1;
+        }
+        bf16x8_t dsh[4], dsl[4];                             // slab sl = 2 half + t
+        split_acc8(s0, 0, dsh[0], dsl[0]); split_acc8(s0, 1, dsh[1], dsl[1]);
+        split_acc8(s1, 0, dsh[2], dsl[2]); split_acc8(s1, 1, dsh[3], dsl[3]);
+        // dQ'^T += K'^T dS^T: A = K'^T by transpose-reads of the hi and the lo image
+        const uint32_t kb_h = lds_addr(kf), kb_l = lds_addr(kf + 2 * IMG);
+        constexpr int SL = 16 * CHP * 16;
+        static_for_bwd<DB>([&](auto DC) {
+            constexpr int d = decltype(DC)::value;
+            u32x2_t hl[4], hh[4], ll[4], lh_[4];
+            {
+                const uint32_t a0 = kb_h + voff[d][0], a1 = kb_h + voff[d][1], c0 = kb_l + voff[d][0], c1 = kb_l + voff[d][1];
+                hl[0] = lds_tr16_b64<0>(a0);      hh[0] = lds_tr16_b64<0>(a1);      ll[0] = lds_tr16_b64<0>(c0);      lh_[0] = lds_tr16_b64<0>(c1);
+                hl[1] = lds_tr16_b64<SL>(a0);     hh[1] = lds_tr16_b64<SL>(a1);     ll[1] = lds_tr16_b64<SL>(c0);     lh_[1] = lds_tr16_b64<SL>(c1);
+                hl[2] = lds_tr16_b64<2 * SL>(a0); hh[2] = lds_tr16_b64<2 * SL>(a1); ll[2] = lds_tr16_b64<2 * SL>(c0); lh_[2] = lds_tr16_b64<2 * SL>(c1);
+                hl[3] = lds_tr16_b64<3 * SL>(a0); hh[3] = lds_tr16_b64<3 * SL>(a1); ll[3] = lds_tr16_b64<3 * SL>(c0); lh_[3] = lds_tr16_b64<3 * SL>(c1);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                const u32x4_t ah = {hl[sl].x, hl[sl].y, hh[sl].x, hh[sl].y}, al = {ll[sl].x, ll[sl].y, lh_[sl].x, lh_[sl].y};
+                dq[d] = mfma3(__builtin_bit_cast(bf16x8_t, ah), __builtin_bit_cast(bf16x8_t, al), dsh[sl], dsl[sl], dq[d]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+
+    // ---- epilogue: dq = A_q^T (c1 dQ') ; d trans_coeff through A_q (as bwd_dq_body, fp32) ----
+    const float c1 = p.scale / (p.tau ? *p.tau : 1.0f);
+    __syncthreads();
+    float* ost = reinterpret_cast<float*>(smem + S::OFF_RING);
+    {
+        const int r = wave * 32 + l31;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4_t v = {dq[d][4 * g] * c1, dq[d][4 * g + 1] * c1, dq[d][4 * g + 2] * c1, dq[d][4 * g + 3] * c1};
+                *reinterpret_cast<f32x4_t*>(ost + r * S::OROW + 32 * d + 8 * g + 4 * lh) = v;
+            }
+    }
+    __syncthreads();
+    const char* qg = (const char*)p.q + ((long)b * p.q_sb + (long)h * p.q_sh) * ESZ;
+    char* dqg = (char*)p.dq + ((long)b * p.dq_sb + (long)h * p.dq_sh) * ESZ;
+    // d tau = -(1/tau) sum_i <q_i, dq_i> = -(ln2/tau) sum_ij dS_ij S2_ij  (gta_hip.h; S2 = the log2-unit logits).  Here the sum is formed in the walk,
+    // in fp32, and CENTRED per row: sum_j dS_ij (S2_ij - m_i) with m_i = sum_j P_ij (S2_ij - lse2_i).  Exactly, sum_j dS_ij = 0 and the centring
+    // changes nothing; in split-bf16 arithmetic a row's dS carries a common-mode error (D_i comes from the forward's o, lse2_i from the
+    // forward's row sums: 2^-17 each) that the uncentred forms -- this one and <q, dq> alike -- multiply by the row's mean logit.
+    float dcpart = 0.f, dtpart = 0.f;
+    if (want_dtau) {
+        const float tBf = tB + __shfl_xor(tB, 32), tCf = tC + __shfl_xor(tC, 32), tAf = tA + __shfl_xor(tA, 32);
+        if (lh == 0 && q0 + my_row < p.Tq) dtpart = LN2 * (tAf - tBf * tCf);
+    }
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int item = wave + 4 * it;
+        const int c = item >> 1;
+        const int r = lane + 64 * (item & 1);
+        const int t = q0 + r;
+        if (c < ch_real && t < p.Tq) {
+            const uint32_t desc = p.ctab[c];
+            float x[1][8];
+            const f32x4_t a = *reinterpret_cast<const f32x4_t*>(ost + r * S::OROW + 8 * c);
+            const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(ost + r * S::OROW + 8 * c + 4);
+            x[0][0] = a.x; x[0][1] = a.y; x[0][2] = a.z; x[0][3] = a.w;
+            x[0][4] = bb.x; x[0][5] = bb.y; x[0][6] = bb.z; x[0][7] = bb.w;
+            if (desc) {
+                const int n = view_of(t, p.Pq, p.invPq) - n_first;
+                const float* rc = rec + n * BREC;
+                if (!(desc & GTA_CHUNK_SO3) && (cd_lo(desc) == GTA_HALF_SE3 || cd_hi(desc) == GTA_HALF_SE3)) {
+                    float q8[8];
+                    g_load_chunk<ESZ>(qg + (long)t * p.q_st * ESZ, c, q8);
+                    const float t0 = rc[BREC_T], t1 = rc[BREC_T + 1], t2 = rc[BREC_T + 2];
+                    if (cd_lo(desc) == GTA_HALF_SE3) dcpart += x[0][3] * (t0 * q8[0] + t1 * q8[1] + t2 * q8[2]);
+                    if (cd_hi(desc) == GTA_HALF_SE3) dcpart += x[0][7] * (t0 * q8[4] + t1 * q8[5] + t2 * q8[6]);
+                }
+                f32x2_t cs[4];
+                if (p.cs_q) load_cs(desc, p.cs_q + ((long)b * p.Tq + t) * 2 * p.nso2, cs);
+                chunk_apply<true, 1>(desc, rc + BREC_MT, rc + BREC_D1T, rc + BREC_D2T, cs, x);
+            }
+            g_store_chunk<ESZ>(dqg + (long)t * p.dq_st * ESZ, c, x[0]);
+        }
+    }
+    const float dc_wg = wg_sum256(dcpart, reinterpret_cast<float*>(smem + S::OFF_SCR), tid);
+    if (tid == 0) p.dc_partial[p.dc_off_dq + w] = dc_wg;
+    if (want_dtau) {
+        __syncthreads();
+        const float dt_wg = wg_sum256(dtpart, reinterpret_cast<float*>(smem + S::OFF_SCR), tid);
+        if (tid == 0) p.dt_partial[w] = dt_wg;
+    }
+}
+
+template <int DHP>
+struct DkvX3Smem {
+    static constexpr int CHP = DHP / 8;
+    static constexpr int IMG = BN * DHP * 2;
+    static constexpr int STAGE = 4 * IMG;                  // [Q''hi | dO~hi | Q''lo | dO~lo] of one 64-row tile
+    static constexpr int RING = 2 * STAGE;
+    static constexpr int OFF_RING = 0;                     // (the workgroup's two K'/V' tiles sit in the ring until their fragments are in VGPRs)
+    static constexpr int OFF_STATS = RING;                 // [2][128] floats
+    static constexpr int OFF_SCR = OFF_STATS + 2 * 128 * 4;
+    static constexpr int OFF_REC = OFF_SCR + 32;
+    static constexpr int OROW = DHP + 4;
+    static constexpr int OST = 128 * OROW * 4;
+    static_assert(OST <= RING, "staging must fit the ring");
+    static constexpr int total(int nviews) { return OFF_REC + nviews * BREC * 4; }
+};
+
+template <int DHP>
+GTA_DEV void bwd_dkv_x3_body(const GtaBwdParams& p, char* smem, const int L, const int nwg) {
+    using S = DkvX3Smem<DHP>;
+    constexpr int CHP = S::CHP, KS = DHP / 16, DB = DHP / 32, BK = 128, ESZ = 4, IMG = S::IMG;
+    constexpr int ITEMS = 2 * CHP / 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    int w;
+    {
+        const int xcd = L & 7, idx = L >> 3, q8 = nwg >> 3, r8 = nwg & 7;
+        w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int n_k128 = (p.Tk + BK - 1) / BK;
+    const int bh = w / n_k128, kt = w - bh * n_k128;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int k0 = kt * BK;
+    const int n_kt64 = (p.Tk + BN - 1) / BN;
+    const int n_qt = (p.Tq + BN - 1) / BN;
+    const int ch_real = p.dh >> 3;
+    char* ring = smem + S::OFF_RING;
+    float* stats = reinterpret_cast<float*>(smem + S::OFF_STATS);
+    float* rec = reinterpret_cast<float*>(smem + S::OFF_REC);
+    const long ktile0 = ((long)b * p.H + h) * n_kt64 + 2 * kt;
+    const int n_my_kt = (2 * kt + 1 < n_kt64) ? 2 : 1;
+    const char* qimg = (const char*)p.qimg + ((long)b * p.H + h) * n_qt * (long)S::STAGE;
+    const float* gstats = p.stats + ((long)b * p.H + h) * n_qt * 128;
+    dma_linear4<S::STAGE>(ring, (const char*)p.kvimg + ktile0 * S::STAGE, wave, lane);
+    if (n_my_kt == 2) dma_linear4<S::STAGE>(ring + S::STAGE, (const char*)p.kvimg + (ktile0 + 1) * S::STAGE, wave, lane);
+    const int t_last = (k0 + BK - 1 < p.Tk ? k0 + BK - 1 : p.Tk - 1);
+    const int n_first = k0 / p.Pk;
+    const int n_cnt = t_last / p.Pk - n_first + 1;
+    const float tc = p.trans_coeff ? *p.trans_coeff : 1.0f;
+    if (p.vrep_k) stage_brec(rec, p.vrep_k, (long)b * p.Nk + n_first, n_cnt, 1, tc, tid, 256);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // this wave's 32 keys: K' and V' fragments, hi and lo (MFMA B operands), stay in VGPRs
+    const int my_key = wave * 32 + l31;
+    const int my_kt = my_key >> 6;
+    bf16x8_t kh[KS], kl[KS], vh[KS], vl[KS];
+    {
+        const char* ki = ring + my_kt * S::STAGE;
+        const int r = my_key & 63;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const u32x4_t z = {0, 0, 0, 0};
+            kh[ks] = kl[ks] = vh[ks] = vl[ks] = __builtin_bit_cast(bf16x8_t, z);
+            if (my_kt < n_my_kt) {
+                const int off = (r * CHP + swz<CHP>(r, 2 * ks + lh)) * 16;
+                kh[ks] = *reinterpret_cast<const bf16x8_t*>(ki + off);
+                vh[ks] = *reinterpret_cast<const bf16x8_t*>(ki + IMG + off);
+                kl[ks] = *reinterpret_cast<const bf16x8_t*>(ki + 2 * IMG + off);
+                vl[ks] = *reinterpret_cast<const bf16x8_t*>(ki + 3 * IMG + off);
+            }
+        }
+    }
+    __syncthreads();      // every wave holds its fragments: the ring is free
+    dma_linear4<S::STAGE>(ring, qimg, wave, lane);
+    dma_stats(stats, gstats, wave, lane);
+
+    f32x16_t dk[DB], dv[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dk[d][i] = 0.f; dv[d][i] = 0.f; }
+    int koff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) koff[ks] = (l31 * CHP + swz<CHP>(l31, 2 * ks + lh)) * 16;
+    const int g16 = lane >> 4, p16 = lane & 15;
+    int voff[DB][2];
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+        const int u = 4 * d + 2 * (g16 & 1) + ((p16 & 3) >> 1);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int r = 4 * lh + (p16 >> 2) + 8 * hf;
+            voff[d][hf] = (r * CHP + swz<CHP>(r, u)) * 16 + (p16 & 1) * 8;
+        }
+    }
+#pragma unroll 1
+    for (int j = 0; j < n_qt; ++j) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // tile j's images and statistics have landed, everyone is past tile j - 1
+        __builtin_amdgcn_s_barrier();
+        if (j + 1 < n_qt) {
+            dma_linear4<S::STAGE>(ring + ((j + 1) & 1) * S::STAGE, qimg + (long)(j + 1) * S::STAGE, wave, lane);
+            dma_stats(stats + ((j + 1) & 1) * 128, gstats + (long)(j + 1) * 128, wave, lane);
+        }
+        const char* qi = ring + (j & 1) * S::STAGE;         // [Q''hi | dO~hi | Q''lo | dO~lo]
+        const float* stj = stats + (j & 1) * 128;
+        constexpr int SL = 16 * CHP * 16;
+        static_for_bwd<2>([&](auto QBC) {                   // 32 query rows at a time
+            constexpr int qb = decltype(QBC)::value;
+            f32x16_t s, e;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(stj + 32 * qb + 8 * g + 4 * lh);
+                const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(stj + 64 + 32 * qb + 8 * g + 4 * lh);
+                s[4 * g] = l4.x; s[4 * g + 1] = l4.y; s[4 * g + 2] = l4.z; s[4 * g + 3] = l4.w;
+                e[4 * g] = d4.x; e[4 * g + 1] = d4.y; e[4 * g + 2] = d4.z; e[4 * g + 3] = d4.w;
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const char* a = qi + koff[ks] + qb * 32 * CHP * 16;
+                const bf16x8_t qh = *reinterpret_cast<const bf16x8_t*>(a), dh_ = *reinterpret_cast<const bf16x8_t*>(a + IMG);
+                const bf16x8_t ql = *reinterpret_cast<const bf16x8_t*>(a + 2 * IMG), dl = *reinterpret_cast<const bf16x8_t*>(a + 3 * IMG);
+                s = mfma3(qh, ql, kh[ks], kl[ks], s);        // S - lse2 = Q'' K'^T - lse2
+                e = mfma3(dh_, dl, vh[ks], vl[ks], e);       // dP - D   = dO~ V'^T - D
+            }
+            f32x16_t ds;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float pv = __builtin_amdgcn_exp2f(s[i]);
+                s[i] = pv;
+                ds[i] = pv * e[i];
+            }
+            bf16x8_t pfh[2], pfl[2], dsh[2], dsl[2];
+            split_acc8(s, 0, pfh[0], pfl[0]); split_acc8(s, 1, pfh[1], pfl[1]);
+            split_acc8(ds, 0, dsh[0], dsl[0]); split_acc8(ds, 1, dsh[1], dsl[1]);
+            // dV'^T += dO~^T P ; dK'^T += Q''^T dS   (A operands by transpose-reads of the row-major hi and lo images)
+            const uint32_t base = lds_addr(qi) + qb * 32 * CHP * 16;
+            static_for_bwd<DB>([&](auto DC) {
+                constexpr int d = decltype(DC)::value;
+                u32x2_t r_[4][2][2];                          // [image: Qhi, dOhi, Qlo, dOlo][t][half]
+#pragma unroll
+                for (int im = 0; im < 4; ++im) {
+                    const uint32_t a0 = base + im * IMG + voff[d][0], a1 = base + im * IMG + voff[d][1];
+                    r_[im][0][0] = lds_tr16_b64<0>(a0);  r_[im][0][1] = lds_tr16_b64<0>(a1);
+                    r_[im][1][0] = lds_tr16_b64<SL>(a0); r_[im][1][1] = lds_tr16_b64<SL>(a1);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    auto frag = [&](int im) {
+                        const u32x4_t v = {r_[im][t][0].x, r_[im][t][0].y, r_[im][t][1].x, r_[im][t][1].y};
+                        return __builtin_bit_cast(bf16x8_t, v);
+                    };
+                    dv[d] = mfma3(frag(1), frag(3), pfh[t], pfl[t], dv[d]);
+                    dk[d] = mfma3(frag(0), frag(2), dsh[t], dsl[t], dk[d]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+    }
+
+    // ---- epilogue: dk = B_k^T (ln2 dK'), dv = B_k^T dV' ; d trans_coeff through B_k (as bwd_dkv_body, fp32) ----
+    const bool xv = (p.flags & GTA_FLAG_V_TRANSFORM) != 0;
+    const char* kg = (const char*)p.k + ((long)b * p.k_sb + (long)h * p.k_sh) * ESZ;
+    const char* vg = (const char*)p.v + ((long)b * p.v_sb + (long)h * p.v_sh) * ESZ;
+    char* dkg = (char*)p.dk + ((long)b * p.dk_sb + (long)h * p.dk_sh) * ESZ;
+    char* dvg = (char*)p.dv + ((long)b * p.dv_sb + (long)h * p.dv_sh) * ESZ;
+    float* ost = reinterpret_cast<float*>(smem + S::OFF_RING);
+    float dcpart = 0.f;
+#pragma unroll 1
+    for (int which = 0; which < 2; ++which) {            // 0: dK, 1: dV
+        __syncthreads();
+        {
+            const int r = wave * 32 + l31;
+            const float sc = which == 0 ? LN2 : 1.0f;
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x16_t& acc = which == 0 ? dk[d] : dv[d];
+                    const f32x4_t v = {acc[4 * g] * sc, acc[4 * g + 1] * sc, acc[4 * g + 2] * sc, acc[4 * g + 3] * sc};
+                    *reinterpret_cast<f32x4_t*>(ost + r * S::OROW + 32 * d + 8 * g + 4 * lh) = v;
+                }
+        }
+        __syncthreads();
+        const bool xf = which == 0 || xv;
+        const char* rawg = which == 0 ? kg : vg;
+        const long raw_st = (which == 0 ? p.k_st : p.v_st) * ESZ;
+        char* outg = which == 0 ? dkg : dvg;
+        const long out_st = (which == 0 ? p.dk_st : p.dv_st) * ESZ;
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int item = wave + 4 * it;
+            const int c = item >> 1;
+            const int r = lane + 64 * (item & 1);
+            const int t = k0 + r;
+            if (c < ch_real && t < p.Tk) {
+                const uint32_t desc = p.ctab[c];
+                float x[1][8];
+                const f32x4_t a = *reinterpret_cast<const f32x4_t*>(ost + r * S::OROW + 8 * c);
+                const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(ost + r * S::OROW + 8 * c + 4);
+                x[0][0] = a.x; x[0][1] = a.y; x[0][2] = a.z; x[0][3] = a.w;
+                x[0][4] = bb.x; x[0][5] = bb.y; x[0][6] = bb.z; x[0][7] = bb.w;
+                if (desc && xf) {
+                    const int n = view_of(t, p.Pk, p.invPk) - n_first;
+                    const float* rc = rec + n * BREC;
+                    if (!(desc & GTA_CHUNK_SO3) && (cd_lo(desc) == GTA_HALF_SE3 || cd_hi(desc) == GTA_HALF_SE3)) {
+                        float r8[8];
+                        g_load_chunk<ESZ>(rawg + (long)t * raw_st, c, r8);
+                        const float t0 = rc[BREC_T], t1 = rc[BREC_T + 1], t2 = rc[BREC_T + 2];
+                        if (cd_lo(desc) == GTA_HALF_SE3) dcpart += (x[0][0] * t0 + x[0][1] * t1 + x[0][2] * t2) * r8[3];
+                        if (cd_hi(desc) == GTA_HALF_SE3) dcpart += (x[0][4] * t0 + x[0][5] * t1 + x[0][6] * t2) * r8[7];
+                    }
+                    f32x2_t cs[4];
+                    if (p.cs_k) load_cs(desc, p.cs_k + ((long)b * p.Tk + t) * 2 * p.nso2, cs);
+                    chunk_apply<true, 1>(desc, rc + BREC_MT, rc + BREC_D1T, rc + BREC_D2T, cs, x);
+                }
+                g_store_chunk<ESZ>(outg + (long)t * out_st, c, x[0]);
+            }
+        }
+    }
+    const float dc_wg = wg_sum256(dcpart, reinterpret_cast<float*>(smem + S::OFF_SCR), tid);
+    if (tid == 0) p.dc_partial[p.dc_off_dkv + w] = dc_wg;
+}
+
+template <int DHP>
+__global__ __launch_bounds__(256, 2) void gta_bwd_dqkv_x3_kernel(const GtaBwdParams p, const int n_dq) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int L = blockIdx.x, n_dkv = (int)gridDim.x - n_dq;
+    if (L < n_dkv) bwd_dkv_x3_body<DHP>(p, smem, L, n_dkv);
+    else bwd_dq_x3_body<DHP>(p, smem, L - n_dkv, n_dq);
+}
+
+__global__ __launch_bounds__(1024) void gta_reduce_kernel(const float* __restrict__ part, int n, float* __restrict__ out, const float* __restrict__ tau);
+
+template <int DHP>
+int run_bwd_x3(const GtaBwdParams& p, hipStream_t stream) {
+    const int n_qt = (p.Tq + BN - 1) / BN;
+    using PS = BPrepSmem<DHP, 4, true>;
+    if (int rc = gta_lds_optin<&gta_bwd_prep_kernel<DHP, 4, true>>(PS::total(GTA_MAX_VIEWS))) return rc;
+    constexpr int LDS_MAX = DqX3Smem<DHP>::total(GTA_MAX_VIEWS) > DkvX3Smem<DHP>::total(GTA_MAX_VIEWS) ? DqX3Smem<DHP>::total(GTA_MAX_VIEWS) : DkvX3Smem<DHP>::total(GTA_MAX_VIEWS);
+    if (int rc = gta_lds_optin<&gta_bwd_dqkv_x3_kernel<DHP>>(LDS_MAX)) return rc;
+    const long prep_grid = ((long)p.B * n_qt + 7) / 8 * 8 * p.H;
+    const long n_dq = (long)p.B * p.H * ((p.Tq + 127) / 128), n_dkv = (long)p.B * p.H * ((p.Tk + 127) / 128);
+    if (prep_grid > 0x7fffffffL || n_dq + n_dkv > 0x7fffffffL) return GTA_E_UNSUPPORTED;
+    hipLaunchKernelGGL((gta_bwd_prep_kernel<DHP, 4, true>), dim3((unsigned)prep_grid), dim3(256), PS::total(p.vrep_q ? p.Nq : 0), stream, p);
+    const int lds_dq = DqX3Smem<DHP>::total(p.vrep_q ? p.Nq : 0), lds_dkv = DkvX3Smem<DHP>::total(p.vrep_k ? p.Nk : 0);
+    hipLaunchKernelGGL((gta_bwd_dqkv_x3_kernel<DHP>), dim3((unsigned)(n_dq + n_dkv)), dim3(256), lds_dq > lds_dkv ? lds_dq : lds_dkv, stream, p, (int)n_dq);
+    if (p.dtrans_coeff)
+        hipLaunchKernelGGL(gta_reduce_kernel, dim3(1), dim3(1024), 0, stream, p.dc_partial, p.dc_total, p.dtrans_coeff, (const float*)nullptr);
+    if (p.dtau)
+        hipLaunchKernelGGL(gta_reduce_kernel, dim3(1), dim3(1024), 0, stream, p.dt_partial, (int)n_dq, p.dtau, p.tau);
+    return hipGetLastError() == hipSuccess ? GTA_OK : GTA_E_LAUNCH;
+}
+
 template <int DHP, int ESZ>
 int run_bwd(const GtaBwdParams& p, hipStream_t stream) {
     const int n_qt = (p.Tq + BN - 1) / BN;
@@ -1374,7 +1907,13 @@ int run_bwd(const GtaBwdParams& p, hipStream_t stream) {
 
 }  // namespace
 
+// the fp32-faithful backward on the matrix cores exists where the forward's two-stage X3 plan does: fp32 inputs, dh <= 64
+bool gta_bwd_x3_takes(int dhp, int esz) { return esz == 4 && dhp <= 64; }
 int gta_bwd_dispatch(const GtaBwdParams& p, int dhp, int esz, hipStream_t stream) {
+    if (p.flags & GTA_FLAG_FP32_PRODUCTS) {
+        if (!gta_bwd_x3_takes(dhp, esz)) return GTA_E_UNSUPPORTED;
+        return dhp == 32 ? run_bwd_x3<32>(p, stream) : run_bwd_x3<64>(p, stream);
+    }
 #define GTA_CASEB(D) case D: return esz == 2 ? run_bwd<D, 2>(p, stream) : run_bwd<D, 4>(p, stream);
     switch (dhp) {
         GTA_CASEB(32)

@@ -281,8 +281,8 @@ class _GtaAttn(torch.autograd.Function):
             if _GtaAttn.flash_events is not None:
                 _GtaAttn.flash_events[1].record()
         ctx.cfg = cfg
-        # K'/V' tile images of the two-stage plan: reused by the backward (not the split hi / lo images of the fp32-faithful plan)
-        ctx.kv_images = ws if not (flags & native.FLAG_FP32_PRODUCTS) else None
+        # K'/V' tile images of the two-stage plan: reused by the backward (fp32-faithful plan: its hi / lo images by the X3 walks, r06)
+        ctx.kv_images = ws
         ctx.save_for_backward(q, k, v, out, lse, tc, ta, vrep_q, vrep_k, cs_q, cs_k)
         ctx.tc_shape = None if trans_coeff is None else trans_coeff.shape
         ctx.tc_dtype = None if trans_coeff is None else trans_coeff.dtype
@@ -471,6 +471,7 @@ def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: 
              full-image decode, trainer.py:137-181) stream them again without re-running the pre-pass."""
     if scale is None:
         scale = q.shape[-1] ** -0.5
+    explicit_fused = kv_mode == "fused"        # (asked for by name: with precise=True and gradients, the exact-fp32 route of r04 -- see below)
     flags = 0
     if v_transform:
         flags |= native.FLAG_V_TRANSFORM
@@ -536,9 +537,18 @@ def gta_attention(q, k, v, f_dims: Dict[str, int], packed: dict, *, so3_degree: 
         tau = None if float(tau) == 1.0 else torch.tensor([float(tau)], device=q.device, dtype=torch.float32)
     needs_grad = torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in (q, k, v, trans_coeff, tau))
     if precise and needs_grad and not pretransformed:
-        # fp32-faithful TRAINING: rho in fp32 (gta_rep_apply), split-bf16 forward products, EXACT-fp32 backward (gta_plain32.hip) and the
-        # adjoint rho kernels -- the generic path serves every layout that way; inference keeps the fused single-kernel forward below
-        return _generic_forward(q, k, v, f_dims, packed, so3_degree, trans_coeff, tau, scale, v_transform, euclid, precise=True)
+        # fp32-faithful TRAINING.  r06: where the fused kernels have split-bf16 instances on BOTH sides (fp32 inputs at dh <= 64: the two-stage forward
+        # of r05 and the X3 walks of gta_bwd.hip) the call stays on the fused path -- hi / lo images, three MFMAs per product, rho and its adjoint in
+        # fp32 inside the pre-passes and epilogues; the forward's images serve the backward.  Elsewhere: rho in fp32 (gta_rep_apply), split-bf16
+        # plain forward, EXACT-fp32 backward (gta_plain32.hip) and the adjoint rho kernels -- the generic path serves every layout that way.
+        fused_x3 = False
+        if q.is_cuda and q.shape[-1] <= 64 and not euclid and not explicit_fused:
+            qp_, kp_, vp_ = (t if (t.dtype == q.dtype and _kernel_layout_ok(t)) else q.new_empty(t.shape) for t in (q, k, v))
+            probe = native.make_desc(qp_, kp_, vp_, qp_, f_dims, so3_degree, Nq, Nk, scale, flags & ~native.FLAG_FUSED_KV)
+            fused_x3 = native.attn_fwd_supported(probe) == 0 and native.attn_fwd_workspace_bytes(probe) > 0
+        if not fused_x3:
+            return _generic_forward(q, k, v, f_dims, packed, so3_degree, trans_coeff, tau, scale, v_transform, euclid, precise=True)
+        flags &= ~native.FLAG_FUSED_KV                       # (the two-stage plan whatever the number of query rows: its images are the backward's)
     if q.is_cuda and not pretransformed:
         probe = native.make_desc(q, k, v, q, f_dims, so3_degree, Nq, Nk, scale, flags)
         if native.attn_fwd_supported(probe) == -3:       # GTA_E_UNSUPPORTED: valid request, no fused kernel
