@@ -79,15 +79,29 @@ GTA_DEV u32x4_t pack8(const float* x) {
 
 // ---- LDS tile swizzle -----------------------------------------------------------------------
 // A tile is rows x UNITS 16-byte units.  Unit `u` of row `r` lives at position swz<UNITS>(r,u):
-// a per-row ROTATION chosen so that 16 rows distinct mod 16 reading the same logical unit with
-// ds_read_b128 touch 16 distinct 16-B slots of the 256-B bank row (conflict-free both for the
-// lane==row staging reads and for the MFMA fragment reads).  tests/test_host_logic.py brute
-// forces this against the ds_read_b128 lane groups of MI355X_MICROARCH.md.
+// a per-row ROTATION (period 16 rows) chosen so that 16 rows distinct mod 16 reading the same
+// logical unit with ds_read_b128 touch 16 distinct 16-B slots of the 256-B bank row
+// (conflict-free both for the lane==row staging reads and for the MFMA fragment reads).
+// r06: for 8- and 16-unit rows (dh = 64 / 128 images) the rotation's bits are permuted so that
+// the TRANSPOSE reads (ds_read_b64_tr_b16: a 32-lane group covers 4 consecutive rows x 4
+// consecutive units x 2 halves) are conflict-free as well -- with rot = (r >> 1) & 7 rows r and
+// r + 2 of an 8-unit image met in the same banks (PMC: SQ_LDS_BANK_CONFLICT = 33 % of the LDS
+// cycles of the CLEVR-TR attention kernel, two extra cycles per transpose read).
+// tests/test_host_logic.py brute forces both properties against the lane groups of
+// MI355X_MICROARCH.md.
+template <int UNITS>
+GTA_DEV int swz_rot(int r) {
+    if constexpr (UNITS == 8) return 4 * ((r >> 1) & 1) + ((r >> 2) & 3);
+    else if constexpr (UNITS == 16) return 4 * (r & 3) + ((r >> 2) & 3);
+    else {
+        constexpr int tz = (UNITS % 16 == 0) ? 4 : (UNITS % 8 == 0) ? 3 : (UNITS % 4 == 0) ? 2
+                           : (UNITS % 2 == 0) ? 1 : 0;
+        return (r >> (4 - tz)) & ((1 << tz) - 1);
+    }
+}
 template <int UNITS>
 GTA_DEV int swz(int r, int u) {
-    constexpr int tz = (UNITS % 16 == 0) ? 4 : (UNITS % 8 == 0) ? 3 : (UNITS % 4 == 0) ? 2
-                       : (UNITS % 2 == 0) ? 1 : 0;
-    const int rot = (r >> (4 - tz)) & ((1 << tz) - 1);
+    const int rot = swz_rot<UNITS>(r);
     int p = u + rot;
     return p >= UNITS ? p - UNITS : p;
 }

@@ -130,8 +130,7 @@ GTA_DEV void stage_raw_tile(char* smem_raw, const char* gbase, long row_stride_b
         const int r = u / U;
         const int pos = u - r * U;
         // logical unit stored at `pos` of row r: inverse rotation
-        constexpr int tz = (U % 16 == 0) ? 4 : (U % 8 == 0) ? 3 : (U % 4 == 0) ? 2 : (U % 2 == 0) ? 1 : 0;
-        const int rot = (r >> (4 - tz)) & ((1 << tz) - 1);
+        const int rot = swz_rot<U>(r);
         int gu = pos - rot;
         gu = gu < 0 ? gu + U : gu;
         gu = gu < real_units ? gu : real_units - 1;    // padding units: harmless duplicate

@@ -44,7 +44,7 @@ extern thread_local void* gta_dbg_fwd_ev_stop;
 
 namespace {
 
-constexpr int C_NW = 4, C_BM = 128, C_DHP = 64, C_CHP = 8, C_KS = 4, C_DB = 2;
+constexpr int C_BM = 128, C_DHP = 64, C_CHP = 8, C_KS = 4, C_DB = 2;
 constexpr int C_IMG = BN * C_DHP * 2;          // one K' or V' tile image: 8 KiB
 constexpr int C_STAGE = 2 * C_IMG;             // [K' | V']
 constexpr int C_NST = 3;

@@ -135,8 +135,7 @@ __global__ __launch_bounds__(256) void gta_kv_prep_kernel(const GtaFwdParams p) 
         for (int i = 0; i < NI; ++i) {
             const int u0 = (wave * NI + i) * 64, u = u0 + lane;
             const int r = u / U, pos = u - r * U;
-            constexpr int tz = (U % 16 == 0) ? 4 : (U % 8 == 0) ? 3 : (U % 4 == 0) ? 2 : (U % 2 == 0) ? 1 : 0;
-            const int rot = (r >> (4 - tz)) & ((1 << tz) - 1);
+            const int rot = swz_rot<U>(r);
             int gu = pos - rot;
             gu = gu < 0 ? gu + U : gu;
             gu = gu < real_units ? gu : real_units - 1;
