@@ -28,8 +28,10 @@
 #include "gta_fwd_params.h"
 #include "gta_bwd_params.h"
 // The generated statements write M0 (LDS-DMA bases) and name it in their clobber lists; M0 is a reserved register for LLVM, which
-// warns about that by default (the clobber is what keeps a hoisted M0 initialisation of compiler-emitted code from living across them).
-#pragma clang diagnostic ignored "-Winline-asm"
+// warns about that by default (the clobber is what keeps a hoisted M0 initialisation of compiler-emitted code from living across them):
+// GTA_ASM_M0_BEGIN / _END silence -Winline-asm around those statements only -- every hand-written asm of this file keeps its diagnostics.
+#define GTA_ASM_M0_BEGIN _Pragma("clang diagnostic push") _Pragma("clang diagnostic ignored \"-Winline-asm\"")
+#define GTA_ASM_M0_END _Pragma("clang diagnostic pop")
 #include "../../include/gta_hip.h"
 
 namespace {
@@ -1043,7 +1045,9 @@ GTA_DEV void bwd_dkv64_body(const GtaBwdParams& p, char* smem, const int L, cons
         }
         // the accumulators are OUTPUTS of the statement, by register: dK'^T[kb][d] = a[16 (3 kb + d) ..], dV'^T[kb][d] = a[96 + 16 (3 kb + d) ..]
         // (GTA_BWD64_DKV_RESULTS, gen_bwd64.py) -- hipcc knows they live there and reads them out itself where the epilogue wants them
+        GTA_ASM_M0_BEGIN
         asm volatile(GTA_BWD64_DKV : GTA_BWD64_DKV_RESULTS : GTA_BWD64_DKV_OPERANDS : GTA_BWD64_DKV_CLOBBERS);
+        GTA_ASM_M0_END
     }
 
     // ---- epilogue: dk = B_k^T (ln2 dK'), dv = B_k^T dV' ; d trans_coeff through B_k.  No staging: lane (key l31, half lh) of a 32-key
@@ -1225,7 +1229,9 @@ GTA_DEV void bwd_dq64_body(const GtaBwdParams& p, char* smem, const int L, const
             }
         }
         // (the accumulators are outputs of the statement: dQ'^T[rb][d] = a[16 (3 rb + d) ..], GTA_BWD64_DQ_RESULTS)
+        GTA_ASM_M0_BEGIN
         asm volatile(GTA_BWD64_DQ : GTA_BWD64_DQ_RESULTS : GTA_BWD64_DQ_OPERANDS : GTA_BWD64_DQ_CLOBBERS);
+        GTA_ASM_M0_END
     }
 
     // ---- epilogue: dq = A_q^T (c1 dQ') ; d trans_coeff through A_q.  As gta_bwd_dkv64_kernel's: lane (row l31, half lh) of a 32-row block holds

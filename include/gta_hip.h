@@ -55,7 +55,7 @@ extern "C" {
 #define GTA_FLAG_BWD_KEYS64    (1u << 14) /* tuning / diagnostics (gta_attn_bwd): run that stream at bf16, dh = 96 whatever the number of blocks    */
 #define GTA_FLAG_BWD_SPLIT     (1u << 15) /* tuning / diagnostics (gta_attn_bwd): the dQ and dK/dV kernels as two launches (per-kernel times under a profiler)     */
                                           /* where one joint launch would run; same results bit for bit                                                         */
-#define GTA_FLAG_FWD2_GENERIC  (1u << 6) /* tuning / diagnostics (r06): keep gta_fwd2_kernel where the dh = 64 instance gta_fwdc_kernel (gta_fwd_cl.hip) would run */
+#define GTA_FLAG_FWD2_GENERIC  (1u << 6) /* tuning / diagnostics (r06): keep gta_fwd2_kernel where the dh = 64 instance of gta_fwd_cl.hip (gta_fwdc_kernel) would run */
 #define GTA_FLAG_NO_DMA        (1u << 8) /* debug: stage K/V tiles through VGPRs, not LDS-DMA  */
 
 /* error codes */

@@ -20,7 +20,7 @@ rnd = os.environ.get("ROUND", "r05")
 src = os.path.join(ROOT, "gpurun_out", "pmc_" + wl, "summary_kernels.json")
 dst = os.path.join(ROOT, "profiles", rnd)
 k = json.load(open(src))
-name = max((n for n in k if "SQ_INSTS_MFMA" in k[n] and ("gta_fwd2_kernel" in n or "gta_attn64" in n)), key=lambda n: k[n]["pct_of_gpu_time"])
+name = max((n for n in k if "SQ_INSTS_MFMA" in k[n] and ("gta_fwd2_kernel" in n or "gta_fwdc_kernel" in n or "gta_attn64" in n)), key=lambda n: k[n]["pct_of_gpu_time"])
 d = k[name]
 simd = d["SQ_BUSY_CYCLES"] / 32.0
 H, Nq, Pq, Nk, Pk, f_dims, so2, so3, B = bench.WORKLOADS[wl]
