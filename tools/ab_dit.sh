@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for rep in 1 2; do for m in prepass prepass_rows32; do
+for rep in 1 2; do for m in ${MODES:-prepass prepass_rows32}; do
 python bench.py --workload dit --kv-mode $m --no-cpu-baseline --block-steps 0 --train-steps 0 --workloads none --no-parity --steps 50 --warmup 10 2>/dev/null | python -c "
 import sys,json
 d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); r=d.get('roofline') or {}
