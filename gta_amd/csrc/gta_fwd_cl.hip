@@ -37,7 +37,8 @@ extern thread_local void* gta_dbg_fwd_ev_start;      // gta_fwd2.hip: events for
 extern thread_local void* gta_dbg_fwd_ev_stop;
 
 // timing-only ablations of the development builds (tools/_ab_fwdc.sh: -DGTA_FWDC_ABL=<bits>; wrong results): 1 no tile barrier, 2 no softmax
-// vector work, 4 no matrix instructions, 8 no LDS reads, 16 no tile DMA, 32 no rho_q arithmetic, 64 no epilogue arithmetic
+// vector work, 4 no matrix instructions, 8 no LDS reads, 16 no tile DMA, 32 no rho_q arithmetic, 64 no epilogue arithmetic; 512 (correct results)
+// fragment-direct item I/O instead of the coalesced form
 #ifndef GTA_FWDC_ABL
 #define GTA_FWDC_ABL 0
 #endif
@@ -162,6 +163,26 @@ GTA_DEV void c_pv(const u32x2_t (&vl)[C_DB], const u32x2_t (&vh)[C_DB], const bf
 }
 GTA_DEV void c_ready(u32x2_t (&vl)[C_DB], u32x2_t (&vh)[C_DB]) { asm volatile("" : "+v"(vl[0]), "+v"(vh[0]), "+v"(vl[1]), "+v"(vh[1])); }
 
+// COAL: the wave's 32 rows of a [rows x 128 B] array (Q rows, (cos, sin) rows) -> 4 KiB of LDS at `lds` by LDS-DMA, four 1-KiB accesses (lane ->
+// row 8 i + (lane >> 3), position lane & 7); the per-lane SOURCE unit carries the inverse of the images' 8-unit rotation, so the rows lie in
+// LDS as a tile image's do (conflict-free fragment reads: swz<8>).  `row0` = first row, rows clamped to n_rows - 1, `stride` in bytes.
+GTA_DEV void c_dma_rows32(uint32_t lds, const char* base, int row0, int n_rows, unsigned stride, int lane) {
+    const int rr = lane >> 3, pos = lane & 7;
+    unsigned vo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int t = row0 + 8 * i + rr;
+        t = t < n_rows ? t : n_rows - 1;
+        const int gu = (pos - swz_rot<C_CHP>(8 * i + rr)) & 7;
+        vo[i] = (unsigned)t * stride + (unsigned)gu * 16u;
+    }
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5"
+                 ::"s"(lds), "v"(vo[0]), "v"(vo[1]), "v"(vo[2]), "v"(vo[3]), "s"(base) : "memory", "scc");
+}
+
 // kernel arguments through laundered pointers to the kernarg segment, one per code region (gta_fwd2.hip: with by-value access hipcc keeps every
 // field the item loop touches in an SGPR across the tile loop and spills them into VGPR lanes)
 typedef const __attribute__((address_space(4))) GtaFwdParams* CArgs;
@@ -176,6 +197,7 @@ __global__ __launch_bounds__(256, 3) void gta_fwdc_kernel(const GtaFwdParams p_k
     static_assert(LAYOUT == GTA_LAYOUT_CL || LAYOUT == GTA_LAYOUT_SO2, "dh = 64 layouts");
     constexpr int NSE3 = LAYOUT == GTA_LAYOUT_CL ? 4 : 0;          // chunks 0 .. NSE3-1 are se3 chunks, the rest so2 chunks
     constexpr int NSO = C_CHP - NSE3;
+    constexpr bool COAL = LAYOUT == GTA_LAYOUT_CL && !(GTA_FWDC_ABL & 512);                 // coalesced item I/O through LDS (below); the pure-so2 layout's 256-B (cos, sin) rows do not fit the scratch
     extern __shared__ __attribute__((aligned(16))) char smem[];
     CArgs pp = c_kargs();
     const int tid = threadIdx.x;
@@ -222,15 +244,35 @@ __global__ __launch_bounds__(256, 3) void gta_fwdc_kernel(const GtaFwdParams p_k
         const char* knext = kimg + 2 * C_STAGE;                    // image of the next tile to request (tile 2)
 
         // ---- every load of the prologue is requested up front ----
+        // COAL (the CLEVR-TR layout: 128-B Q rows, 128-B (cos, sin) rows): the wave's 32 rows travel as four 1-KiB accesses each (lane -> row
+        // 8 i + (lane >> 3), 16-B unit lane & 7) and change hands in LDS.  A fragment-direct access (lane = row) touches 32 cache lines with
+        // 32 B each; the twelve waves of a CU issue 20 of them per item each, and the tile DMAs queue behind them in the same address path:
+        // timing-only builds with coalesced (wrong) addresses ran cl-dec in 87-89 us against 98-104 (profiles/r06/README.md section 1).
+        // Scratch: ring stage 2 -- free from the item's start until step 0 requests tile 2 behind its barrier -- 4 KiB per wave, rows in the
+        // images' own 8-unit rotation (conflict-free fragment reads); Q first, then the (cos, sin) rows through the same 4 KiB.
         u32x4_t qraw[C_KS];
-        {
+        f32x4_t qcs[C_KS - NSE3 / 2][2];
+        if constexpr (COAL) {
+            // Q rows: LDS-DMA into ring stage 2 (4 KiB per wave), requested right behind the tiles; fragments read back below
+            c_dma_rows32(ring + 2 * C_STAGE + wave * 4096, (const char*)pp->q + ((long)b * pp->q_sb + (long)h * pp->q_sh) * 2, q0 + wave * 32, pp->Tq,
+                         (unsigned)pp->q_st * 2u, lane);
+            // (cos, sin) rows: fragment-direct as before (the prologue has one free ring stage: rho_q^-1's copies travel by DMA in the last tile step)
+            const float* csrow = pp->cs_q + ((long)b * pp->Tq + my_t) * 2 * pp->nso2;
+#pragma unroll
+            for (int ks = NSE3 / 2; ks < C_KS; ++ks) {
+                const float* cp = csrow + 8 * (2 * ks + lh - NSE3);
+                qcs[ks - NSE3 / 2][0] = *reinterpret_cast<const f32x4_t*>(cp);
+                qcs[ks - NSE3 / 2][1] = *reinterpret_cast<const f32x4_t*>(cp + 4);
+            }
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // the tiles and the Q rows have landed; the four (cos, sin) loads may still fly
+            const char* sc = smem + 2 * C_STAGE + wave * 4096;
+#pragma unroll
+            for (int ks = 0; ks < C_KS; ++ks) qraw[ks] = *reinterpret_cast<const u32x4_t*>(sc + (l31 * C_CHP + swz<C_CHP>(l31, 2 * ks + lh)) * 16);
+        } else {
             const char* qrow = (const char*)pp->q + ((long)b * pp->q_sb + (long)h * pp->q_sh + (long)my_t * pp->q_st) * 2 + lh * 16;
 #pragma unroll
             for (int ks = 0; ks < C_KS; ++ks) qraw[ks] = *reinterpret_cast<const u32x4_t*>(qrow + ks * 32);
-        }
-        // (cos, sin) of the lane's so2 chunks 2 ks + lh, ks >= NSE3 / 2: blocks 4 (c - NSE3) .. + 3
-        f32x4_t qcs[C_KS - NSE3 / 2][2];
-        {
+            // (cos, sin) of the lane's so2 chunks 2 ks + lh, ks >= NSE3 / 2: blocks 4 (c - NSE3) .. + 3
             const float* csrow = pp->cs_q + ((long)b * pp->Tq + my_t) * 2 * pp->nso2;
 #pragma unroll
             for (int ks = NSE3 / 2; ks < C_KS; ++ks) {
@@ -356,6 +398,16 @@ __global__ __launch_bounds__(256, 3) void gta_fwdc_kernel(const GtaFwdParams p_k
             if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             if (!(GTA_FWDC_ABL & 1)) __builtin_amdgcn_s_barrier();
+            if constexpr (COAL) {
+                if (last) {
+                    // the item's (cos, sin) rows for rho_q^-1 -> this step's request slot (stage STN), by DMA: no register lives through the step
+                    CArgs pp = c_kargs();
+                    unsigned zc;
+                    asm volatile("s_mov_b32 %0, 0" : "=s"(zc));
+                    const int lane_c = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zc));
+                    c_dma_rows32(ring + STN * C_STAGE + wave * 4096, (const char*)(pp->cs_q + (long)b * pp->Tq * 32), q0 + wave * 32, pp->Tq, 128u, lane_c);
+                }
+            }
             if (j + 2 < n_tiles && !(GTA_FWDC_ABL & 16)) {
                 // (the lane's DMA offset is re-derived per step from nothing -- v_mbcnt on a zero that an asm statement pins inside the step: three
                 //  instructions, and neither it nor the thread id lives through the loop)
@@ -484,7 +536,19 @@ __global__ __launch_bounds__(256, 3) void gta_fwdc_kernel(const GtaFwdParams p_k
             // (cos, sin) of the half-chunks the epilogue rotates: half lh of so2 chunk c -> blocks 4 (c - NSE3) + 2 lh, + 1  (requested here: inside the
             // last tile step the 16 registers spill the step's own state -- tried)
             f32x4_t ocs[NSO];
-            {
+            // COAL: the epilogue's scratch is the two ring stages the last tile does not use -- every wave is past the last step's barrier, i.e.
+            // done with the two tiles before the last one; the next item's first requests wait for the barrier at its top.  O goes through
+            // stage n_tiles % 3
+            char* const sce = smem + (n_tiles % C_NST) * C_STAGE + wave * 4096;
+            const int rr = lane_e >> 3, ru = lane_e & 7;
+            if constexpr (COAL) {
+                // the (cos, sin) rows came by DMA in the last tile step (stage (n_tiles + 1) % 3: that step's request slot)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const char* scs = smem + ((n_tiles + 1) % C_NST) * C_STAGE + wave * 4096;
+                const int l31e = lane_e & 31;
+#pragma unroll
+                for (int i = 0; i < NSO; ++i) ocs[i] = *reinterpret_cast<const f32x4_t*>(scs + (l31e * C_CHP + swz<C_CHP>(l31e, 2 * i + lh)) * 16);
+            } else {
                 const float* csrow = pp->cs_q + ((long)b * pp->Tq + my_t) * 2 * pp->nso2;
 #pragma unroll
                 for (int i = 0; i < NSO; ++i) ocs[i] = *reinterpret_cast<const f32x4_t*>(csrow + 8 * i + 4 * lh);
@@ -532,7 +596,23 @@ __global__ __launch_bounds__(256, 3) void gta_fwdc_kernel(const GtaFwdParams p_k
                     o[c][2] = cs.z * a1 + cs.w * b1; o[c][3] = cs.z * b1 - cs.w * a1;
                 }
             }
-            if (rowok) {
+            if constexpr (COAL) {
+                // the lane's eight 8-byte half-chunks -> its row of the scratch (behind the (cos, sin) reads: LDS serves a wave in order), then the
+                // wave's 32 rows out in four 1-KiB stores
+                const int l31e = lane_e & 31;
+#pragma unroll
+                for (int c = 0; c < C_CHP; ++c) {
+                    u32x2_t wv;
+                    wv.x = pack_bf16x2(o[c][0], o[c][1]); wv.y = pack_bf16x2(o[c][2], o[c][3]);
+                    *reinterpret_cast<u32x2_t*>(sce + (l31e * C_CHP + swz<C_CHP>(l31e, c)) * 16 + lh * 8) = wv;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int t = q0 + wave * 32 + 8 * i + rr;
+                    const u32x4_t wv = *reinterpret_cast<const u32x4_t*>(sce + ((8 * i + rr) * C_CHP + swz<C_CHP>(8 * i + rr, ru)) * 16);
+                    if (t < pp->Tq) *reinterpret_cast<u32x4_t*>((char*)pp->o + ((long)b * pp->o_sb + (long)h * pp->o_sh + (long)t * pp->o_st) * 2 + ru * 16) = wv;
+                }
+            } else if (rowok) {
                 char* orow = (char*)pp->o + ((long)b * pp->o_sb + (long)h * pp->o_sh + (long)tE * pp->o_st) * 2 + lh * 8;
 #pragma unroll
                 for (int c = 0; c < C_CHP; ++c) {
