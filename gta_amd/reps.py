@@ -32,10 +32,22 @@ def _check(attn_kwargs):
     f = attn_kwargs["f_dims"]
     if attn_kwargs.get("ray_to_se3", False):
         raise NotImplementedError("ray_to_se3 is dead code in the reference (ray2rotation is undefined)")
-    for key in ("zeroout_so3", "id_so3"):
-        if attn_kwargs.get(key, False):
-            raise NotImplementedError(f"{key} ablation is not built")
     return f
+
+
+def _so3_override(attn_kwargs, vrep, L):
+    """encoder.py:250-258 / decoder.py:337-345: ``zeroout_so3`` replaces every D^l of the freshly built view records by zeros, ``id_so3``
+    (checked second, as in the reference) by identities.  ``vrep`` [B, N, VREP_STRIDE] is the builder's own output (nothing else holds it yet)."""
+    if L <= 0 or not (attn_kwargs.get("zeroout_so3", False) or attn_kwargs.get("id_so3", False)):
+        return vrep
+    import torch
+    blocks = ((native.VREP_D1, 3), (native.VREP_D2, 5))[:L]
+    for off, n in blocks:
+        if attn_kwargs.get("zeroout_so3", False):
+            vrep[..., off:off + n * n] = 0.0
+        else:
+            vrep[..., off:off + n * n] = torch.eye(n, device=vrep.device, dtype=vrep.dtype).reshape(n * n)
+    return vrep
 
 
 def _flattened(vrep, cs, T):
@@ -65,12 +77,12 @@ def pre_compute_reps_encoder(attn_kwargs: dict, extras: dict) -> dict:
         vrep, cs = native.build_reps(extras["input_transforms"], L, c, attn_kwargs["so2"], attn_kwargs["max_freq_h"],
                                      attn_kwargs["max_freq_w"], attn_kwargs.get("shared_freqs", False))
         extras["gta_cs_q"] = extras["gta_cs_k"] = cs
-        extras["gta_vrep_q"] = extras["gta_vrep_k"] = vrep
+        extras["gta_vrep_q"] = extras["gta_vrep_k"] = _so3_override(attn_kwargs, vrep, L)
         extras["gta_so3_degree"] = L
     elif f.get("so2", 0) > 0:
         extras["gta_cs_q"] = extras["gta_cs_k"] = _so2(attn_kwargs, extras["input_coord"])
     elif need_view:
-        extras["gta_vrep_q"] = extras["gta_vrep_k"] = native.build_view_reps(extras["input_transforms"], L)
+        extras["gta_vrep_q"] = extras["gta_vrep_k"] = _so3_override(attn_kwargs, native.build_view_reps(extras["input_transforms"], L), L)
         extras["gta_so3_degree"] = L
     if f.get("t2", 0) > 0:                            # encoder.py:208-215: T2 reps are the raw token coordinates
         c = extras["input_coord"]
@@ -92,8 +104,8 @@ def pre_compute_reps_decoder(attn_kwargs: dict, extras: dict) -> dict:
             extras["gta_cs_k"] = _so2(attn_kwargs, extras["input_coord"])
     if f.get("se3", 0) > 0 or f.get("so3", 0) > 0:
         L = attn_kwargs.get("so3", 0) if f.get("so3", 0) > 0 else 0
-        extras["gta_vrep_q"] = native.build_view_reps(extras["target_transforms"], L)
-        if "gta_vrep_k" not in extras:
+        extras["gta_vrep_q"] = _so3_override(attn_kwargs, native.build_view_reps(extras["target_transforms"], L), L)
+        if "gta_vrep_k" not in extras:                # (decoder.py:300-303 rebuilds only se3rep_k here; the so3 key side is the encoder's)
             extras["gta_vrep_k"] = native.build_view_reps(extras["input_transforms"], L)
         extras["gta_so3_degree"] = L
     if f.get("t2", 0) > 0:                            # decoder.py:283-290: q side only

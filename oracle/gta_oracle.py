@@ -190,6 +190,16 @@ def build_view_reps(transforms: torch.Tensor, so3_degree: int = 0, wigner: str =
     return se3rep, transforms, Ds
 
 
+def _so3_override(attn_kwargs: dict, Ds: List[torch.Tensor]) -> List[torch.Tensor]:
+    """The two so3 ablation knobs of the rep builders (encoder.py:250-258, decoder.py:337-345): ``zeroout_so3`` replaces every D^l by
+    zeros, ``id_so3`` (checked second) by identities; otherwise D^l as computed."""
+    if attn_kwargs.get("zeroout_so3", False):
+        return [torch.zeros_like(D) for D in Ds]
+    if attn_kwargs.get("id_so3", False):
+        return [torch.eye(D.shape[-1], dtype=D.dtype, device=D.device).expand_as(D).clone() for D in Ds]
+    return Ds
+
+
 def encoder_reps(attn_kwargs: dict, extras: dict, wigner: str = "euler") -> dict:
     """Self-attention reps: q-side == k-side (encoder.py:183-265).  Returns a new dict."""
     f = attn_kwargs["f_dims"]
@@ -216,7 +226,7 @@ def encoder_reps(attn_kwargs: dict, extras: dict, wigner: str = "euler") -> dict
             reps["se3rep_q"] = reps["se3rep_k"] = se3rep
             reps["inv_se3rep_q"] = inv
         if need_so3:
-            reps["so3rep_q"] = reps["so3rep_k"] = Ds
+            reps["so3rep_q"] = reps["so3rep_k"] = _so3_override(attn_kwargs, Ds)
     return reps
 
 
@@ -253,7 +263,7 @@ def decoder_reps(attn_kwargs: dict, extras: dict, enc_reps: dict, wigner: str = 
             if "se3rep_k" not in reps:
                 reps["se3rep_k"] = torch.linalg.inv(extras["input_transforms"])
         if need_so3:
-            reps["so3rep_q"] = Ds
+            reps["so3rep_q"] = _so3_override(attn_kwargs, Ds)
     return reps
 
 
