@@ -680,7 +680,9 @@ bool gta_fwdc_takes(const GtaFwdParams& p, int dhp, int layout, int esz) {
     const long n_items = (long)p.B * p.H * ((p.Tq + C_BM - 1) / C_BM);
     return dhp == 64 && p.dh == 64 && esz == 2 && (layout == GTA_LAYOUT_CL || layout == GTA_LAYOUT_SO2) && p.cs_q != nullptr && p.kn != nullptr &&
            (layout != GTA_LAYOUT_CL || p.vrep_q != nullptr) && !(p.flags & (GTA_FLAG_FP32_PRODUCTS | GTA_FLAG_FWD2_GENERIC)) && n_tiles >= 2 &&
-           n_tiles <= C_MAX_TILES && n_items < (1L << 22) && p.Tq < (1 << 22) && p.nso2 == (layout == GTA_LAYOUT_CL ? 16 : 32);
+           n_tiles <= C_MAX_TILES && n_items < (1L << 22) && p.Tq < (1 << 22) && p.nso2 == (layout == GTA_LAYOUT_CL ? 16 : 32) &&
+           // (the coalesced item I/O of the CLEVR-TR layout addresses a (b,h)'s Q rows and a scene's (cos, sin) rows with 32-bit byte offsets)
+           (layout != GTA_LAYOUT_CL || ((long)p.Tq * p.q_st * 2 < (1L << 31) && (long)p.Tq * 128 < (1L << 31)));
 }
 int gta_fwdc_dispatch(const GtaFwdParams& p, int layout, hipStream_t stream) {
     return layout == GTA_LAYOUT_CL ? launch_fwdc<GTA_LAYOUT_CL>(p, stream) : launch_fwdc<GTA_LAYOUT_SO2>(p, stream);
