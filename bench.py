@@ -51,6 +51,9 @@ WORKLOADS = {
     "cl-enc": (6, 2, 300, 2, 300, {"se3": 32, "so2": 32}, 8, 0, 32),
     "cl-dec": (6, 3, 853, 2, 300, {"se3": 32, "so2": 32}, 8, 0, 32),
     "dit": (16, 1, 1024, 1, 1024, {"so2": 64}, 16, 0, 32),
+    # not BASELINE configs, not in the default line (`--workload` only): the MSN runs without the so3 slab (runs/msn/GTA/gta: se3 48 | so2 48)
+    "ms-gta-enc": (8, 5, 256, 5, 256, {"triv": 0, "se3": 48, "so2": 48}, 12, 0, 32),
+    "ms-gta-dec": (8, 5, 512, 5, 256, {"triv": 0, "se3": 48, "so2": 48}, 12, 0, 32),
 }
 
 

@@ -912,8 +912,8 @@ int gta_fwd2_lds_bytes(int dhp, int nrec) {
 static int layout_of(const GtaFwdParams& p, int dhp) {
     const int ch = p.dh / 8;
     if (p.dh != dhp) return GTA_LAYOUT_GENERIC;
-    for (int L : {GTA_LAYOUT_MS, GTA_LAYOUT_CL, GTA_LAYOUT_SO2}) {
-        if ((L == GTA_LAYOUT_MS && dhp != 96) || (L == GTA_LAYOUT_CL && dhp != 64)) continue;
+    for (int L : {GTA_LAYOUT_MS, GTA_LAYOUT_MSG, GTA_LAYOUT_CL, GTA_LAYOUT_SO2}) {
+        if (((L == GTA_LAYOUT_MS || L == GTA_LAYOUT_MSG) && dhp != 96) || (L == GTA_LAYOUT_CL && dhp != 64)) continue;
         bool same = true;
         for (int c = 0; c < ch; ++c) same = same && p.ctab[c] == gta_layout_desc(L, c);
         if (same) return L;
@@ -962,7 +962,8 @@ int gta_fwd2_dispatch(GtaFwdParams& p, int dhp, int esz, bool run_prep, bool run
     p.nrec = 128 / p.Pq + 2 < p.Nq ? 128 / p.Pq + 2 : p.Nq;
     int rc = GTA_OK;
     // the q-side rep tiles (rho_q / rho_q^-1 on the matrix cores) only where the 64-rows-per-wave kernel will use them
-    if (!(p.qtiles && esz == 2 && run_flash && gta_attn64_takes(p, dhp, layout_of(p, dhp), esz))) p.qtiles = nullptr;
+    // (the operand tiles are the MSN gta_so3 layout's: GTA_LAYOUT_MS)
+    if (!(p.qtiles && esz == 2 && run_flash && layout_of(p, dhp) == GTA_LAYOUT_MS && gta_attn64_takes(p, dhp, GTA_LAYOUT_MS, esz))) p.qtiles = nullptr;
     if (run_prep) rc = gta_prep_dispatch(p, dhp, esz, stream);
     else if (p.qtiles) rc = gta_qtiles_dispatch(p, stream);
     if (rc != GTA_OK || !run_flash) return rc;
