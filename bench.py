@@ -54,6 +54,7 @@ WORKLOADS = {
     # not BASELINE configs, not in the default line (`--workload` only): the MSN runs without the so3 slab (runs/msn/GTA/gta: se3 48 | so2 48)
     "ms-gta-enc": (8, 5, 256, 5, 256, {"triv": 0, "se3": 48, "so2": 48}, 12, 0, 32),
     "ms-gta-dec": (8, 5, 512, 5, 256, {"triv": 0, "se3": 48, "so2": 48}, 12, 0, 32),
+    "ms-se3-enc": (8, 5, 256, 5, 256, {"se3": 96}, 0, 0, 32),        # the encoder of runs/msn/GTA/gta_no2demb
 }
 
 

@@ -50,6 +50,7 @@ GTA_DEV uint32_t cd_so2_hi(uint32_t d) { return (d >> 16) & 0xffu; }  // first s
 #define GTA_LAYOUT_CL 2      // dh 64: se3 32 | so2 32                  runs/clevrtr/GTA/gta/config.yaml
 #define GTA_LAYOUT_SO2 3     // pure so2 (any dh): 2-D GTA / *_no3demb configs
 #define GTA_LAYOUT_MSG 4     // dh 96: se3 48 | so2 48                  runs/msn/GTA/{gta,gta_novtrnsfm,gta_sharedfreqs}, the decoders of gta_no2demb / gta_no3demb
+#define GTA_LAYOUT_SE3 5     // se3 only (dh 96 instance)               runs/msn/GTA/gta_no2demb (encoder)
 __host__ __device__ constexpr uint32_t gta_so2_desc(int first_block) {
     return GTA_HALF_SO2 | (GTA_HALF_SO2 << 2) | ((uint32_t)first_block << 8) | ((uint32_t)(first_block + 2) << 16);
 }
@@ -57,6 +58,7 @@ __host__ __device__ constexpr uint32_t gta_layout_desc(int layout, int c) {
     return layout == GTA_LAYOUT_MS ? (c < 6 ? (GTA_HALF_SE3 | (GTA_HALF_SE3 << 2)) : c < 9 ? GTA_CHUNK_SO3 : gta_so2_desc(4 * (c - 9)))
          : layout == GTA_LAYOUT_CL ? (c < 4 ? (GTA_HALF_SE3 | (GTA_HALF_SE3 << 2)) : gta_so2_desc(4 * (c - 4)))
          : layout == GTA_LAYOUT_MSG ? (c < 6 ? (GTA_HALF_SE3 | (GTA_HALF_SE3 << 2)) : gta_so2_desc(4 * (c - 6)))
+         : layout == GTA_LAYOUT_SE3 ? (GTA_HALF_SE3 | (GTA_HALF_SE3 << 2))
          : gta_so2_desc(4 * c);
 }
 

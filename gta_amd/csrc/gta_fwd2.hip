@@ -912,8 +912,8 @@ int gta_fwd2_lds_bytes(int dhp, int nrec) {
 static int layout_of(const GtaFwdParams& p, int dhp) {
     const int ch = p.dh / 8;
     if (p.dh != dhp) return GTA_LAYOUT_GENERIC;
-    for (int L : {GTA_LAYOUT_MS, GTA_LAYOUT_MSG, GTA_LAYOUT_CL, GTA_LAYOUT_SO2}) {
-        if (((L == GTA_LAYOUT_MS || L == GTA_LAYOUT_MSG) && dhp != 96) || (L == GTA_LAYOUT_CL && dhp != 64)) continue;
+    for (int L : {GTA_LAYOUT_MS, GTA_LAYOUT_MSG, GTA_LAYOUT_SE3, GTA_LAYOUT_CL, GTA_LAYOUT_SO2}) {
+        if (((L == GTA_LAYOUT_MS || L == GTA_LAYOUT_MSG || L == GTA_LAYOUT_SE3) && dhp != 96) || (L == GTA_LAYOUT_CL && dhp != 64)) continue;
         bool same = true;
         for (int c = 0; c < ch; ++c) same = same && p.ctab[c] == gta_layout_desc(L, c);
         if (same) return L;
