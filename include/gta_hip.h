@@ -171,6 +171,11 @@ int64_t gta_attn_fwd_workspace_bytes(const GtaAttnDesc* desc);
  *            = -(1/tau) sum_i <q'_i, dq'_i> = -(1/tau) sum_i <q_i, dq_i>  (rho_q is linear): it falls out of
  *            the dQ kernel's epilogue, no extra pass over the tiles.
  *   No gradient is produced for the reps/poses (gta.py:194-198 detaches them; poses are data).
+ *   GTA_FLAG_FP32_PRODUCTS (r06; fp32 inputs, dh <= 64; other sizes: GTA_E_UNSUPPORTED -> gta_rep_apply + gta_attn_bwd_plain_f32): the fp32-faithful
+ *            backward on the matrix cores -- every product of the five contractions as three bf16 MFMAs over hi / lo operand images (the
+ *            arithmetic of the forward under the same flag); kv_images must then be the workspace of a forward run WITH the flag (four
+ *            images per tile) or NULL; the workspace is twice as large (gta_attn_bwd_workspace_bytes depends on desc->flags); dtau is formed
+ *            in the dQ walk as sum_ij dS_ij (S_ij - m_i), m_i = sum_j P_ij S_ij (centred per row: DESIGN.md section 4.6).
  * ------------------------------------------------------------------------------------------- */
 int64_t gta_attn_bwd_workspace_bytes(const GtaAttnDesc* desc);
 int gta_attn_bwd(const GtaAttnDesc* desc,
