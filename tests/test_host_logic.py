@@ -650,5 +650,6 @@ def test_bench_host_helpers():
     n = bench.precondition(lambda: calls.append(1), 0.05, chunk=7)
     assert n == len(calls) and n % 7 == 0 and n >= 7 and time.perf_counter() - t0 >= 0.05
     assert bench.precondition(lambda: calls.append(1), 0.0) == 0
-    assert set(bench.WORKLOADS) == {"ms-enc", "ms-dec", "cl-enc", "cl-dec", "dit"}
+    # the five BASELINE workloads (the default line times exactly these) + the `--workload`-only MSN layouts without the so3 slab (r06)
+    assert set(bench.WORKLOADS) == {"ms-enc", "ms-dec", "cl-enc", "cl-dec", "dit", "ms-gta-enc", "ms-gta-dec", "ms-se3-enc"}
     assert os.environ.get("OMP_WAIT_POLICY") == "PASSIVE"
