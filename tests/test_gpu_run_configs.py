@@ -141,3 +141,50 @@ def test_run_config_forward_backward_vs_oracle(run, side):
                     pq, pk, pv = (t * (1 + (torch.rand(t.shape, generator=gp) - 0.5) * 2.0 ** -8) for t in (qq, kk, vv))
                     slack = max(slack, abs(float(_oracle(pq, pk, pv, w, ex, enc, dec, side, 0.37, scale)[4].item()) - r))
             assert abs(g_ - r) <= (5e-2 if not precise else tol_c) * max(1.0, abs(r)) + 3.0 * slack, (run, side, dtype, precise, "dtrans_coeff", g_, r, slack)
+
+
+@pytest.mark.parametrize("side", ["enc", "dec"])
+@pytest.mark.parametrize("run", sorted(RUNS))
+def test_run_config_transformer_module_vs_oracle(run, side):
+    """The same 17 configs one level up (layers.py:172-488): a one-layer `Transformer` built from the config's `attn_args` exactly as the
+    reference builds it (self-attention for the encoder, cross-attention over `z` for the decoder), the oracle module's weights loaded
+    `strict=True`, y and dx against the oracle module in fp64."""
+    dh, mixed, enc, dec = RUNS[run]
+    args = enc if side == "enc" else dec
+    dim, kv = 64, (None if side == "enc" else 48)
+    aa = {"method": {"name": "gta", "args": dict(args)}}
+    torch.manual_seed(sum(map(ord, run)) + 7 * (side == "dec"))
+    ref = O.OracleTransformer(dim, 1, H, dh, 2 * dim, 0.0, side == "enc", kv, False, aa).double()
+    tr = gta_amd.Transformer(dim, 1, H, dh, 2 * dim, 0.0, side == "enc", kv, False, aa)
+    tr.load_state_dict({k: v.float() for k, v in ref.state_dict().items()}, strict=True)
+    tr = tr.cuda()
+    g = torch.Generator().manual_seed(3 + sum(map(ord, run)))
+    from gta_amd import synth
+    ex = {"input_transforms": synth.random_extrinsics(B, NV, g), "input_coord": torch.rand(B, NV, P_ENC, 2, generator=g)}
+    Tk = NV * P_ENC
+    if side == "dec":
+        ex["target_transforms"] = synth.random_extrinsics(B, NQ, g)
+        ex["target_coord"] = torch.rand(B, NQ, P_DEC, 2, generator=g)
+    Tq = Tk if side == "enc" else NQ * P_DEC
+    x = torch.randn(B, Tq, dim, generator=g)
+    z = None if side == "enc" else torch.randn(B, Tk, kv, generator=g)
+    w = torch.randn(B, Tq, dim, generator=g)
+    ex64 = {kk: vv.double() for kk, vv in ex.items()}
+    reps = O.encoder_reps(enc, ex64)
+    if side == "dec":
+        reps = O.decoder_reps(dec, ex64, reps)
+    xo = x.double().requires_grad_()
+    yo = ref(xo, None if z is None else z.double(), reps)
+    (yo * w.double()).sum().backward()
+    exd = {kk: vv.cuda() for kk, vv in ex.items()}
+    gta_amd.pre_compute_reps_encoder(enc, exd)
+    if side == "dec":
+        gta_amd.pre_compute_reps_decoder(dec, exd)
+    xd = x.cuda().requires_grad_()
+    yd = tr(xd, None if z is None else z.cuda(), exd)
+    (yd * w.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    st = C.err_stats(yd.detach().float().cpu(), yo.detach().float())
+    assert st["finite"] and st["rel_rms"] < 1e-2 and st["max_abs"] < 3e-2 * st["ref_max"], (run, side, "y", st)
+    st = C.err_stats(xd.grad.float().cpu(), xo.grad.float())
+    assert st["finite"] and st["rel_rms"] < 3e-2, (run, side, "dx", st)
