@@ -23,6 +23,8 @@ CL = ("CL", {"se3": 32, "so2": 32}, 8, 0)
 DT = ("DT", {"so2": 64}, 16, 0)
 MIX = ("MIX", {"triv": 8, "se3": 16, "so2": 8}, 2, 0)          # dh = 32
 WIDE = ("WIDE", {"se3": 64, "so2": 64}, 16, 0)                  # dh = 128
+MSG = ("MSG", {"triv": 0, "se3": 48, "so2": 48}, 12, 0)         # r06: the MSN runs without the so3 slab
+SE3 = ("SE3", {"se3": 96}, 0, 0)                                # r06: the gta_no2demb encoder
 
 
 def stats(a, b):
@@ -36,7 +38,7 @@ def main():
     random.seed(seed)
     bad = 0
     for it in range(count):
-        name, f_dims, so2, so3 = random.choice([MS, MS, CL, CL, DT, DT, MIX, WIDE])
+        name, f_dims, so2, so3 = random.choice([MS, MS, CL, CL, DT, DT, MIX, WIDE, MSG, MSG, SE3])
         one_view = name == "DT"
         Nk = 1 if one_view else random.choice([1, 2, 3, 5])
         Pk = random.choice([24, 64, 75, 128, 150, 256, 300])
